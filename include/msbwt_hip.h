@@ -1,0 +1,133 @@
+/*
+ * msbwt_hip.h -- C ABI of the MI355X (gfx950) implementation of rust-msbwt's RleBWT
+ * count_kmer / constrain_range path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.  Each
+ * entry point names the reference interface it replaces (file:line relative to the
+ * reference repo root).  The Rust side a maintainer would add -- `impl BWT for GpuRleBWT`
+ * over these symbols -- is shown in INTEGRATION.md.
+ *
+ * Every query entry point runs on the GPU.  There is no CPU fallback: when no HIP device
+ * is usable the calls return MSBWT_ERR_HIP.
+ *
+ * Threading: query calls on a loaded handle may be made from several host threads (they
+ * serialise on the handle's stream); load calls need exclusive access, like `&mut self`
+ * in the reference.
+ */
+#ifndef MSBWT_HIP_H
+#define MSBWT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* src/msbwt_core.rs:3-14 */
+#define MSBWT_VC_LEN 6      /* $ A C G N T */
+#define MSBWT_LETTER_BITS 3
+#define MSBWT_NUMBER_BITS 5
+#define MSBWT_NUM_POWER 32
+#define MSBWT_MASK 0x07
+#define MSBWT_COUNT_MASK 0x1F
+
+/* Return codes.  The reference reports file problems as io::Error and panics on malformed
+ * headers / symbols >= 6; nothing unwinds across this ABI, so both become codes that the
+ * Rust shim maps back. */
+#define MSBWT_OK 0
+#define MSBWT_ERR_IO (-1)              /* io::Error from open/metadata/read            */
+#define MSBWT_ERR_UNEXPECTED_EOF (-2)  /* io::ErrorKind::UnexpectedEof (size mismatch) */
+#define MSBWT_ERR_BAD_HEADER (-3)      /* reference panics (rle_bwt.rs:91-93,115,123-125) */
+#define MSBWT_ERR_INVALID_SYMBOL (-4)  /* reference panics (msbwt_core.rs:127, rle_bwt.rs:212) */
+#define MSBWT_ERR_INVALID_RANGE (-5)   /* l > h or h > total (reference: OOB panic / underflow) */
+#define MSBWT_ERR_HIP (-6)             /* HIP runtime error or no usable device         */
+#define MSBWT_ERR_NOT_LOADED (-7)
+#define MSBWT_ERR_TOO_LARGE (-8)       /* total symbols >= 2^40 (device block counts are 40-bit) */
+#define MSBWT_ERR_INVALID_ARG (-9)
+
+typedef struct msbwt_rle msbwt_rle; /* opaque; replaces `struct RleBWT` (src/rle_bwt.rs:14-24) */
+
+/* RleBWT::with_bin_power (src/rle_bwt.rs:309-322); RleBWT::new() == bin_power 8 (:297).
+ * bin_power is accepted for interface compatibility; results never depend on it (the
+ * device index always uses its own fixed block size).  `device` is the HIP ordinal, -1 =
+ * the current device.  Returns NULL when out of memory. */
+msbwt_rle *msbwt_rle_new(uint8_t bin_power);
+msbwt_rle *msbwt_rle_new_on_device(uint8_t bin_power, int device);
+void msbwt_rle_free(msbwt_rle *bwt);
+
+/* BWT::load_vector (src/msbwt_core.rs:43, src/rle_bwt.rs:59-66).  Copies: the caller keeps
+ * (or drops) its Vec<u8>. */
+int msbwt_rle_load_vector(msbwt_rle *bwt, const uint8_t *rle_bytes, size_t len);
+/* BWT::load_numpy_file (src/msbwt_core.rs:58, src/rle_bwt.rs:81-155). */
+int msbwt_rle_load_numpy_file(msbwt_rle *bwt, const char *utf8_path);
+/* BWT::get_symbol_count (src/msbwt_core.rs:75, src/rle_bwt.rs:172-175); 0 if symbol >= 6 */
+uint64_t msbwt_rle_get_symbol_count(const msbwt_rle *bwt, uint8_t symbol);
+/* BWT::get_total_size (src/msbwt_core.rs:90, src/rle_bwt.rs:190-193) */
+uint64_t msbwt_rle_get_total_size(const msbwt_rle *bwt);
+/* BWT::constrain_range (src/msbwt_core.rs:99, src/rle_bwt.rs:202-287).  BWTRange is not
+ * repr(C), so l/h travel as scalars. */
+int msbwt_rle_constrain_range(const msbwt_rle *bwt, uint8_t sym, uint64_t l, uint64_t h,
+                              uint64_t *out_l, uint64_t *out_h);
+/* BWT::count_kmer (src/msbwt_core.rs:124-161).  kmer: k symbol codes 0..5. */
+int msbwt_rle_count_kmer(const msbwt_rle *bwt, const uint8_t *kmer, size_t k, uint64_t *out_count);
+
+/* ---- batch extensions: the GPU entry points proper (the reference has no batch API; each
+ * element is exactly one count_kmer / constrain_range call) ---- */
+/* kmers: n x k row-major, one byte per symbol (codes 0..5); out_counts: n.  Host pointers. */
+int msbwt_rle_count_kmers(const msbwt_rle *bwt, const uint8_t *kmers, size_t k, size_t n,
+                          uint64_t *out_counts);
+int msbwt_rle_constrain_ranges(const msbwt_rle *bwt, const uint8_t *syms, const uint64_t *l,
+                               const uint64_t *h, size_t n, uint64_t *out_l, uint64_t *out_h);
+/* Same, with DEVICE pointers on the handle's device; asynchronous on `hip_stream` (a
+ * hipStream_t, NULL = default stream).  Invalid input is reported by
+ * msbwt_rle_device_status(), which synchronises the stream. */
+int msbwt_rle_count_kmers_device(const msbwt_rle *bwt, const void *d_kmers, size_t k, size_t n,
+                                 void *d_out_counts, void *hip_stream);
+int msbwt_rle_constrain_ranges_device(const msbwt_rle *bwt, const void *d_syms, const void *d_l,
+                                      const void *d_h, size_t n, void *d_out_l, void *d_out_h,
+                                      void *hip_stream);
+int msbwt_rle_device_status(const msbwt_rle *bwt, void *hip_stream);
+
+/* ---- tuning / introspection (no reference counterpart) ---- */
+/* Depth of the precomputed suffix table (the reference's stubbed kmer_cache,
+ * src/msbwt_core.rs:133-146): ranges for every ACGT suffix of length `depth` are computed
+ * on the device at load time and replace the first `depth` steps of each query.  0 turns it
+ * off.  Takes effect immediately if an index is loaded.  Results never change. */
+int msbwt_rle_set_table_depth(msbwt_rle *bwt, int depth);
+int msbwt_rle_get_table_depth(const msbwt_rle *bwt);
+/* Bytes of HBM held by the index (blocks + table). */
+uint64_t msbwt_rle_device_bytes(const msbwt_rle *bwt);
+/* Average duration in ms of the count kernel launches since the last reset, measured with
+ * HIP events on the launch stream (bench.py's roofline uses it); resets the accumulator. */
+int msbwt_rle_kernel_time_ms(const msbwt_rle *bwt, double *avg_ms, uint64_t *launches);
+int msbwt_rle_set_kernel_timing(msbwt_rle *bwt, int enabled);
+int msbwt_rle_device_ordinal(const msbwt_rle *bwt);
+const char *msbwt_rle_last_error(const msbwt_rle *bwt);
+/* Host half of the load path, exposed for inspection (no device needed): expands an RLE
+ * stream into the plane blocks the kernels read (layout: rust-msbwt_amd/csrc/plane_index.hpp).
+ * Returns the number of 128-byte blocks (= total/256 + 1); writes at most `cap_blocks` of
+ * them to out_blocks (may be NULL), the symbol total to *out_total. SIZE_MAX on bad input. */
+size_t msbwt_build_plane_blocks(const uint8_t *rle_bytes, size_t len, void *out_blocks, size_t cap_blocks,
+                                uint64_t *out_total);
+const char *msbwt_version(void);
+
+/* ---- codecs either side of the path ---- */
+/* convert_to_vec (src/bwt_converter.rs:26-80): ASCII "$ACGNT" (+ '\n', ignored) -> RLE
+ * bytes.  Returns the number of bytes needed/written; out may be NULL to size.  Returns
+ * SIZE_MAX for a byte outside the alphabet (the reference panics). */
+size_t msbwt_convert_to_vec(const uint8_t *ascii, size_t n, uint8_t *out, size_t cap);
+/* save_bwt_numpy (src/bwt_converter.rs:102-130): 96-byte NumPy v1.0 header + payload */
+int msbwt_save_bwt_numpy(const uint8_t *rle_bytes, size_t n, const char *utf8_path);
+/* save_bwt_runs_numpy (src/bwt_converter.rs:151-184) */
+int msbwt_save_bwt_runs_numpy(const uint8_t *syms, const uint64_t *counts, size_t nruns,
+                              const char *utf8_path);
+/* string_util (src/string_util.rs:3-88) */
+void msbwt_convert_stoi(const uint8_t *ascii, size_t n, uint8_t *out_codes);
+void msbwt_convert_itos(const uint8_t *codes, size_t n, uint8_t *out_ascii);
+void msbwt_reverse_complement_i(const uint8_t *codes, size_t n, uint8_t *out_codes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

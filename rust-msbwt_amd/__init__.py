@@ -1,0 +1,22 @@
+"""rust-msbwt_amd -- MI355X-native batched k-mer counting over a run-length-encoded
+multi-string BWT: the `RleBWT::count_kmer` path of HudsonAlpha/rust-msbwt, rebuilt for
+gfx950 behind the reference's own interface.
+
+The directory name carries a hyphen (it is fixed by the project layout), so import it with
+    import importlib; msbwt = importlib.import_module("rust-msbwt_amd")
+or through the `rust_msbwt_amd` alias module at the repo root.
+
+Modules mirror the reference crate: msbwt_core (BWTRange, constants, BWT), rle_bwt (RleBWT),
+string_util, bwt_converter.  Everything that computes runs in libmsbwt_hip.so.
+"""
+from . import _lib
+from .msbwt_core import BWT, BWTRange, VC_LEN, LETTER_BITS, NUMBER_BITS, NUM_POWER, MASK, COUNT_MASK
+from .rle_bwt import RleBWT, MsbwtError
+from . import string_util, bwt_converter, msbwt_core, rle_bwt
+
+__all__ = ["BWT", "BWTRange", "RleBWT", "MsbwtError", "string_util", "bwt_converter", "msbwt_core",
+           "rle_bwt", "VC_LEN", "LETTER_BITS", "NUMBER_BITS", "NUM_POWER", "MASK", "COUNT_MASK"]
+
+
+def version():
+    return _lib.lib().msbwt_version().decode()

@@ -1,0 +1,70 @@
+"""ctypes binding of libmsbwt_hip.so (include/msbwt_hip.h).  No fallback: if the library is
+missing this raises, telling the caller to build it."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmsbwt_hip.so")
+
+OK = 0
+ERR_IO, ERR_UNEXPECTED_EOF, ERR_BAD_HEADER, ERR_INVALID_SYMBOL = -1, -2, -3, -4
+ERR_INVALID_RANGE, ERR_HIP, ERR_NOT_LOADED, ERR_TOO_LARGE, ERR_INVALID_ARG = -5, -6, -7, -8, -9
+
+SIZE_MAX = C.c_size_t(-1).value
+
+# every symbol include/msbwt_hip.h declares: name -> (restype, argtypes)
+_vp, _u8, _u64, _sz, _int = C.c_void_p, C.c_uint8, C.c_uint64, C.c_size_t, C.c_int
+_pu64 = C.POINTER(C.c_uint64)
+SIGNATURES = {
+    "msbwt_rle_new": (_vp, [_u8]),
+    "msbwt_rle_new_on_device": (_vp, [_u8, _int]),
+    "msbwt_rle_free": (None, [_vp]),
+    "msbwt_rle_load_vector": (_int, [_vp, _vp, _sz]),
+    "msbwt_rle_load_numpy_file": (_int, [_vp, C.c_char_p]),
+    "msbwt_rle_get_symbol_count": (_u64, [_vp, _u8]),
+    "msbwt_rle_get_total_size": (_u64, [_vp]),
+    "msbwt_rle_constrain_range": (_int, [_vp, _u8, _u64, _u64, _pu64, _pu64]),
+    "msbwt_rle_count_kmer": (_int, [_vp, _vp, _sz, _pu64]),
+    "msbwt_rle_count_kmers": (_int, [_vp, _vp, _sz, _sz, _vp]),
+    "msbwt_rle_constrain_ranges": (_int, [_vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "msbwt_rle_count_kmers_device": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "msbwt_rle_constrain_ranges_device": (_int, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "msbwt_rle_device_status": (_int, [_vp, _vp]),
+    "msbwt_rle_set_table_depth": (_int, [_vp, _int]),
+    "msbwt_rle_get_table_depth": (_int, [_vp]),
+    "msbwt_rle_device_bytes": (_u64, [_vp]),
+    "msbwt_rle_kernel_time_ms": (_int, [_vp, C.POINTER(C.c_double), _pu64]),
+    "msbwt_rle_set_kernel_timing": (_int, [_vp, _int]),
+    "msbwt_rle_device_ordinal": (_int, [_vp]),
+    "msbwt_rle_last_error": (C.c_char_p, [_vp]),
+    "msbwt_version": (C.c_char_p, []),
+    "msbwt_build_plane_blocks": (_sz, [_vp, _sz, _vp, _sz, _pu64]),
+    "msbwt_convert_to_vec": (_sz, [_vp, _sz, _vp, _sz]),
+    "msbwt_save_bwt_numpy": (_int, [_vp, _sz, C.c_char_p]),
+    "msbwt_save_bwt_runs_numpy": (_int, [_vp, _vp, _sz, C.c_char_p]),
+    "msbwt_convert_stoi": (None, [_vp, _sz, _vp]),
+    "msbwt_convert_itos": (None, [_vp, _sz, _vp]),
+    "msbwt_reverse_complement_i": (None, [_vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+class MsbwtLibraryMissing(ImportError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MsbwtLibraryMissing(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib

@@ -1,0 +1,487 @@
+// extern "C" boundary (include/msbwt_hip.h): handle management, load path, batch plumbing.
+// The query work itself is in kernels.hip; nothing here computes a rank on the CPU.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/msbwt_hip.h"
+#include "kernels.hpp"
+#include "npy_io.hpp"
+#include "plane_index.hpp"
+#include "rle_codec.hpp"
+
+using namespace msbwt;
+
+struct msbwt_rle {
+    int device = 0;
+    uint8_t bin_power = 8;
+    bool loaded = false;
+    Totals totals{};
+    void *d_blocks = nullptr;
+    uint64_t nblocks = 0;
+    void *d_table = nullptr;
+    int table_depth = 0;         // depth of the table currently in HBM
+    int wanted_table_depth = -1; // -1 = pick from the index size
+    uint32_t *d_flags = nullptr;
+    hipStream_t stream = nullptr;  // used by the host-pointer entry points
+    void *d_stage = nullptr;
+    size_t stage_bytes = 0;
+    bool timing = false;
+    std::vector<hipEvent_t> events;  // start/stop pairs not yet read back
+    double timed_ms = 0.0;
+    uint64_t timed_launches = 0;
+    std::mutex mu;
+    std::string err;
+};
+
+namespace {
+
+const char *kVersion = "rust-msbwt_amd 0.1.0 (gfx950 plane-block index)";
+
+// Makes the handle's device current for the scope, restoring the caller's afterwards (the
+// caller may be a torch process with its own current device).
+class DeviceScope {
+  public:
+    explicit DeviceScope(int device) {
+        ok_ = hipGetDevice(&prev_) == hipSuccess;
+        if (ok_ && prev_ != device) ok_ = hipSetDevice(device) == hipSuccess, switched_ = ok_;
+    }
+    ~DeviceScope() {
+        if (switched_) (void)hipSetDevice(prev_);
+    }
+    bool ok() const { return ok_; }
+
+  private:
+    int prev_ = 0;
+    bool ok_ = false, switched_ = false;
+};
+
+int fail(msbwt_rle *h, int code, const std::string &msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+int hip_fail(msbwt_rle *h, hipError_t e, const char *what) {
+    return fail(h, MSBWT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(h, expr)                                      \
+    do {                                                      \
+        hipError_t e_ = (expr);                               \
+        if (e_ != hipSuccess) return hip_fail(h, e_, #expr);  \
+    } while (0)
+
+void release_index(msbwt_rle *h) {
+    if (h->d_blocks) (void)hipFree(h->d_blocks);
+    if (h->d_table) (void)hipFree(h->d_table);
+    h->d_blocks = h->d_table = nullptr;
+    h->nblocks = 0;
+    h->table_depth = 0;
+    h->loaded = false;
+}
+
+IndexView view_of(const msbwt_rle *h) {
+    IndexView v;
+    v.blocks = h->d_blocks;
+    v.nblocks = h->nblocks;
+    v.total = h->totals.total;
+    v.table.entries = h->d_table;
+    v.table.depth = h->d_table ? h->table_depth : 0;
+    return v;
+}
+
+int ensure_runtime(msbwt_rle *h) {
+    if (!h->stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    if (!h->d_flags) {
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_flags), sizeof(uint32_t)));
+        HIP_TRY(h, hipMemset(h->d_flags, 0, sizeof(uint32_t)));
+    }
+    return MSBWT_OK;
+}
+
+int ensure_stage(msbwt_rle *h, size_t bytes) {
+    if (bytes <= h->stage_bytes) return MSBWT_OK;
+    if (h->d_stage) (void)hipFree(h->d_stage);
+    h->d_stage = nullptr;
+    h->stage_bytes = 0;
+    HIP_TRY(h, hipMalloc(&h->d_stage, bytes));
+    h->stage_bytes = bytes;
+    return MSBWT_OK;
+}
+
+// Chooses the suffix-table depth: deep enough to skip the cache-friendly top of the search,
+// small enough (<= 64 MiB) to stay resident in the 256 MiB Infinity Cache next to the hot
+// blocks, and never deeper than the data warrants (4^depth <= total).
+int auto_table_depth(uint64_t total) {
+    int d = 0;
+    while (d < 11 && (4ull << (2 * d)) <= total) ++d;
+    return d;
+}
+
+int rebuild_table(msbwt_rle *h) {
+    if (h->d_table) (void)hipFree(h->d_table);
+    h->d_table = nullptr;
+    h->table_depth = 0;
+    int depth = h->wanted_table_depth < 0 ? auto_table_depth(h->totals.total) : h->wanted_table_depth;
+    if (depth <= 0) return MSBWT_OK;
+    const size_t bytes = (size_t(1) << (2 * depth)) * 16;
+    void *tab = nullptr;
+    HIP_TRY(h, hipMalloc(&tab, bytes));
+    IndexView v = view_of(h);
+    hipError_t e = launch_build_table(v, depth, tab, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(tab);
+        if (e == hipErrorNotSupported) return MSBWT_OK;  // kernel set without a table
+        return hip_fail(h, e, "build suffix table");
+    }
+    h->d_table = tab;
+    h->table_depth = depth;
+    return MSBWT_OK;
+}
+
+// Common tail of both load entry points: totals, plane blocks, upload, table.
+int install(msbwt_rle *h, const uint8_t *rle, size_t n) {
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, "no usable HIP device");
+    release_index(h);
+    Totals t;
+    if (!compute_totals(rle, n, &t)) return fail(h, MSBWT_ERR_INVALID_SYMBOL, "RLE stream holds a symbol code >= 6");
+    if (t.total > kMaxTotal) return fail(h, MSBWT_ERR_TOO_LARGE, "BWT has 2^40 symbols or more");
+    int rc = ensure_runtime(h);
+    if (rc) return rc;
+    const uint64_t nblocks = plane_block_count(t.total);
+    const size_t bytes = size_t(nblocks) * kBlockBytes;
+    uint32_t *host = nullptr;
+    // pinned staging so the upload runs at PCIe rate; fall back to pageable memory
+    const bool pinned = hipHostMalloc(reinterpret_cast<void **>(&host), bytes, hipHostMallocDefault) == hipSuccess;
+    if (!pinned) {
+        host = static_cast<uint32_t *>(std::malloc(bytes));
+        if (!host) return fail(h, MSBWT_ERR_IO, "out of host memory while building the index");
+    }
+    build_plane_blocks(rle, n, t, host, 0);
+    hipError_t e = hipMalloc(&h->d_blocks, bytes);
+    if (e == hipSuccess) e = hipMemcpy(h->d_blocks, host, bytes, hipMemcpyHostToDevice);
+    if (pinned) (void)hipHostFree(host);
+    else std::free(host);
+    if (e != hipSuccess) {
+        release_index(h);
+        return hip_fail(h, e, "upload index");
+    }
+    h->totals = t;
+    h->nblocks = nblocks;
+    h->loaded = true;
+    rc = rebuild_table(h);
+    if (rc) {
+        release_index(h);
+        return rc;
+    }
+    h->err.clear();
+    return MSBWT_OK;
+}
+
+int read_flags(msbwt_rle *h, hipStream_t stream, uint32_t *flags) {
+    HIP_TRY(h, hipMemcpyAsync(flags, h->d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_flags, 0, sizeof(uint32_t), stream));
+    HIP_TRY(h, hipStreamSynchronize(stream));
+    return MSBWT_OK;
+}
+
+int flags_to_code(msbwt_rle *h, uint32_t flags) {
+    if (flags & kFlagInvalidSymbol) return fail(h, MSBWT_ERR_INVALID_SYMBOL, "a query holds a symbol code >= 6");
+    if (flags & kFlagInvalidRange) return fail(h, MSBWT_ERR_INVALID_RANGE, "a range has l > h or h > total size");
+    return MSBWT_OK;
+}
+
+int launch_count(msbwt_rle *h, const uint8_t *d_kmers, size_t k, size_t n, uint64_t *d_out, hipStream_t stream) {
+    if (k > 0xFFFFFFFFull) return fail(h, MSBWT_ERR_INVALID_ARG, "k does not fit 32 bits");
+    hipEvent_t start = nullptr, stop = nullptr;
+    if (h->timing) {
+        HIP_TRY(h, hipEventCreate(&start));
+        HIP_TRY(h, hipEventCreate(&stop));
+        HIP_TRY(h, hipEventRecord(start, stream));
+    }
+    HIP_TRY(h, launch_count_kmers(view_of(h), d_kmers, uint32_t(k), n, d_out, h->d_flags, stream));
+    if (h->timing) {
+        HIP_TRY(h, hipEventRecord(stop, stream));
+        h->events.push_back(start);
+        h->events.push_back(stop);
+    }
+    return MSBWT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *msbwt_version(void) { return kVersion; }
+
+msbwt_rle *msbwt_rle_new_on_device(uint8_t bin_power, int device) {
+    msbwt_rle *h = new (std::nothrow) msbwt_rle();
+    if (!h) return nullptr;
+    h->bin_power = bin_power;
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;
+    h->device = device;
+    if (const char *env = std::getenv("MSBWT_TABLE_DEPTH")) h->wanted_table_depth = std::atoi(env);
+    return h;
+}
+
+msbwt_rle *msbwt_rle_new(uint8_t bin_power) { return msbwt_rle_new_on_device(bin_power, -1); }
+
+void msbwt_rle_free(msbwt_rle *h) {
+    if (!h) return;
+    {
+        DeviceScope scope(h->device);
+        release_index(h);
+        for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+        if (h->d_stage) (void)hipFree(h->d_stage);
+        if (h->d_flags) (void)hipFree(h->d_flags);
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+    }
+    delete h;
+}
+
+int msbwt_rle_load_vector(msbwt_rle *h, const uint8_t *rle_bytes, size_t len) {
+    if (!h || (!rle_bytes && len)) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    return install(h, rle_bytes, len);
+}
+
+int msbwt_rle_load_numpy_file(msbwt_rle *h, const char *utf8_path) {
+    if (!h || !utf8_path) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    std::vector<uint8_t> payload;
+    std::string msg;
+    switch (read_npy_payload(utf8_path, &payload, &msg)) {
+        case NpyStatus::kOk: break;
+        case NpyStatus::kIo: return fail(h, MSBWT_ERR_IO, msg);
+        case NpyStatus::kUnexpectedEof: return fail(h, MSBWT_ERR_UNEXPECTED_EOF, msg);
+        case NpyStatus::kBadHeader: return fail(h, MSBWT_ERR_BAD_HEADER, msg);
+    }
+    return install(h, payload.data(), payload.size());
+}
+
+uint64_t msbwt_rle_get_symbol_count(const msbwt_rle *h, uint8_t symbol) {
+    return (h && symbol < kAlphabet) ? h->totals.symbol_counts[symbol] : 0;
+}
+
+uint64_t msbwt_rle_get_total_size(const msbwt_rle *h) { return h ? h->totals.total : 0; }
+
+int msbwt_rle_count_kmers_device(const msbwt_rle *ch, const void *d_kmers, size_t k, size_t n,
+                                 void *d_out_counts, void *hip_stream) {
+    msbwt_rle *h = const_cast<msbwt_rle *>(ch);
+    if (!h) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!h->loaded) return fail(h, MSBWT_ERR_NOT_LOADED, "no BWT loaded");
+    if (n && (!d_out_counts || (!d_kmers && k))) return fail(h, MSBWT_ERR_INVALID_ARG, "null device pointer");
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, "no usable HIP device");
+    return launch_count(h, static_cast<const uint8_t *>(d_kmers), k, n, static_cast<uint64_t *>(d_out_counts),
+                        static_cast<hipStream_t>(hip_stream));
+}
+
+int msbwt_rle_constrain_ranges_device(const msbwt_rle *ch, const void *d_syms, const void *d_l, const void *d_h,
+                                      size_t n, void *d_out_l, void *d_out_h, void *hip_stream) {
+    msbwt_rle *h = const_cast<msbwt_rle *>(ch);
+    if (!h) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!h->loaded) return fail(h, MSBWT_ERR_NOT_LOADED, "no BWT loaded");
+    if (n && (!d_syms || !d_l || !d_h || !d_out_l || !d_out_h)) return fail(h, MSBWT_ERR_INVALID_ARG, "null device pointer");
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, "no usable HIP device");
+    HIP_TRY(h, launch_constrain_ranges(view_of(h), static_cast<const uint8_t *>(d_syms),
+                                       static_cast<const uint64_t *>(d_l), static_cast<const uint64_t *>(d_h), n,
+                                       static_cast<uint64_t *>(d_out_l), static_cast<uint64_t *>(d_out_h),
+                                       h->d_flags, static_cast<hipStream_t>(hip_stream)));
+    return MSBWT_OK;
+}
+
+int msbwt_rle_device_status(const msbwt_rle *ch, void *hip_stream) {
+    msbwt_rle *h = const_cast<msbwt_rle *>(ch);
+    if (!h) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!h->d_flags) return MSBWT_OK;
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, "no usable HIP device");
+    uint32_t flags = 0;
+    int rc = read_flags(h, static_cast<hipStream_t>(hip_stream), &flags);
+    return rc ? rc : flags_to_code(h, flags);
+}
+
+int msbwt_rle_count_kmers(const msbwt_rle *ch, const uint8_t *kmers, size_t k, size_t n, uint64_t *out_counts) {
+    msbwt_rle *h = const_cast<msbwt_rle *>(ch);
+    if (!h) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!h->loaded) return fail(h, MSBWT_ERR_NOT_LOADED, "no BWT loaded");
+    if (n && (!out_counts || (!kmers && k))) return fail(h, MSBWT_ERR_INVALID_ARG, "null pointer");
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, "no usable HIP device");
+    // bounded staging: chunks of up to 4 Mi queries travel host -> HBM -> host
+    const size_t chunk = std::min<size_t>(n, size_t(1) << 22);
+    const size_t kmer_bytes = (chunk * k + 15) / 16 * 16;
+    int rc = ensure_stage(h, kmer_bytes + chunk * sizeof(uint64_t) + 16);
+    if (rc) return rc;
+    uint8_t *d_k = static_cast<uint8_t *>(h->d_stage);
+    uint64_t *d_c = reinterpret_cast<uint64_t *>(d_k + kmer_bytes);
+    uint32_t all_flags = 0;
+    for (size_t done = 0; done < n; done += chunk) {
+        const size_t m = std::min(chunk, n - done);
+        if (k) HIP_TRY(h, hipMemcpyAsync(d_k, kmers + done * k, m * k, hipMemcpyHostToDevice, h->stream));
+        rc = launch_count(h, d_k, k, m, d_c, h->stream);
+        if (rc) return rc;
+        HIP_TRY(h, hipMemcpyAsync(out_counts + done, d_c, m * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+        uint32_t flags = 0;
+        rc = read_flags(h, h->stream, &flags);
+        if (rc) return rc;
+        all_flags |= flags;
+    }
+    return flags_to_code(h, all_flags);
+}
+
+int msbwt_rle_constrain_ranges(const msbwt_rle *ch, const uint8_t *syms, const uint64_t *l, const uint64_t *hh,
+                               size_t n, uint64_t *out_l, uint64_t *out_h) {
+    msbwt_rle *h = const_cast<msbwt_rle *>(ch);
+    if (!h) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!h->loaded) return fail(h, MSBWT_ERR_NOT_LOADED, "no BWT loaded");
+    if (n && (!syms || !l || !hh || !out_l || !out_h)) return fail(h, MSBWT_ERR_INVALID_ARG, "null pointer");
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, "no usable HIP device");
+    const size_t chunk = std::min<size_t>(n, size_t(1) << 22);
+    const size_t sym_bytes = (chunk + 15) / 16 * 16;
+    int rc = ensure_stage(h, sym_bytes + 4 * chunk * sizeof(uint64_t));
+    if (rc) return rc;
+    uint8_t *d_s = static_cast<uint8_t *>(h->d_stage);
+    uint64_t *d_l = reinterpret_cast<uint64_t *>(d_s + sym_bytes);
+    uint64_t *d_h = d_l + chunk, *d_ol = d_h + chunk, *d_oh = d_ol + chunk;
+    uint32_t all_flags = 0;
+    for (size_t done = 0; done < n; done += chunk) {
+        const size_t m = std::min(chunk, n - done);
+        HIP_TRY(h, hipMemcpyAsync(d_s, syms + done, m, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(d_l, l + done, m * 8, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(d_h, hh + done, m * 8, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, launch_constrain_ranges(view_of(h), d_s, d_l, d_h, m, d_ol, d_oh, h->d_flags, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(out_l + done, d_ol, m * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(out_h + done, d_oh, m * 8, hipMemcpyDeviceToHost, h->stream));
+        uint32_t flags = 0;
+        rc = read_flags(h, h->stream, &flags);
+        if (rc) return rc;
+        all_flags |= flags;
+    }
+    return flags_to_code(h, all_flags);
+}
+
+int msbwt_rle_constrain_range(const msbwt_rle *h, uint8_t sym, uint64_t l, uint64_t hh, uint64_t *out_l,
+                              uint64_t *out_h) {
+    if (!out_l || !out_h) return MSBWT_ERR_INVALID_ARG;
+    return msbwt_rle_constrain_ranges(h, &sym, &l, &hh, 1, out_l, out_h);
+}
+
+int msbwt_rle_count_kmer(const msbwt_rle *h, const uint8_t *kmer, size_t k, uint64_t *out_count) {
+    if (!out_count) return MSBWT_ERR_INVALID_ARG;
+    return msbwt_rle_count_kmers(h, kmer, k, 1, out_count);
+}
+
+int msbwt_rle_set_table_depth(msbwt_rle *h, int depth) {
+    if (!h || depth > 13) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->wanted_table_depth = depth;
+    if (!h->loaded) return MSBWT_OK;
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, "no usable HIP device");
+    return rebuild_table(h);
+}
+
+int msbwt_rle_get_table_depth(const msbwt_rle *h) { return h ? h->table_depth : 0; }
+
+uint64_t msbwt_rle_device_bytes(const msbwt_rle *h) {
+    if (!h || !h->loaded) return 0;
+    return h->nblocks * kBlockBytes + (h->d_table ? (uint64_t(16) << (2 * h->table_depth)) : 0);
+}
+
+int msbwt_rle_set_kernel_timing(msbwt_rle *h, int enabled) {
+    if (!h) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->timing = enabled != 0;
+    return MSBWT_OK;
+}
+
+int msbwt_rle_kernel_time_ms(const msbwt_rle *ch, double *avg_ms, uint64_t *launches) {
+    msbwt_rle *h = const_cast<msbwt_rle *>(ch);
+    if (!h) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, "no usable HIP device");
+    for (size_t i = 0; i + 1 < h->events.size(); i += 2) {
+        float ms = 0.f;
+        HIP_TRY(h, hipEventSynchronize(h->events[i + 1]));
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->events[i], h->events[i + 1]));
+        h->timed_ms += ms;
+        h->timed_launches += 1;
+        (void)hipEventDestroy(h->events[i]);
+        (void)hipEventDestroy(h->events[i + 1]);
+    }
+    h->events.clear();
+    if (avg_ms) *avg_ms = h->timed_launches ? h->timed_ms / double(h->timed_launches) : 0.0;
+    if (launches) *launches = h->timed_launches;
+    h->timed_ms = 0.0;
+    h->timed_launches = 0;
+    return MSBWT_OK;
+}
+
+int msbwt_rle_device_ordinal(const msbwt_rle *h) { return h ? h->device : -1; }
+
+const char *msbwt_rle_last_error(const msbwt_rle *h) { return h ? h->err.c_str() : "null handle"; }
+
+size_t msbwt_build_plane_blocks(const uint8_t *rle_bytes, size_t len, void *out_blocks, size_t cap_blocks,
+                                uint64_t *out_total) {
+    Totals t;
+    if ((!rle_bytes && len) || !compute_totals(rle_bytes, len, &t) || t.total > kMaxTotal) return SIZE_MAX;
+    if (out_total) *out_total = t.total;
+    const uint64_t nblocks = plane_block_count(t.total);
+    if (out_blocks && cap_blocks >= nblocks) build_plane_blocks(rle_bytes, len, t, static_cast<uint32_t *>(out_blocks), 0);
+    return size_t(nblocks);
+}
+
+size_t msbwt_convert_to_vec(const uint8_t *ascii, size_t n, uint8_t *out, size_t cap) {
+    std::vector<uint8_t> enc;
+    if (!encode_text(ascii, n, &enc)) return SIZE_MAX;
+    if (out) std::memcpy(out, enc.data(), std::min(cap, enc.size()));
+    return enc.size();
+}
+
+static int npy_code(NpyStatus s) {
+    switch (s) {
+        case NpyStatus::kOk: return MSBWT_OK;
+        case NpyStatus::kIo: return MSBWT_ERR_IO;
+        case NpyStatus::kUnexpectedEof: return MSBWT_ERR_UNEXPECTED_EOF;
+        default: return MSBWT_ERR_BAD_HEADER;
+    }
+}
+
+int msbwt_save_bwt_numpy(const uint8_t *rle_bytes, size_t n, const char *utf8_path) {
+    if (!utf8_path || (!rle_bytes && n)) return MSBWT_ERR_INVALID_ARG;
+    std::string msg;
+    return npy_code(write_npy_payload(utf8_path, rle_bytes, n, &msg));
+}
+
+int msbwt_save_bwt_runs_numpy(const uint8_t *syms, const uint64_t *counts, size_t nruns, const char *utf8_path) {
+    if (!utf8_path || (nruns && (!syms || !counts))) return MSBWT_ERR_INVALID_ARG;
+    std::vector<uint8_t> enc;
+    encode_runs(syms, counts, nruns, &enc);
+    std::string msg;
+    return npy_code(write_npy_payload(utf8_path, enc.data(), enc.size(), &msg));
+}
+
+void msbwt_convert_stoi(const uint8_t *ascii, size_t n, uint8_t *out_codes) { ascii_to_codes(ascii, n, out_codes); }
+void msbwt_convert_itos(const uint8_t *codes, size_t n, uint8_t *out_ascii) { codes_to_ascii(codes, n, out_ascii); }
+void msbwt_reverse_complement_i(const uint8_t *codes, size_t n, uint8_t *out_codes) {
+    reverse_complement_codes(codes, n, out_codes);
+}
+
+}  // extern "C"

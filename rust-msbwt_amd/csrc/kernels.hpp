@@ -1,0 +1,40 @@
+// Launch wrappers of the gfx950 kernels (kernels.hip).  All pointers are device pointers.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+namespace msbwt {
+
+// bits of the device status word
+constexpr uint32_t kFlagInvalidSymbol = 1u;
+constexpr uint32_t kFlagInvalidRange = 2u;
+
+// One entry of the suffix table: the range after the last `depth` symbols of a k-mer.
+struct TableView {
+    const void *entries;  // uint4-aligned {l, h} pairs, 4^depth of them, or nullptr
+    int depth;            // 0 = no table
+};
+
+struct IndexView {
+    const void *blocks;  // plane blocks, 128 B each
+    uint64_t nblocks;
+    uint64_t total;
+    TableView table;
+};
+
+// counts[q] = count_kmer(kmers[q*k .. q*k+k)) for q < n.  Sets kFlagInvalidSymbol in *flags
+// (and writes UINT64_MAX) for a query holding a code >= 6.
+hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_t k, uint64_t n,
+                              uint64_t *counts, uint32_t *flags, hipStream_t stream);
+
+// (out_l[i], out_h[i]) = constrain_range(syms[i], [l[i], h[i])).
+hipError_t launch_constrain_ranges(const IndexView &ix, const uint8_t *syms, const uint64_t *l,
+                                   const uint64_t *h, uint64_t n, uint64_t *out_l, uint64_t *out_h,
+                                   uint32_t *flags, hipStream_t stream);
+
+// Fills the suffix table of `depth` symbols (entries: 4^depth x {l,h}) by backward search
+// on the device.
+hipError_t launch_build_table(const IndexView &ix, int depth, void *entries, hipStream_t stream);
+
+}  // namespace msbwt

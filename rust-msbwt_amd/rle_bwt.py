@@ -1,0 +1,158 @@
+"""`RleBWT` -- host-side mirror of the reference's `msbwt2::rle_bwt::RleBWT`
+(src/rle_bwt.rs) whose queries run on the MI355X through the C ABI (include/msbwt_hip.h).
+
+Same method names, argument meaning and error behaviour as the reference's `impl BWT for
+RleBWT`; `count_kmers` / `constrain_ranges` are the batch forms (host arrays), and the
+`*_device` forms take device pointers (e.g. `torch.Tensor.data_ptr()`) and a HIP stream.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from .msbwt_core import BWT, BWTRange, VC_LEN
+
+
+class MsbwtError(Exception):
+    def __init__(self, code, message=""):
+        super().__init__("msbwt error %d: %s" % (code, message))
+        self.code = code
+
+
+def _raise(code, handle):
+    msg = _lib.lib().msbwt_rle_last_error(handle)
+    msg = msg.decode(errors="replace") if msg else ""
+    if code in (_lib.ERR_IO, _lib.ERR_UNEXPECTED_EOF):
+        # the reference returns io::Error for these (rle_bwt.rs:84-148)
+        err = EOFError(msg) if code == _lib.ERR_UNEXPECTED_EOF else OSError(msg)
+        err.code = code
+        raise err
+    raise MsbwtError(code, msg)
+
+
+class RleBWT(BWT):
+    def __init__(self, bin_power=8, device=-1):
+        """RleBWT::new() / with_bin_power (rle_bwt.rs:297-322). `device` = HIP ordinal."""
+        self._h = None
+        self._h = _lib.lib().msbwt_rle_new_on_device(bin_power, device)
+        if not self._h:
+            raise MemoryError("msbwt_rle_new failed")
+        self.bin_power = bin_power
+
+    @classmethod
+    def with_bin_power(cls, bin_power, device=-1):
+        return cls(bin_power, device)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.lib().msbwt_rle_free(self._h)
+            self._h = None
+
+    # ---- trait BWT -------------------------------------------------------------------
+    def load_vector(self, bwt):
+        a = np.ascontiguousarray(bwt, dtype=np.uint8)
+        rc = _lib.lib().msbwt_rle_load_vector(self._h, a.ctypes.data_as(C.c_void_p), a.size)
+        if rc:
+            _raise(rc, self._h)
+
+    def load_numpy_file(self, filename):
+        rc = _lib.lib().msbwt_rle_load_numpy_file(self._h, os.fsencode(filename))
+        if rc:
+            _raise(rc, self._h)
+
+    def get_symbol_count(self, symbol):
+        if not 0 <= symbol < VC_LEN:
+            raise IndexError("symbol out of range")  # the reference panics (array index)
+        return int(_lib.lib().msbwt_rle_get_symbol_count(self._h, symbol))
+
+    def get_total_size(self):
+        return int(_lib.lib().msbwt_rle_get_total_size(self._h))
+
+    def constrain_range(self, sym, input_range):
+        ol, oh = C.c_uint64(), C.c_uint64()
+        rc = _lib.lib().msbwt_rle_constrain_range(self._h, sym, input_range.l, input_range.h,
+                                                  C.byref(ol), C.byref(oh))
+        if rc:
+            _raise(rc, self._h)
+        return BWTRange(int(ol.value), int(oh.value))
+
+    def count_kmer(self, kmer):
+        a = np.ascontiguousarray(kmer, dtype=np.uint8)
+        out = C.c_uint64()
+        rc = _lib.lib().msbwt_rle_count_kmer(self._h, a.ctypes.data_as(C.c_void_p), a.size, C.byref(out))
+        if rc:
+            _raise(rc, self._h)
+        return int(out.value)
+
+    # ---- batch forms -----------------------------------------------------------------
+    def count_kmers(self, kmers):
+        """kmers: (n, k) uint8 symbol codes -> uint64[n]."""
+        a = np.ascontiguousarray(kmers, dtype=np.uint8)
+        if a.ndim != 2:
+            raise ValueError("kmers must be (n, k)")
+        n, k = a.shape
+        out = np.empty(n, dtype=np.uint64)
+        rc = _lib.lib().msbwt_rle_count_kmers(self._h, a.ctypes.data_as(C.c_void_p), k, n,
+                                              out.ctypes.data_as(C.c_void_p))
+        if rc:
+            _raise(rc, self._h)
+        return out
+
+    def constrain_ranges(self, syms, l, h):
+        s = np.ascontiguousarray(syms, dtype=np.uint8)
+        l = np.ascontiguousarray(l, dtype=np.uint64)
+        h = np.ascontiguousarray(h, dtype=np.uint64)
+        if not (s.shape == l.shape == h.shape and s.ndim == 1):
+            raise ValueError("syms, l, h must be 1-D and equally long")
+        ol = np.empty(s.size, dtype=np.uint64)
+        oh = np.empty(s.size, dtype=np.uint64)
+        rc = _lib.lib().msbwt_rle_constrain_ranges(self._h, s.ctypes.data_as(C.c_void_p),
+                                                   l.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p),
+                                                   s.size, ol.ctypes.data_as(C.c_void_p), oh.ctypes.data_as(C.c_void_p))
+        if rc:
+            _raise(rc, self._h)
+        return ol, oh
+
+    def count_kmers_device(self, d_kmers, k, n, d_out, stream=0):
+        """Device pointers (ints); asynchronous on `stream` (a hipStream_t as int)."""
+        rc = _lib.lib().msbwt_rle_count_kmers_device(self._h, d_kmers, k, n, d_out, stream)
+        if rc:
+            _raise(rc, self._h)
+
+    def constrain_ranges_device(self, d_syms, d_l, d_h, n, d_out_l, d_out_h, stream=0):
+        rc = _lib.lib().msbwt_rle_constrain_ranges_device(self._h, d_syms, d_l, d_h, n, d_out_l, d_out_h, stream)
+        if rc:
+            _raise(rc, self._h)
+
+    def device_status(self, stream=0):
+        """Synchronises `stream` and raises if a device batch saw invalid input."""
+        rc = _lib.lib().msbwt_rle_device_status(self._h, stream)
+        if rc:
+            _raise(rc, self._h)
+
+    # ---- tuning / introspection --------------------------------------------------------
+    def set_table_depth(self, depth):
+        rc = _lib.lib().msbwt_rle_set_table_depth(self._h, depth)
+        if rc:
+            _raise(rc, self._h)
+
+    def get_table_depth(self):
+        return int(_lib.lib().msbwt_rle_get_table_depth(self._h))
+
+    def device_bytes(self):
+        return int(_lib.lib().msbwt_rle_device_bytes(self._h))
+
+    def set_kernel_timing(self, enabled):
+        _lib.lib().msbwt_rle_set_kernel_timing(self._h, 1 if enabled else 0)
+
+    def kernel_time_ms(self):
+        """(average ms per count-kernel launch, launches) since the last call; HIP events."""
+        avg, cnt = C.c_double(), C.c_uint64()
+        rc = _lib.lib().msbwt_rle_kernel_time_ms(self._h, C.byref(avg), C.byref(cnt))
+        if rc:
+            _raise(rc, self._h)
+        return float(avg.value), int(cnt.value)
+
+    def device_ordinal(self):
+        return int(_lib.lib().msbwt_rle_device_ordinal(self._h))

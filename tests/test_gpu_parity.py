@@ -1,0 +1,235 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and with the reference's
+golden vectors.  Needs an MI355X: run with `pytest -m gpu`."""
+import itertools
+import os
+
+import numpy as np
+import pytest
+
+import rust_msbwt_amd as msbwt
+from rust_msbwt_amd import BWTRange, RleBWT
+from oracle import oracle as orc
+from rle_random import random_kmers, random_stream, raw_byte_stream, runs_to_bytes
+
+pytestmark = pytest.mark.gpu
+
+CODES = {"$": 0, "A": 1, "C": 2, "G": 3, "N": 4, "T": 5}
+
+
+def stoi(s):
+    return [CODES[c] for c in s]
+
+
+def gpu_bwt(rle, bin_power=8):
+    b = RleBWT.with_bin_power(bin_power)
+    b.load_vector(rle)
+    return b
+
+
+def test_g4_totals_via_npy(golden, tmp_path):
+    g = golden["G4_totals"]
+    path = str(tmp_path / "g4.npy")
+    msbwt.bwt_converter.save_bwt_numpy(msbwt.bwt_converter.convert_to_vec(orc.naive_bwt(g["strings"])), path)
+    b = RleBWT()
+    b.load_numpy_file(path)
+    assert [b.get_symbol_count(s) for s in range(6)] == g["symbol_counts"]
+
+
+def test_g6_constrain_range_exhaustive(golden):
+    """rle_bwt.rs:603-675, through the GPU."""
+    g = golden["G6_constrain_range"]
+    text = g["bwt"]
+    ints = stoi(text)
+    rle = msbwt.bwt_converter.convert_to_vec(text)
+    for bp in g["bin_powers"] + [8]:
+        b = gpu_bwt(rle, bp)
+        counts = [b.get_symbol_count(s) for s in range(6)]
+        start = np.concatenate([[0], np.cumsum(counts)[:-1]])
+        end = np.cumsum(counts)
+        for sym in range(6):
+            assert b.constrain_range(sym, BWTRange(0, len(text))) == BWTRange(int(start[sym]), int(end[sym]))
+            cnt = 0
+            for ind in range(len(text) + 1):
+                assert b.constrain_range(sym, BWTRange(0, ind)) == BWTRange(int(start[sym]), int(start[sym]) + cnt)
+                assert b.constrain_range(sym, BWTRange(ind, len(text))) == BWTRange(int(start[sym]) + cnt, int(end[sym]))
+                if ind < len(text) and ints[ind] == sym:
+                    cnt += 1
+
+
+@pytest.mark.parametrize("key", ["G7_count_kmer", "G10_load_and_add"])
+def test_count_kmer_literals(golden, key):
+    """rle_bwt.rs:677-710 and dynamic_bwt.rs:733-773."""
+    g = golden[key]
+    rle = msbwt.bwt_converter.convert_to_vec(orc.naive_bwt(g["strings"]))
+    for bp in g.get("bin_powers", [1, 2, 3, 4]):
+        b = gpu_bwt(rle, bp)
+        for c in range(6):
+            assert b.count_kmer([c]) == b.get_symbol_count(c)
+        for s in g["strings"]:
+            assert b.count_kmer(msbwt.string_util.convert_stoi(s)) == 1
+        for kmer, n in g["counts"].items():
+            assert b.count_kmer(msbwt.string_util.convert_stoi(kmer)) == n
+
+
+def test_g8_doc_tests(golden):
+    g = golden["G8_doc_tests"]
+    b = gpu_bwt(msbwt.bwt_converter.convert_to_vec(g["bwt"]))
+    for codes, n in g["count_codes"]:
+        assert b.count_kmer(codes) == n
+    for text, n in g["count_text"]:
+        assert b.count_kmer(msbwt.string_util.convert_stoi(text)) == n
+    assert b.get_symbol_count(0) == g["symbol_count_0"]
+    assert b.get_total_size() == g["total_size"]
+
+
+def test_g9_config_c1_two_string(golden, golden_dir):
+    """BASELINE.json configs[0]: two_string.npy, every 4-mer (all 1296 over the 6 symbols)."""
+    g = golden["G9_two_string"]
+    b = RleBWT()
+    b.load_numpy_file(os.path.join(golden_dir, g["file"]))
+    for kmer, n in g["counts"].items():
+        assert b.count_kmer(msbwt.string_util.convert_stoi(kmer)) == n
+    o = orc.OracleRleBWT()
+    o.load_numpy_file(os.path.join(golden_dir, g["file"]))
+    kmers = np.array(list(itertools.product(range(6), repeat=4)), dtype=np.uint8)
+    got = b.count_kmers(kmers)
+    assert np.array_equal(got, o.count_kmers(kmers))
+    present = {"$ACG", "ACGT", "CGT$", "GT$A", "T$AC", "$TGC", "TGCA", "GCA$", "CA$T", "A$TG"}
+    syms = "$ACGNT"
+    for row, c in zip(kmers, got):
+        assert int(c) == (1 if "".join(syms[x] for x in row) in present else 0)
+
+
+def _ranges_parity(rle, seed, n=4000):
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    total = o.get_total_size()
+    assert b.get_total_size() == total
+    assert [b.get_symbol_count(s) for s in range(6)] == [o.get_symbol_count(s) for s in range(6)]
+    rng = np.random.default_rng(seed)
+    pos = np.concatenate([rng.integers(0, total + 1, size=n), [0, total, total, 0]])
+    edge = np.arange(0, total + 1, 256)[:200]
+    pos = np.concatenate([pos, edge, np.maximum(edge, 1) - 1, np.minimum(edge + 1, total)])
+    l = rng.choice(pos, size=n)
+    h = rng.choice(pos, size=n)
+    l, h = np.minimum(l, h).astype(np.uint64), np.maximum(l, h).astype(np.uint64)
+    syms = rng.integers(0, 6, size=n).astype(np.uint8)
+    gl, gh = b.constrain_ranges(syms, l, h)
+    ol, oh = o.constrain_ranges(syms, l, h)
+    assert np.array_equal(gl, ol)
+    assert np.array_equal(gh, oh)
+    return o, b
+
+
+@pytest.mark.parametrize("kind", ["ones", "short", "long", "mixed"])
+def test_constrain_ranges_random_streams(kind):
+    _ranges_parity(random_stream(21, 3000, kind), seed=5)
+
+
+def test_constrain_ranges_edge_streams():
+    for syms, lens in [([1, 2], [256, 256]), ([0, 1], [1, 255]), ([3], [100000]), ([0], [512]),
+                       ([5, 0, 5], [32, 1024, 32768]), ([4, 1], [255, 1])]:
+        _ranges_parity(runs_to_bytes(syms, lens), seed=1, n=500)
+    for seed in range(3):
+        _ranges_parity(raw_byte_stream(seed, 300), seed=seed, n=500)
+
+
+def _real_bwt(seed, nreads, length):
+    """A small true multi-string BWT (so that k-mers of the reads are present)."""
+    rng = np.random.default_rng(seed)
+    genome = "".join(rng.choice(list("ACGT"), size=600))
+    reads = []
+    for _ in range(nreads):
+        p = int(rng.integers(0, len(genome) - length))
+        r = list(genome[p:p + length])
+        if rng.random() < 0.3:
+            r[int(rng.integers(0, length))] = "ACGTN"[int(rng.integers(0, 5))]
+        reads.append("".join(r))
+    return reads, orc.convert_to_vec(orc.naive_bwt(reads))
+
+
+@pytest.mark.parametrize("k", [1, 2, 5, 12, 21, 31, 32, 33, 50])
+def test_count_kmers_on_true_bwt(k):
+    reads, rle = _real_bwt(2, 150, 60)
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    rng = np.random.default_rng(k)
+    qs = []
+    for r in reads:                       # present k-mers (windows of the reads)
+        if len(r) >= k:
+            p = int(rng.integers(0, len(r) - k + 1))
+            qs.append(orc.convert_stoi(r[p:p + k]))
+    qs = np.array(qs, dtype=np.uint8)
+    qs = np.concatenate([qs, random_kmers(k, 300, k), random_kmers(k + 1, 100, k, alphabet=(0, 1, 2, 3, 4, 5))])
+    got = b.count_kmers(qs)
+    exp = o.count_kmers(qs)
+    assert np.array_equal(got, exp)
+    assert got[:10].sum() > 0
+    # the single-query trait call is the same path
+    for i in (0, len(qs) // 2, len(qs) - 1):
+        assert b.count_kmer(qs[i]) == int(exp[i])
+
+
+def test_count_kmers_random_stream_any_symbols():
+    rle = random_stream(4, 20000, "short")
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    for k in (3, 8, 21):
+        qs = random_kmers(k, 5000, k, alphabet=(0, 1, 2, 3, 4, 5))
+        assert np.array_equal(b.count_kmers(qs), o.count_kmers(qs))
+
+
+def test_empty_kmer_and_empty_bwt():
+    b = gpu_bwt(msbwt.bwt_converter.convert_to_vec("GTN$$ACCC$G"))
+    assert b.count_kmer([]) == 11                       # msbwt_core.rs:128-131,160
+    assert np.array_equal(b.count_kmers(np.zeros((3, 0), dtype=np.uint8)), [11, 11, 11])
+    assert len(b.count_kmers(np.zeros((0, 5), dtype=np.uint8))) == 0
+    e = gpu_bwt(np.zeros(0, dtype=np.uint8))
+    assert e.get_total_size() == 0
+    assert e.count_kmer([1, 2]) == 0
+    assert e.count_kmer([]) == 0
+
+
+def test_error_behaviour(tmp_path, golden_dir):
+    b = gpu_bwt(msbwt.bwt_converter.convert_to_vec("GTN$$ACCC$G"))
+    with pytest.raises(msbwt.MsbwtError) as e:          # reference: assert -> panic
+        b.count_kmer([1, 6])
+    assert e.value.code == msbwt._lib.ERR_INVALID_SYMBOL
+    with pytest.raises(msbwt.MsbwtError) as e:
+        b.count_kmers(np.array([[1, 2], [7, 1]], dtype=np.uint8))
+    assert e.value.code == msbwt._lib.ERR_INVALID_SYMBOL
+    with pytest.raises(msbwt.MsbwtError) as e:
+        b.constrain_range(1, BWTRange(0, 12))
+    assert e.value.code == msbwt._lib.ERR_INVALID_RANGE
+    with pytest.raises(msbwt.MsbwtError) as e:
+        b.constrain_range(1, BWTRange(5, 4))
+    assert e.value.code == msbwt._lib.ERR_INVALID_RANGE
+    assert b.count_kmer([1]) == 1                        # the handle stays usable
+    fresh = RleBWT()
+    with pytest.raises(msbwt.MsbwtError) as e:
+        fresh.count_kmer([1])
+    assert e.value.code == msbwt._lib.ERR_NOT_LOADED
+    with pytest.raises(OSError):
+        fresh.load_numpy_file(str(tmp_path / "missing.npy"))
+    good = open(os.path.join(golden_dir, "two_string.npy"), "rb").read()
+    for name, blob, exc in [("trunc", good[:-1], EOFError), ("short", good[:50], EOFError),
+                            ("tiny", good[:7], msbwt.MsbwtError),
+                            ("nojson", good[:10] + b"{'descr' '|u1'}".ljust(86) + good[96:], msbwt.MsbwtError)]:
+        p = str(tmp_path / (name + ".npy"))
+        open(p, "wb").write(blob)
+        with pytest.raises(exc):
+            fresh.load_numpy_file(p)
+    with pytest.raises(msbwt.MsbwtError) as e:
+        fresh.load_vector(np.array([9, 14], dtype=np.uint8))  # symbol code 6 in the stream
+    assert e.value.code == msbwt._lib.ERR_INVALID_SYMBOL
+
+
+def test_reload_replaces_index():
+    b = gpu_bwt(msbwt.bwt_converter.convert_to_vec("GTN$$ACCC$G"))
+    assert b.count_kmer(stoi("CC")) == 2
+    b.load_vector(msbwt.bwt_converter.convert_to_vec("TG$$CAGCCG"))
+    assert b.get_total_size() == 10
+    assert b.count_kmer(stoi("CG")) == 2

@@ -1,0 +1,139 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports every
+symbol include/msbwt_hip.h declares, the codecs match the reference's vectors, and the
+load-path layout builder produces blocks that decode back to the BWT.  No GPU compute."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import rust_msbwt_amd as msbwt
+from conftest import ROOT, expand_case
+from oracle import oracle as orc
+from rle_random import random_stream, raw_byte_stream, runs_to_bytes
+
+_lib = msbwt._lib
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "msbwt_hip.h")).read()
+    declared = set(re.findall(r"\b(msbwt_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    L = C.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), "libmsbwt_hip.so lacks %s" % name
+    # and the Python binding covers exactly the declared set
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert "gfx950" in msbwt.version()
+
+
+def test_library_embeds_gfx950_code_object():
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+
+
+def test_codecs_match_reference_vectors(golden, tmp_path):
+    for case in golden["G1_convert_to_vec"]["cases"]:
+        got = msbwt.bwt_converter.convert_to_vec(expand_case(case))
+        if "bytes" in case:
+            assert got.tolist() == case["bytes"]
+        else:
+            assert len(got) == case["len"]
+    with pytest.raises(ValueError):
+        msbwt.bwt_converter.convert_to_vec("ACGX")
+    g = golden["string_util"]
+    for text, codes in g["stoi"]:
+        assert msbwt.string_util.convert_stoi(text).tolist() == codes
+    for codes, text in g["itos"]:
+        assert msbwt.string_util.convert_itos(codes) == text
+    for codes, rc in g["revcomp"]:
+        assert msbwt.string_util.reverse_complement_i(codes).tolist() == rc
+    # .npy writer: byte-identical with the oracle's (which is pinned by G2)
+    g2 = golden["G2_npy"]
+    for i, case in enumerate(g2["cases"]):
+        a, b = str(tmp_path / ("a%d.npy" % i)), str(tmp_path / ("b%d.npy" % i))
+        if case["kind"] == "bytes":
+            rle = msbwt.bwt_converter.convert_to_vec(expand_case(case))
+            msbwt.bwt_converter.save_bwt_numpy(rle, a)
+            orc.save_bwt_numpy(rle, b)
+        else:
+            msbwt.bwt_converter.save_bwt_runs_numpy(case["runs"], a)
+            orc.save_bwt_runs_numpy(case["runs"], b)
+        assert open(a, "rb").read() == open(b, "rb").read()
+        assert list(open(a, "rb").read()[96:]) == case["payload"]
+
+
+def test_codec_agrees_with_oracle_on_random_text():
+    rng = np.random.default_rng(5)
+    text = "".join(rng.choice(list("$ACGNT\n"), p=[.05, .3, .2, .2, .05, .15, .05], size=5000))
+    assert np.array_equal(msbwt.bwt_converter.convert_to_vec(text), orc.convert_to_vec(text))
+    raw = bytes(rng.integers(0, 256, size=2000, dtype=np.uint8))
+    assert np.array_equal(msbwt.string_util.convert_stoi(raw), orc.convert_stoi(raw))
+
+
+def build_blocks(rle):
+    rle = np.ascontiguousarray(rle, dtype=np.uint8)
+    total = C.c_uint64()
+    L = _lib.lib()
+    n = L.msbwt_build_plane_blocks(rle.ctypes.data_as(C.c_void_p), rle.size, None, 0, C.byref(total))
+    assert n != _lib.SIZE_MAX
+    out = np.zeros((n, 8, 4), dtype=np.uint32)
+    L.msbwt_build_plane_blocks(rle.ctypes.data_as(C.c_void_p), rle.size, out.ctypes.data_as(C.c_void_p), n, C.byref(total))
+    return out, int(total.value)
+
+
+def decode_blocks(blocks, total):
+    """plane blocks -> (symbols, A) with A[b, s] = the 40-bit bound of block b."""
+    bits = np.arange(32, dtype=np.uint32)
+    planes = [((blocks[:, :, p][:, :, None] >> bits) & 1).reshape(len(blocks), 256) for p in range(3)]
+    sym = (planes[0] | (planes[1] << 1) | (planes[2] << 2)).astype(np.uint8).reshape(-1)
+    meta = blocks[:, :, 3].astype(np.uint64)
+    A = np.zeros((len(blocks), 6), dtype=np.uint64)
+    for s in range(6):
+        hi = (meta[:, 6 + s // 4] >> np.uint64(8 * (s % 4))) & np.uint64(0xFF)
+        A[:, s] = meta[:, s] | (hi << np.uint64(32))
+    return sym, A
+
+
+def check_layout(rle):
+    blocks, total = build_blocks(rle)
+    plain = orc.decompress(rle)
+    assert total == len(plain)
+    assert len(blocks) == total // 256 + 1
+    sym, A = decode_blocks(blocks, total)
+    assert np.array_equal(sym[:total], plain)
+    assert not sym[total:].any(), "padding past the end must be zero"
+    counts = np.array([(plain == s).sum() for s in range(6)], dtype=np.uint64)
+    start = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64)
+    for s in range(6):
+        occ_at_block = np.concatenate([[0], np.cumsum(plain == s)])[np.arange(len(blocks)) * 256 if total else [0]]
+        assert np.array_equal(A[:, s], start[s] + occ_at_block.astype(np.uint64)), s
+
+
+@pytest.mark.parametrize("kind", ["ones", "short", "long", "mixed"])
+def test_plane_blocks_random(kind):
+    check_layout(random_stream(3, 500, kind))
+
+
+def test_plane_blocks_edges():
+    check_layout(np.zeros(0, dtype=np.uint8))                      # empty BWT: one header-only block
+    check_layout(runs_to_bytes([1, 2], [256, 256]))                # exact multiple of the block size
+    check_layout(runs_to_bytes([5], [100000]))                     # one run over many blocks
+    check_layout(runs_to_bytes([0, 5, 0], [1, 254, 1]))
+    for seed in range(3):
+        check_layout(raw_byte_stream(seed, 200))                   # zero digits / zero-length runs
+    check_layout(orc.convert_to_vec("GTN$$ACCC$G"))
+
+
+def test_plane_blocks_threaded_build_matches_serial():
+    # > 1 MiB of RLE bytes switches the builder to its multi-threaded path
+    rle = random_stream(9, 1_200_000, "short")
+    assert rle.size > (1 << 20)
+    check_layout(rle)
+
+
+def test_bad_input_is_rejected():
+    bad = np.array([9, 14], dtype=np.uint8)  # symbol code 6
+    total = C.c_uint64()
+    assert _lib.lib().msbwt_build_plane_blocks(bad.ctypes.data_as(C.c_void_p), 2, None, 0, C.byref(total)) == _lib.SIZE_MAX
