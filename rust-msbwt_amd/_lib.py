@@ -54,9 +54,31 @@ class MsbwtLibraryMissing(ImportError):
     pass
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so
+    (soname libamdhip64.so.7, loaded through an RPATH); if this library pulled in
+    /opt/rocm's copy first, a later `import torch` would map a second runtime and one of the
+    two would see no device.  So, when torch is installed, map its copy first: the loader
+    then binds libmsbwt_hip.so's NEEDED libamdhip64.so.7 to it.  MSBWT_HIP_RUNTIME=system
+    skips this (pure C/Rust hosts never come through here anyway)."""
+    if os.environ.get("MSBWT_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     global _lib
     if _lib is None:
+        _share_hip_runtime_with_torch()
         if not os.path.exists(LIB_PATH):
             raise MsbwtLibraryMissing(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

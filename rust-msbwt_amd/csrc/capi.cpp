@@ -48,15 +48,21 @@ const char *kVersion = "rust-msbwt_amd 0.1.0 (gfx950 plane-block index)";
 class DeviceScope {
   public:
     explicit DeviceScope(int device) {
-        ok_ = hipGetDevice(&prev_) == hipSuccess;
-        if (ok_ && prev_ != device) ok_ = hipSetDevice(device) == hipSuccess, switched_ = ok_;
+        err_ = hipGetDevice(&prev_);
+        if (err_ == hipSuccess && prev_ != device) {
+            err_ = hipSetDevice(device);
+            switched_ = err_ == hipSuccess;
+        }
+        ok_ = err_ == hipSuccess;
     }
     ~DeviceScope() {
         if (switched_) (void)hipSetDevice(prev_);
     }
     bool ok() const { return ok_; }
+    std::string why() const { return std::string("no usable HIP device: ") + hipGetErrorString(err_); }
 
   private:
+    hipError_t err_ = hipSuccess;
     int prev_ = 0;
     bool ok_ = false, switched_ = false;
 };
@@ -148,7 +154,7 @@ int rebuild_table(msbwt_rle *h) {
 // Common tail of both load entry points: totals, plane blocks, upload, table.
 int install(msbwt_rle *h, const uint8_t *rle, size_t n) {
     DeviceScope scope(h->device);
-    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, "no usable HIP device");
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
     release_index(h);
     Totals t;
     if (!compute_totals(rle, n, &t)) return fail(h, MSBWT_ERR_INVALID_SYMBOL, "RLE stream holds a symbol code >= 6");
@@ -280,7 +286,7 @@ int msbwt_rle_count_kmers_device(const msbwt_rle *ch, const void *d_kmers, size_
     if (!h->loaded) return fail(h, MSBWT_ERR_NOT_LOADED, "no BWT loaded");
     if (n && (!d_out_counts || (!d_kmers && k))) return fail(h, MSBWT_ERR_INVALID_ARG, "null device pointer");
     DeviceScope scope(h->device);
-    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, "no usable HIP device");
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
     return launch_count(h, static_cast<const uint8_t *>(d_kmers), k, n, static_cast<uint64_t *>(d_out_counts),
                         static_cast<hipStream_t>(hip_stream));
 }
@@ -293,7 +299,7 @@ int msbwt_rle_constrain_ranges_device(const msbwt_rle *ch, const void *d_syms, c
     if (!h->loaded) return fail(h, MSBWT_ERR_NOT_LOADED, "no BWT loaded");
     if (n && (!d_syms || !d_l || !d_h || !d_out_l || !d_out_h)) return fail(h, MSBWT_ERR_INVALID_ARG, "null device pointer");
     DeviceScope scope(h->device);
-    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, "no usable HIP device");
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
     HIP_TRY(h, launch_constrain_ranges(view_of(h), static_cast<const uint8_t *>(d_syms),
                                        static_cast<const uint64_t *>(d_l), static_cast<const uint64_t *>(d_h), n,
                                        static_cast<uint64_t *>(d_out_l), static_cast<uint64_t *>(d_out_h),
@@ -307,7 +313,7 @@ int msbwt_rle_device_status(const msbwt_rle *ch, void *hip_stream) {
     std::lock_guard<std::mutex> lock(h->mu);
     if (!h->d_flags) return MSBWT_OK;
     DeviceScope scope(h->device);
-    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, "no usable HIP device");
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
     uint32_t flags = 0;
     int rc = read_flags(h, static_cast<hipStream_t>(hip_stream), &flags);
     return rc ? rc : flags_to_code(h, flags);
@@ -320,7 +326,7 @@ int msbwt_rle_count_kmers(const msbwt_rle *ch, const uint8_t *kmers, size_t k, s
     if (!h->loaded) return fail(h, MSBWT_ERR_NOT_LOADED, "no BWT loaded");
     if (n && (!out_counts || (!kmers && k))) return fail(h, MSBWT_ERR_INVALID_ARG, "null pointer");
     DeviceScope scope(h->device);
-    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, "no usable HIP device");
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
     // bounded staging: chunks of up to 4 Mi queries travel host -> HBM -> host
     const size_t chunk = std::min<size_t>(n, size_t(1) << 22);
     const size_t kmer_bytes = (chunk * k + 15) / 16 * 16;
@@ -351,7 +357,7 @@ int msbwt_rle_constrain_ranges(const msbwt_rle *ch, const uint8_t *syms, const u
     if (!h->loaded) return fail(h, MSBWT_ERR_NOT_LOADED, "no BWT loaded");
     if (n && (!syms || !l || !hh || !out_l || !out_h)) return fail(h, MSBWT_ERR_INVALID_ARG, "null pointer");
     DeviceScope scope(h->device);
-    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, "no usable HIP device");
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
     const size_t chunk = std::min<size_t>(n, size_t(1) << 22);
     const size_t sym_bytes = (chunk + 15) / 16 * 16;
     int rc = ensure_stage(h, sym_bytes + 4 * chunk * sizeof(uint64_t));
@@ -393,7 +399,7 @@ int msbwt_rle_set_table_depth(msbwt_rle *h, int depth) {
     h->wanted_table_depth = depth;
     if (!h->loaded) return MSBWT_OK;
     DeviceScope scope(h->device);
-    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, "no usable HIP device");
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
     return rebuild_table(h);
 }
 
@@ -416,7 +422,7 @@ int msbwt_rle_kernel_time_ms(const msbwt_rle *ch, double *avg_ms, uint64_t *laun
     if (!h) return MSBWT_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
     DeviceScope scope(h->device);
-    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, "no usable HIP device");
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
     for (size_t i = 0; i + 1 < h->events.size(); i += 2) {
         float ms = 0.f;
         HIP_TRY(h, hipEventSynchronize(h->events[i + 1]));

@@ -229,7 +229,7 @@ def test_error_behaviour(tmp_path, golden_dir):
 
 def test_reload_replaces_index():
     b = gpu_bwt(msbwt.bwt_converter.convert_to_vec("GTN$$ACCC$G"))
-    assert b.count_kmer(stoi("CC")) == 2
+    assert b.count_kmer(stoi("CC")) == 1
     b.load_vector(msbwt.bwt_converter.convert_to_vec("TG$$CAGCCG"))
     assert b.get_total_size() == 10
     assert b.count_kmer(stoi("CG")) == 2
