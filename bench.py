@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- batched count_kmer throughput of the MI355X path (BASELINE.json metric).
+
+One "step" = one pass of the hot path (msbwt_rle_count_kmers_device) over one batch of
+synthetic queries that is already resident in HBM.  Default workload = BASELINE.json
+configs[1] ("c2": 1M synthetic 100-bp reads -> MSBWT, 10M random 21-mers); --workload c3
+runs the E. coli-like config (read-derived 31-mers).  With --gpus N (launched by
+torch.distributed.run, one rank per GPU) the index is replicated, every rank runs its own
+batch (weak scaling) and the per-rank counts are gathered with one RCCL all_gather per step.
+
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for how the roofline figures are
+defined.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is achievable
+
+
+def log(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def make_queries(synth, cfg, reads, nq, k, seed, kind):
+    if kind == "random":
+        return synth.random_kmers(nq, k, seed)
+    return synth.read_kmers(reads, k, limit=nq, seed=seed)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--queries", type=int, default=0, help="queries per GPU per step (0 = the config's)")
+    ap.add_argument("--k", type=int, default=0, help="override k")
+    ap.add_argument("--query-kind", default="", choices=["", "random", "reads"])
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the index (tests)")
+    ap.add_argument("--table-depth", type=int, default=-2, help="-2 = library default")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-sample", type=int, default=200_000)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    msbwt = importlib.import_module("rust-msbwt_amd")
+    import synth
+
+    cfg = dict(synth.CONFIGS[args.workload])
+    k = args.k or cfg["k"]
+    kind = args.query_kind or cfg["queries"]
+    nq = args.queries or cfg["nq"] or 20_000_000
+    nq = int(nq * min(1.0, args.scale * 4)) if args.scale < 1.0 and not args.queries else nq
+
+    # ---- inputs: rank 0 builds (and caches) the index file, everyone loads it -------------
+    t0 = time.time()
+    if rank == 0:
+        npy, reads = synth.workload_index(args.workload, args.scale)
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        npy, reads = synth.workload_index(args.workload, args.scale)
+    log("rank %d: index file %s ready in %.1fs" % (rank, os.path.basename(npy), time.time() - t0))
+    t0 = time.time()
+    bwt = msbwt.RleBWT(device=local_rank)
+    if args.table_depth > -2:
+        bwt.set_table_depth(args.table_depth)
+    bwt.load_numpy_file(npy)
+    total = bwt.get_total_size()
+    log("rank %d: %d symbols on the GPU (%.1f MB index, table depth %d) in %.1fs"
+        % (rank, total, bwt.device_bytes() / 1e6, bwt.get_table_depth(), time.time() - t0))
+
+    queries = make_queries(synth, cfg, reads, nq, k, cfg["qseed"] + 1000 * rank, kind)
+    nq = len(queries)
+    d_q = torch.from_numpy(queries).to(dev)
+    d_out = torch.empty(nq, dtype=torch.int64, device=dev)
+    d_all = torch.empty(nq * world, dtype=torch.int64, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        bwt.count_kmers_device(d_q.data_ptr(), k, nq, d_out.data_ptr(), stream)
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_out)  # the path's one exchange step (RCCL)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    bwt.device_status(stream)
+    bwt.set_kernel_timing(True)
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t_start
+    bwt.set_kernel_timing(False)
+    kernel_ms, launches = bwt.kernel_time_ms()
+    bwt.device_status(stream)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = nq * world * args.steps / elapsed
+
+    result = {
+        "metric": "k-mer count queries/sec (whole node)",
+        "value": value,
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s: %d synthetic %d-bp reads (%.0fx of a %d-bp random genome, %.1f%% subst.) -> MSBWT of %d symbols; "
+                        "%d %s %d-mers per GPU per step" % (
+                            args.workload, len(reads), reads.shape[1], len(reads) * reads.shape[1] / max(1, int(cfg["genome"] * args.scale)),
+                            int(cfg["genome"] * args.scale), cfg["err"] * 100, total, nq,
+                            "random" if kind == "random" else "read-derived", k),
+            "k": k, "queries_per_gpu": nq, "bwt_symbols": total, "index_bytes": bwt.device_bytes(),
+            "table_depth": bwt.get_table_depth(),
+            "parallelism": "query-sharded x%d, index replicated, RCCL all_gather of counts" % world if world > 1 else "1 GPU",
+        },
+    }
+
+    if rank == 0:
+        # ---- parity + algorithmic bytes (the oracle is the checker, never the thing timed as `value`) ----
+        from oracle import oracle as orc
+        ref = orc.OracleRleBWT(8)
+        ref.load_numpy_file(npy)
+        got = d_out.cpu().numpy().astype(np.uint64)
+        ns = min(nq, args.parity_sample)
+        sel = np.linspace(0, nq - 1, ns).astype(np.int64)
+        exp = ref.count_kmers(queries[sel], nthreads=os.cpu_count() or 1)
+        mism = int((exp != got[sel]).sum())
+        result["parity"] = {"checked": int(ns), "mismatches": mism, "vs": "CPU oracle (restated RleBWT::count_kmer)",
+                            "nonzero_counts": int((got > 0).sum())}
+        if mism:
+            log("PARITY FAILURE: %d of %d sampled counts differ" % (mism, ns))
+        # algorithmic bytes of the reference algorithm for THIS query set: exact counters
+        st = orc.Stats()
+        ncpu = min(os.cpu_count() or 1, 16)
+        t0 = time.time()
+        ref.count_kmers(queries, nthreads=ncpu, stats=st)
+        t_all = time.time() - t0
+        alg_bytes = st.algorithmic_bytes(k)
+        kern_s = kernel_ms / 1e3 if launches else elapsed / args.steps
+        achieved = alg_bytes / kern_s / 1e9
+        result["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "k_count_kmers", "kernel_ms": kernel_ms, "kernel_launches": launches,
+            "algorithmic_bytes_per_launch": int(alg_bytes),
+            "algorithmic_bytes_per_query": alg_bytes / nq,
+            "mean_steps_per_query": st.steps / nq, "mean_bin_visits_per_query": st.visits / nq,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            ncs = min(nq, args.cpu_sample)
+            t0 = time.time()
+            ref.count_kmers(queries[:ncs], nthreads=1)
+            t1 = time.time() - t0
+            result["cpu_baseline"] = {
+                "value": ncs / t1, "unit": "queries/s", "cores": 1, "kind": "port",
+                "sample": "first %d queries of the same batch, same comp_msbwt.npy, 1 thread (the reference is single-threaded), -O3 C restatement" % ncs,
+                "all_cores": {"value": nq / t_all, "cores": ncpu, "note": "same batch, static partition, instrumented build"},
+            }
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,152 @@
+"""Synthetic workloads (test / bench infrastructure): genome, reads, MSBWT, queries.
+
+SURVEY.md 8(d) generators, seeded and integer-only; `workload(name)` builds (and caches
+under synth/cache/) the inputs of a BASELINE.json config."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libmsbwt_synth.so")
+SRC = os.path.join(HERE, "msbwt_synth.cpp")
+CACHE = os.path.join(HERE, "cache")
+
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(SRC):
+        subprocess.check_call(["g++", "-O3", "-march=x86-64-v3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+                               "-Wextra", "-o", SO, SRC, "-lpthread"])
+    return SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(SO)
+        vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+        L.synth_genome.argtypes = [u64, u64, vp]
+        L.synth_reads.argtypes = [vp, u64, u64, u32, u64, u32, vp]
+        L.synth_random_kmers.argtypes = [u64, u32, u64, vp]
+        L.synth_build_msbwt.argtypes = [vp, vp, u64, vp, C.c_int]
+        L.synth_build_msbwt.restype = C.c_int
+        L.synth_rle_encode.argtypes = [vp, u64, vp, u64]
+        L.synth_rle_encode.restype = u64
+        L.synth_rle_stream.argtypes = [u64, C.c_double, u64, vp, u64, C.POINTER(u64)]
+        L.synth_rle_stream.restype = u64
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def genome(length, seed):
+    out = np.empty(length, dtype=np.uint8)
+    lib().synth_genome(length, seed, _p(out))
+    return out
+
+
+def reads(genome_codes, n, length, seed, err=0.005):
+    out = np.empty((n, length), dtype=np.uint8)
+    g = np.ascontiguousarray(genome_codes, dtype=np.uint8)
+    lib().synth_reads(_p(g), g.size, n, length, seed, int(round(err * 1e6)), _p(out))
+    return out
+
+
+def random_kmers(n, k, seed):
+    out = np.empty((n, k), dtype=np.uint8)
+    lib().synth_random_kmers(n, k, seed, _p(out))
+    return out
+
+
+def read_kmers(read_codes, k, limit=None, seed=0):
+    """k-mer windows of the reads: all of them, or `limit` sampled uniformly (seeded)."""
+    n, length = read_codes.shape
+    per = length - k + 1
+    if limit is None or limit >= n * per:
+        win = np.lib.stride_tricks.sliding_window_view(read_codes, k, axis=1)
+        return np.ascontiguousarray(win.reshape(-1, k))
+    rng = np.random.default_rng(seed)
+    r = rng.integers(0, n, size=limit)
+    p = rng.integers(0, per, size=limit)
+    idx = p[:, None] + np.arange(k)[None, :]
+    return np.ascontiguousarray(read_codes[r[:, None], idx])
+
+
+def build_msbwt_symbols(read_list_or_array, threads=0):
+    """BWT symbol codes (one per position) of a read set, in the reference's ordering."""
+    if isinstance(read_list_or_array, np.ndarray) and read_list_or_array.ndim == 2:
+        n, length = read_list_or_array.shape
+        flat = np.ascontiguousarray(read_list_or_array, dtype=np.uint8).reshape(-1)
+        offsets = (np.arange(n + 1, dtype=np.uint64) * np.uint64(length))
+    else:
+        arrs = [np.asarray(r, dtype=np.uint8) for r in read_list_or_array]
+        n = len(arrs)
+        flat = np.concatenate(arrs) if arrs else np.zeros(0, dtype=np.uint8)
+        offsets = np.concatenate([[0], np.cumsum([len(a) for a in arrs])]).astype(np.uint64)
+    out = np.empty(int(offsets[-1]) + n, dtype=np.uint8)
+    rc = lib().synth_build_msbwt(_p(flat), _p(offsets), n, _p(out), threads)
+    if rc:
+        raise ValueError("synth_build_msbwt failed (symbols must be codes 1..5)")
+    return out
+
+
+def rle_encode(symbols):
+    s = np.ascontiguousarray(symbols, dtype=np.uint8)
+    need = lib().synth_rle_encode(_p(s), s.size, None, 0)
+    out = np.empty(need, dtype=np.uint8)
+    lib().synth_rle_encode(_p(s), s.size, _p(out), need)
+    return out
+
+
+def rle_stream(target_symbols, mean_run, seed):
+    """Structure-equivalent synthetic RLE stream (NOT a real BWT). Returns (bytes, total)."""
+    cap = int(target_symbols / max(mean_run, 1.0) * 1.6) + 1024
+    while True:
+        out = np.empty(cap, dtype=np.uint8)
+        total = C.c_uint64()
+        n = lib().synth_rle_stream(target_symbols, mean_run, seed, _p(out), cap, C.byref(total))
+        if n <= cap:
+            return out[:n].copy(), int(total.value)
+        cap = int(n) + 1024
+
+
+def write_npy(path, rle_bytes):
+    """The crate's 96-byte NumPy v1.0 header + payload (bwt_converter.rs:102-130 format)."""
+    head = b"\x93NUMPY\x01\x00\x56\x00" + ("{'descr': '|u1', 'fortran_order': False, 'shape': (%d, ), }" % len(rle_bytes)).encode()
+    head = head + b" " * (95 - len(head)) + b"\n"
+    with open(path, "wb") as f:
+        f.write(head)
+        f.write(np.ascontiguousarray(rle_bytes, dtype=np.uint8).tobytes())
+
+
+# BASELINE.json configs made concrete.  scale < 1 shrinks a config for tests.
+CONFIGS = {
+    "c2": dict(genome=3_333_333, gseed=1, nreads=1_000_000, rlen=100, rseed=2, err=0.005, k=21,
+               nq=10_000_000, qseed=3, queries="random"),
+    "c3": dict(genome=4_641_652, gseed=11, nreads=1_547_217, rlen=150, rseed=12, err=0.005, k=31,
+               nq=None, qseed=13, queries="reads"),
+    "c4": dict(genome=64_444_167, gseed=21, nreads=12_888_833, rlen=150, rseed=22, err=0.005, k=31,
+               nq=100_000_000, qseed=23, queries="random"),
+}
+
+
+def workload_index(name, scale=1.0, cache=True, threads=0):
+    """Returns (path of comp_msbwt.npy, reads array) for a config, building it if needed."""
+    cfg = dict(CONFIGS[name])
+    g = max(int(cfg["genome"] * scale), 4 * cfg["rlen"])
+    n = max(int(cfg["nreads"] * scale), 4)
+    tag = "%s_g%d_n%d_l%d" % (name, g, n, cfg["rlen"])
+    os.makedirs(CACHE, exist_ok=True)
+    npy = os.path.join(CACHE, tag + "_comp_msbwt.npy")
+    rd = reads(genome(g, cfg["gseed"]), n, cfg["rlen"], cfg["rseed"], cfg["err"])
+    if not (cache and os.path.exists(npy)):
+        sym = build_msbwt_symbols(rd, threads)
+        write_npy(npy, rle_encode(sym))
+    return npy, rd

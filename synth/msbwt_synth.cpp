@@ -1,0 +1,305 @@
+// Synthetic workload generators for tests and bench.py (TEST / BENCH INFRASTRUCTURE, not
+// part of the product): a random genome, Illumina-like reads, the multi-string BWT of a read
+// set in the reference's ordering, and random k-mer queries.  Everything is integer and
+// seeded with splitmix64, so the CPU box and the GPU box produce identical inputs.
+//
+// MSBWT ordering (what the reference's msbwt2-build produces and bwt_util::naive_bwt
+// defines, src/bwt_util.rs:154-171): suffixes of read+'$' sorted with $ < A < C < G < N < T;
+// equal suffixes are ordered by their owning read's lexicographic rank.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <atomic>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <thread>
+#include <vector>
+
+namespace {
+
+inline uint64_t splitmix64(uint64_t &state) {
+    uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// stateless form: the i-th output of the stream seeded with `seed`
+inline uint64_t splitmix64_at(uint64_t seed, uint64_t i) {
+    uint64_t s = seed + i * 0x9E3779B97F4A7C15ull;
+    return splitmix64(s);
+}
+
+const uint8_t kBase[4] = {1, 2, 3, 5};  // A C G T
+
+int pick_threads(int threads) {
+    if (threads > 0) return threads;
+    unsigned hw = std::thread::hardware_concurrency();
+    return int(std::max(1u, std::min(hw, 16u)));
+}
+
+template <class Fn>
+void parallel_for(int threads, size_t n, Fn fn) {  // fn(thread, begin, end)
+    threads = int(std::min<size_t>(size_t(threads), std::max<size_t>(n, 1)));
+    if (threads <= 1) { fn(0, size_t(0), n); return; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([=] { fn(t, n * size_t(t) / size_t(threads), n * size_t(t + 1) / size_t(threads)); });
+    for (auto &th : pool) th.join();
+}
+
+struct Suffix {
+    uint64_t key;  // first 21 symbols, 3 bits each, first symbol most significant
+    uint64_t pos;  // position in the concatenated text
+};
+
+}  // namespace
+
+extern "C" {
+
+// genome[i] in {A,C,G,T} codes, uniform i.i.d.
+void synth_genome(uint64_t length, uint64_t seed, uint8_t *out) {
+    parallel_for(pick_threads(0), size_t(length), [=](int, size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) out[i] = kBase[splitmix64_at(seed, i) & 3u];
+    });
+}
+
+// n reads of `len` bases: uniform start, forward strand, each base substituted by one of
+// the other three with probability err_per_million / 1e6.  out: n x len codes.
+void synth_reads(const uint8_t *genome, uint64_t glen, uint64_t n, uint32_t len, uint64_t seed,
+                 uint32_t err_per_million, uint8_t *out) {
+    parallel_for(pick_threads(0), size_t(n), [=](int, size_t b, size_t e) {
+        for (size_t r = b; r < e; ++r) {
+            uint64_t st = seed ^ (0xD1B54A32D192ED03ull * (r + 1));
+            const uint64_t start = splitmix64(st) % (glen - len + 1);
+            uint8_t *dst = out + r * len;
+            for (uint32_t i = 0; i < len; ++i) {
+                uint8_t c = genome[start + i];
+                const uint64_t x = splitmix64(st);
+                if (uint32_t(x % 1000000u) < err_per_million) {
+                    const uint32_t which = uint32_t(x >> 32) % 3u;  // one of the other three
+                    uint32_t idx = 0;
+                    while (kBase[idx] != c) ++idx;
+                    c = kBase[(idx + 1 + which) & 3u];
+                }
+                dst[i] = c;
+            }
+        }
+    });
+}
+
+// n x k uniform k-mers over {A,C,G,T}
+void synth_random_kmers(uint64_t n, uint32_t k, uint64_t seed, uint8_t *out) {
+    parallel_for(pick_threads(0), size_t(n), [=](int, size_t b, size_t e) {
+        for (size_t q = b; q < e; ++q) {
+            uint64_t st = seed ^ (0xA0761D6478BD642Full * (q + 1));
+            uint64_t bits = 0;
+            int left = 0;
+            for (uint32_t i = 0; i < k; ++i) {
+                if (left == 0) { bits = splitmix64(st); left = 32; }
+                out[q * k + i] = kBase[bits & 3u];
+                bits >>= 2;
+                --left;
+            }
+        }
+    });
+}
+
+// Multi-string BWT of n reads (codes 1..5, no 0) given as a flat buffer with offsets[n+1].
+// Writes one symbol code per BWT position to out_symbols (sum(len)+n of them).
+// Returns 0, or -1 on bad input / out of memory.
+int synth_build_msbwt(const uint8_t *reads, const uint64_t *offsets, uint64_t n, uint8_t *out_symbols,
+                      int threads) {
+    threads = pick_threads(threads);
+    const bool verbose = std::getenv("SYNTH_VERBOSE") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!verbose) return;
+        auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[synth] %-10s %.2fs\n", what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    };
+    for (uint64_t i = 0; i < offsets[n]; ++i)
+        if (reads[i] == 0 || reads[i] > 5) return -1;
+    // 1. lexicographic order of the reads ('$' terminator smallest => shorter prefix first)
+    std::vector<uint64_t> order(n);
+    std::iota(order.begin(), order.end(), uint64_t(0));
+    auto read_less = [&](uint64_t a, uint64_t b) {
+        const uint64_t la = offsets[a + 1] - offsets[a], lb = offsets[b + 1] - offsets[b];
+        const int c = std::memcmp(reads + offsets[a], reads + offsets[b], size_t(std::min(la, lb)));
+        if (c) return c < 0;
+        if (la != lb) return la < lb;
+        return a < b;
+    };
+    {   // parallel: sort slices, then merge pairwise
+        std::vector<size_t> cuts;
+        for (int t = 0; t <= threads; ++t) cuts.push_back(size_t(n) * size_t(t) / size_t(threads));
+        parallel_for(threads, size_t(threads), [&](int, size_t b, size_t e) {
+            for (size_t s = b; s < e; ++s) std::sort(order.begin() + cuts[s], order.begin() + cuts[s + 1], read_less);
+        });
+        for (size_t width = 1; width < size_t(threads); width *= 2) {
+            std::vector<std::thread> pool;
+            for (size_t s = 0; s + width < size_t(threads); s += 2 * width) {
+                const size_t lo = cuts[s], mid = cuts[s + width], hi = cuts[std::min(s + 2 * width, size_t(threads))];
+                pool.emplace_back([&, lo, mid, hi] {
+                    std::inplace_merge(order.begin() + lo, order.begin() + mid, order.begin() + hi, read_less);
+                });
+            }
+            for (auto &th : pool) th.join();
+        }
+    }
+    lap("sort reads");
+    // 2. text = sorted reads, each followed by a 0 terminator
+    const uint64_t N = offsets[n] + n;
+    std::vector<uint64_t> tstart(n + 1);
+    tstart[0] = 0;
+    for (uint64_t r = 0; r < n; ++r) tstart[r + 1] = tstart[r] + (offsets[order[r] + 1] - offsets[order[r]]) + 1;
+    // plain malloc: the pages are first touched by the parallel loops below (a value-
+    // initialising container would fault all of them in on one thread)
+    struct Free { void operator()(void *p) const { std::free(p); } };
+    std::unique_ptr<uint8_t, Free> text_mem(static_cast<uint8_t *>(std::malloc(N + 32)));
+    std::unique_ptr<Suffix, Free> a_mem(static_cast<Suffix *>(std::malloc((N + 1) * sizeof(Suffix))));
+    std::unique_ptr<Suffix, Free> b_mem(static_cast<Suffix *>(std::malloc((N + 1) * sizeof(Suffix))));
+    if (!text_mem || !a_mem || !b_mem) return -1;
+    uint8_t *text = text_mem.get();
+    Suffix *a = a_mem.get(), *b = b_mem.get();
+    std::memset(text + N, 0, 32);
+    parallel_for(threads, size_t(n), [&](int, size_t rb, size_t re) {
+        for (size_t r = rb; r < re; ++r) {
+            const uint64_t src = offsets[order[r]], len = tstart[r + 1] - tstart[r] - 1;
+            std::memcpy(text + tstart[r], reads + src, size_t(len));
+            text[tstart[r] + len] = 0;
+            // keys, from the terminator backwards: key(p) = text[p] << 60 | key(p+1) >> 3
+            uint64_t key = 0;
+            for (uint64_t i = len + 1; i-- > 0;) {
+                const uint64_t p = tstart[r] + i;
+                key = (uint64_t(text[p]) << 60) | (key >> 3);
+                a[p].key = key;
+                a[p].pos = p;
+            }
+        }
+    });
+    lap("keys");
+    // 3. bucket by the first 4 symbols (top 12 key bits), then sort buckets in parallel
+    constexpr int kBucketBits = 12;
+    constexpr size_t kBuckets = size_t(1) << kBucketBits;
+    std::vector<std::vector<uint64_t>> hist(size_t(threads), std::vector<uint64_t>(kBuckets, 0));
+    parallel_for(threads, size_t(N), [&](int t, size_t lo, size_t hi) {
+        auto &h = hist[size_t(t)];
+        for (size_t i = lo; i < hi; ++i) ++h[a[i].key >> (63 - kBucketBits)];
+    });
+    std::vector<uint64_t> bucket_begin(kBuckets + 1, 0);
+    {
+        uint64_t acc = 0;
+        for (size_t k = 0; k < kBuckets; ++k) {
+            bucket_begin[k] = acc;
+            for (int t = 0; t < threads; ++t) {
+                const uint64_t c = hist[size_t(t)][k];
+                hist[size_t(t)][k] = acc;  // becomes this thread's write cursor
+                acc += c;
+            }
+        }
+        bucket_begin[kBuckets] = acc;
+    }
+    parallel_for(threads, size_t(N), [&](int t, size_t lo, size_t hi) {
+        auto &cur = hist[size_t(t)];
+        for (size_t i = lo; i < hi; ++i) b[cur[a[i].key >> (63 - kBucketBits)]++] = a[i];
+    });
+    a_mem.reset();
+    lap("scatter");
+    const uint8_t *tx = text;
+    auto deep_less = [tx](const Suffix &x, const Suffix &y) {
+        // equal 21-symbol keys without a terminator: keep comparing from symbol 21
+        for (uint64_t i = 21;; ++i) {
+            const uint8_t cx = tx[x.pos + i], cy = tx[y.pos + i];
+            if (cx != cy) return cx < cy;
+            if (cx == 0) return x.pos < y.pos;  // same suffix: owner's rank decides
+        }
+    };
+    std::atomic<size_t> next_bucket{0};
+    {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t)
+            pool.emplace_back([&] {
+                for (;;) {
+                    const size_t k = next_bucket.fetch_add(1);
+                    if (k >= kBuckets) break;
+                    Suffix *lo = b + bucket_begin[k], *hi = b + bucket_begin[k + 1];
+                    if (hi - lo < 2) continue;
+                    std::sort(lo, hi, [](const Suffix &x, const Suffix &y) {
+                        return x.key != y.key ? x.key < y.key : x.pos < y.pos;
+                    });
+                    // refine runs of equal keys whose 21 symbols hold no terminator
+                    for (Suffix *g = lo; g < hi;) {
+                        Suffix *e = g + 1;
+                        while (e < hi && e->key == g->key) ++e;
+                        if (e - g > 1 && (g->key & 7u) != 0) std::sort(g, e, deep_less);
+                        g = e;
+                    }
+                }
+            });
+        for (auto &th : pool) th.join();
+    }
+    lap("sort");
+    // 4. the BWT symbol of a suffix is the text symbol before it ('$' before a read start)
+    parallel_for(threads, size_t(N), [&](int, size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const uint64_t p = b[i].pos;
+            out_symbols[i] = p == 0 ? 0 : tx[p - 1];
+        }
+    });
+    lap("emit");
+    return 0;
+}
+
+// symbols (one code per position) -> RLE bytes; returns the byte count (out may be NULL)
+uint64_t synth_rle_encode(const uint8_t *symbols, uint64_t n, uint8_t *out, uint64_t cap) {
+    uint64_t w = 0, i = 0;
+    while (i < n) {
+        const uint8_t s = symbols[i];
+        uint64_t j = i + 1;
+        while (j < n && symbols[j] == s) ++j;
+        for (uint64_t len = j - i; len > 0; len >>= 5) {
+            if (out && w < cap) out[w] = uint8_t(s | ((len & 31u) << 3));
+            ++w;
+        }
+        i = j;
+    }
+    return w;
+}
+
+// Structure-equivalent synthetic RLE stream (not a real BWT): runs over {A,C,G,T} with a few
+// '$'/'N', lengths geometric with the given mean.  Writes up to cap bytes; returns bytes
+// written and the symbol total.  Used for index sizes that cannot be suffix-sorted here.
+uint64_t synth_rle_stream(uint64_t target_symbols, double mean_run, uint64_t seed, uint8_t *out, uint64_t cap,
+                          uint64_t *out_total) {
+    uint64_t st = seed, total = 0, w = 0;
+    uint8_t prev = 255;
+    const double p = 1.0 / (mean_run < 1.0 ? 1.0 : mean_run);
+    // geometric via inverse transform on a 53-bit uniform
+    const double log1mp = p >= 1.0 ? 0.0 : __builtin_log1p(-p);
+    while (total < target_symbols) {
+        const uint64_t x = splitmix64(st);
+        uint8_t sym;
+        const uint32_t pick = uint32_t(x & 1023u);
+        if (pick < 8) sym = 0; else if (pick < 12) sym = 4; else sym = kBase[(x >> 10) & 3u];
+        if (sym == prev) sym = kBase[((x >> 12) & 3u)] == prev ? uint8_t(prev == 1 ? 2 : 1) : kBase[(x >> 12) & 3u];
+        const double u = double(splitmix64(st) >> 11) * (1.0 / 9007199254740992.0);
+        uint64_t len = p >= 1.0 ? 1 : 1 + uint64_t(__builtin_log(1.0 - u) / log1mp);
+        if (len > target_symbols - total) len = target_symbols - total;
+        if (len == 0) len = 1;
+        for (uint64_t l = len; l > 0; l >>= 5) {
+            if (w < cap) out[w] = uint8_t(sym | ((l & 31u) << 3));
+            ++w;
+        }
+        total += len;
+        prev = sym;
+    }
+    if (out_total) *out_total = total;
+    return w;
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+"""The synthetic-workload generators: the fast MSBWT builder must reproduce the reference's
+ordering (checked against the oracle's naive_bwt restatement), generators are deterministic."""
+import numpy as np
+import pytest
+
+import synth
+from oracle import oracle as orc
+
+
+def _random_reads(rng, n, lo, hi, alphabet="ACGT", genome_len=200):
+    genome = "".join(rng.choice(list(alphabet), size=genome_len))
+    out = []
+    for _ in range(n):
+        length = int(rng.integers(lo, hi + 1))
+        p = int(rng.integers(0, genome_len - length + 1))
+        out.append(genome[p:p + length])
+    return out
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_builder_matches_naive_bwt(seed):
+    rng = np.random.default_rng(seed)
+    alphabet = "ACGT" if seed % 2 == 0 else "ACGNT"
+    reads = _random_reads(rng, 60, 1, 40, alphabet)
+    reads += reads[:5]                                  # exact duplicates
+    reads += ["A", "AA", "AAA", "ACA", "CA"]            # bwt_util.rs:201-236 tie-break cases
+    sym = synth.build_msbwt_symbols([orc.convert_stoi(r) for r in reads], threads=3)
+    assert orc.convert_itos(sym) == orc.naive_bwt(reads)
+
+
+def test_builder_long_shared_prefixes():
+    # suffixes equal for far more than the 21 packed symbols
+    base = "ACGTTGCA" * 12
+    reads = [base[i:i + 60] for i in range(0, 30, 3)] + [base[:70], base[:70], "T" * 50, "T" * 49]
+    sym = synth.build_msbwt_symbols([orc.convert_stoi(r) for r in reads], threads=2)
+    assert orc.convert_itos(sym) == orc.naive_bwt(reads)
+
+
+def test_builder_reference_vectors(golden):
+    for case in golden["G3_naive_bwt"]["cases"]:
+        sym = synth.build_msbwt_symbols([orc.convert_stoi(r) for r in case["strings"]])
+        assert orc.convert_itos(sym) == case["bwt"]
+
+
+def test_fixed_length_reads_array_and_rle():
+    g = synth.genome(3000, 5)
+    assert set(np.unique(g)) <= {1, 2, 3, 5}
+    rd = synth.reads(g, 300, 50, 6, 0.01)
+    assert rd.shape == (300, 50)
+    sym = synth.build_msbwt_symbols(rd)
+    assert orc.convert_itos(sym) == orc.naive_bwt([orc.convert_itos(r) for r in rd])
+    rle = synth.rle_encode(sym)
+    assert np.array_equal(rle, orc.convert_to_vec(orc.convert_itos(sym)))
+    assert np.array_equal(orc.decompress(rle), sym)
+
+
+def test_generators_are_deterministic():
+    assert np.array_equal(synth.genome(1000, 1), synth.genome(1000, 1))
+    assert not np.array_equal(synth.genome(1000, 1), synth.genome(1000, 2))
+    g = synth.genome(5000, 1)
+    assert np.array_equal(synth.reads(g, 50, 100, 2), synth.reads(g, 50, 100, 2))
+    q = synth.random_kmers(1000, 31, 3)
+    assert np.array_equal(q, synth.random_kmers(1000, 31, 3))
+    assert abs((q == 1).mean() - 0.25) < 0.02
+    # error rate is about what was asked for
+    clean = synth.reads(g, 2000, 100, 9, 0.0)
+    noisy = synth.reads(g, 2000, 100, 9, 0.05)
+    assert 0.03 < (clean != noisy).mean() < 0.07
+
+
+def test_read_kmers_and_npy(tmp_path):
+    g = synth.genome(2000, 3)
+    rd = synth.reads(g, 20, 40, 4, 0.0)
+    allk = synth.read_kmers(rd, 31)
+    assert allk.shape == (20 * 10, 31)
+    assert np.array_equal(allk[10], rd[1, 0:31])
+    some = synth.read_kmers(rd, 31, limit=50, seed=1)
+    assert some.shape == (50, 31)
+    rle = synth.rle_encode(synth.build_msbwt_symbols(rd))
+    a, b = str(tmp_path / "a.npy"), str(tmp_path / "b.npy")
+    synth.write_npy(a, rle)
+    orc.save_bwt_numpy(rle, b)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    o = orc.OracleRleBWT()
+    o.load_numpy_file(a)
+    assert o.count_kmers(allk).min() >= 1           # every read k-mer is present
+
+
+def test_rle_stream_is_well_formed():
+    rle, total = synth.rle_stream(200000, 6.0, 7)
+    plain = orc.decompress(rle)
+    assert len(plain) == total == 200000
+    runs = 1 + int((plain[1:] != plain[:-1]).sum())
+    assert 4.0 < total / runs < 8.0
