@@ -1,11 +1,21 @@
 // gfx950 (MI355X, CDNA4) kernels for batched FM-index backward search over plane blocks.
 // Integer / bit work bound by random 128-byte fetches: no MFMA anywhere.
 //
-// Work decomposition: an 8-lane group owns one query (64-lane wave = 8 queries in flight).
-// For a rank the group's 8 lanes load the 8 x 16-byte chunks of one 128-byte block with a
-// single coalesced global_load_dwordx4, each lane popcounts its 32 symbols, and the group
-// sums with three DPP steps (quad_perm xor 1, xor 2, row_half_mirror) -- no LDS, no
-// barriers.  Layout of a block: plane_index.hpp.
+// Rank primitive: an 8-lane group owns one query.  For a rank the group's 8 lanes load the
+// 8 x 16-byte chunks of one 128-byte block with a single coalesced global_load_dwordx4, each
+// lane popcounts its 32 symbols, and the group sums with three DPP steps (quad_perm xor 1,
+// xor 2, row_half_mirror) -- no LDS traffic, no barriers.  Block layout: plane_index.hpp.
+//
+// count_kmers (k <= 32) works on tiles of 64 queries per wave, in two phases:
+//   1. lane-per-query setup: the tile's query bytes are staged through LDS with coalesced
+//      16-byte loads; every lane validates and bit-packs one query and looks its last
+//      `depth` symbols up in the suffix table (64 independent loads in flight per wave).
+//      Queries that are already decided are done; the others are compacted into an LDS
+//      work list with a wave ballot + prefix count.
+//   2. group-per-query search: the wave's 8 groups pull queries off the work list and run
+//      one backward-search step per loop iteration each, refilling as they finish, so lanes
+//      stay busy although queries need different numbers of steps.
+// Results go to LDS and leave as one coalesced 512-byte store per tile.
 #include <hip/hip_runtime.h>
 
 #include "kernels.hpp"
@@ -13,9 +23,12 @@
 namespace msbwt {
 namespace {
 
-constexpr int kGroup = 8;  // lanes per query
+constexpr int kGroup = 8;       // lanes per query in the search phase
+constexpr int kTile = 64;       // queries per wave tile
+constexpr int kMaxShortK = 32;  // tiled kernel: symbols fit 96 bits
+constexpr int kWavesPerBlock = 4;
 
-// x + (value of x in the lane selected by the DPP control), all 64 lanes
+// x (op) value of x in the lane selected by the DPP control, all 64 lanes
 template <int kCtrl>
 __device__ __forceinline__ uint32_t dpp_add(uint32_t x) {
     return x + uint32_t(__builtin_amdgcn_update_dpp(0, int(x), kCtrl, 0xF, 0xF, true));
@@ -61,10 +74,19 @@ __device__ __forceinline__ Range constrain(const uint4 *__restrict__ blocks, uin
     return r;
 }
 
-// ---- count_kmers, version 1: one query per group at a time, symbols read as needed ----
-__global__ __launch_bounds__(256) void k_count_kmers(const uint4 *__restrict__ blocks, uint64_t total,
-                                                     const uint8_t *__restrict__ kmers, uint32_t k, uint64_t n,
-                                                     uint64_t *__restrict__ counts, uint32_t *__restrict__ flags) {
+// compiler-level ordering of one wave's LDS writes before its later LDS reads (the LDS
+// executes a wave's operations in issue order; no s_barrier is needed inside a wave)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- count_kmers, any k: one query per group at a time, symbols read as needed ----------
+__global__ __launch_bounds__(256) void k_count_kmers_generic(const uint4 *__restrict__ blocks, uint64_t total,
+                                                             const uint8_t *__restrict__ kmers, uint32_t k,
+                                                             uint64_t n, uint64_t *__restrict__ counts,
+                                                             uint32_t *__restrict__ flags) {
     const uint32_t sub = threadIdx.x & (kGroup - 1);
     const uint64_t ngroups = (uint64_t(gridDim.x) * blockDim.x) / kGroup;
     for (uint64_t q = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) / kGroup; q < n; q += ngroups) {
@@ -84,6 +106,187 @@ __global__ __launch_bounds__(256) void k_count_kmers(const uint4 *__restrict__ b
         }
         if (sub == 0) counts[q] = result;
     }
+}
+
+// ---- count_kmers, 1 <= k <= 32: tiled two-phase kernel -----------------------------------
+struct alignas(16) WorkItem {  // one undecided query of the tile, 32 bytes
+    uint32_t l_lo, l_hi, h_lo, h_hi;
+    uint32_t w0, w1, w2;  // remaining symbols, 3 bits each, next step in the low bits
+    uint32_t rem_slot;    // remaining steps | slot in tile << 8
+};
+
+struct WaveScratch {
+    uint4 stage[kTile * kMaxShortK / 16];  // the tile's query bytes (2 KiB)
+    WorkItem work[kTile];                  // 2 KiB
+    uint64_t result[kTile];                // 512 B
+};
+
+__global__ __launch_bounds__(256) void k_count_kmers_tiled(const uint4 *__restrict__ blocks, uint64_t total,
+                                                           const uint4 *__restrict__ table, uint32_t depth,
+                                                           const uint8_t *__restrict__ kmers, uint32_t k, uint64_t n,
+                                                           uint64_t *__restrict__ counts, uint32_t *__restrict__ flags) {
+    __shared__ WaveScratch scratch[kWavesPerBlock];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t sub = lane & (kGroup - 1);
+    const uint32_t group_first_lane = lane & ~uint32_t(kGroup - 1);
+    WaveScratch &ws = scratch[threadIdx.x >> 6];
+    const uint8_t *stage_bytes = reinterpret_cast<const uint8_t *>(ws.stage);
+
+    const uint64_t ntiles = (n + kTile - 1) / kTile;
+    const uint64_t wave_id = uint64_t(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+    const uint64_t nwaves = uint64_t(gridDim.x) * kWavesPerBlock;
+    const bool use_table = table != nullptr && depth > 0 && k >= depth;
+
+    for (uint64_t tile = wave_id; tile < ntiles; tile += nwaves) {
+        const uint64_t q0 = tile * kTile;
+        const uint32_t in_tile = uint32_t(min(uint64_t(kTile), n - q0));
+        // ---- phase 1a: stage the tile's bytes (contiguous, 16-byte aligned) through LDS ----
+        {
+            const uint8_t *src = kmers + q0 * k;
+            const uint32_t nbytes = in_tile * k;
+            for (uint32_t piece = lane; piece * 16u < nbytes; piece += 64u) {
+                uint4 v;
+                if (piece * 16u + 16u <= nbytes) {
+                    v = *reinterpret_cast<const uint4 *>(src + piece * 16u);
+                } else {  // ragged end of the batch: never read past the caller's buffer
+                    uint32_t w[4] = {0u, 0u, 0u, 0u};
+                    for (uint32_t b = piece * 16u; b < nbytes; ++b) w[(b & 15u) >> 2] |= uint32_t(src[b]) << ((b & 3u) * 8u);
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                ws.stage[piece] = v;
+            }
+        }
+        wave_lds_sync();
+        // ---- phase 1b: one lane = one query: validate, pack, table lookup ----
+        bool pending = false;
+        uint64_t l = 0, h = total;
+        uint32_t w0 = 0, w1 = 0, w2 = 0, rem = k;
+        if (lane < in_tile) {
+            uint64_t lo = 0, hi = 0;  // symbol of step t (t = 0 first) at bits [3t, 3t+3) of hi:lo
+            uint32_t bad = 0, acgt = 1, tidx = 0;
+            const uint8_t *mine = stage_bytes + lane * k;
+            for (uint32_t t = 0; t < k; ++t) {
+                const uint32_t s = mine[k - 1u - t];
+                bad |= (s >= 6u) ? 1u : 0u;
+                const uint32_t pos = 3u * t;
+                if (pos < 64u) {
+                    lo |= uint64_t(s & 7u) << pos;
+                    if (pos > 61u) hi |= uint64_t(s & 7u) >> (64u - pos);
+                } else {
+                    hi |= uint64_t(s & 7u) << (pos - 64u);
+                }
+                if (t < depth) {  // table index: A C G T -> 0..3, step t at bits [2t, 2t+2)
+                    const uint32_t two = (s == 5u) ? 3u : (s - 1u);
+                    acgt &= (s == 5u || (s >= 1u && s <= 3u)) ? 1u : 0u;
+                    tidx |= (two & 3u) << (2u * t);
+                }
+            }
+            if (bad) {
+                ws.result[lane] = ~0ull;
+                atomicOr(flags, kFlagInvalidSymbol);
+            } else {
+                if (use_table && acgt) {
+                    const uint4 e = table[tidx];
+                    l = (uint64_t(e.y) << 32) | e.x;
+                    h = (uint64_t(e.w) << 32) | e.z;
+                    rem = k - depth;
+                    const uint32_t sh = 3u * depth;  // 3..39
+                    lo = (lo >> sh) | (hi << (64u - sh));
+                    hi >>= sh;
+                }
+                if (rem == 0u || l == h) {
+                    ws.result[lane] = h - l;
+                } else {
+                    pending = true;
+                    w0 = uint32_t(lo);
+                    w1 = uint32_t(lo >> 32);
+                    w2 = uint32_t(hi);
+                }
+            }
+        }
+        // compact the undecided queries into the work list: ballot + prefix count
+        const uint64_t pend_mask = __ballot(pending);
+        const uint32_t nwork = uint32_t(__popcll(pend_mask));
+        if (pending) {
+            const uint32_t at = __builtin_amdgcn_mbcnt_hi(uint32_t(pend_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(pend_mask), 0u));
+            WorkItem it;
+            it.l_lo = uint32_t(l); it.l_hi = uint32_t(l >> 32);
+            it.h_lo = uint32_t(h); it.h_hi = uint32_t(h >> 32);
+            it.w0 = w0; it.w1 = w1; it.w2 = w2;
+            it.rem_slot = rem | (lane << 8);
+            ws.work[at] = it;
+        }
+        wave_lds_sync();
+        // ---- phase 2: groups pull work items; one backward-search step per iteration ----
+        {
+            uint32_t next = 0;  // wave-uniform: first unassigned work item
+            bool have = false;
+            uint32_t slot = 0;
+            for (;;) {
+                // hand the next items to the idle groups, in group order
+                const uint64_t idle = __ballot(!have && sub == 0u);  // one bit per idle group (its first lane)
+                const uint32_t idle_before = uint32_t(__popcll(idle & ((1ull << group_first_lane) - 1ull)));
+                if (!have && next + idle_before < nwork) {
+                    const WorkItem *it = &ws.work[next + idle_before];
+                    const uint4 a = *reinterpret_cast<const uint4 *>(it);
+                    const uint4 b = *(reinterpret_cast<const uint4 *>(it) + 1);
+                    l = (uint64_t(a.y) << 32) | a.x;
+                    h = (uint64_t(a.w) << 32) | a.z;
+                    w0 = b.x; w1 = b.y; w2 = b.z;
+                    rem = b.w & 0xFFu;
+                    slot = b.w >> 8;
+                    have = true;
+                }
+                next = min(nwork, next + uint32_t(__popcll(idle)));
+                if (!__any(have)) break;
+                if (have) {
+                    const Range r = constrain(blocks, w0 & 7u, l, h, sub);
+                    l = r.l;
+                    h = r.h;
+                    w0 = __builtin_amdgcn_alignbit(w1, w0, 3);
+                    w1 = __builtin_amdgcn_alignbit(w2, w1, 3);
+                    w2 >>= 3;
+                    --rem;
+                    if (rem == 0u || l == h) {
+                        if (sub == 0u) ws.result[slot] = h - l;
+                        have = false;
+                    }
+                }
+            }
+        }
+        wave_lds_sync();
+        if (lane < in_tile) counts[q0 + lane] = ws.result[lane];
+        wave_lds_sync();  // the next tile must not overwrite result[] / stage[] before this
+    }
+}
+
+// ---- suffix table, built level by level in place ------------------------------------------
+// Level j holds the range of every ACGT string of length j, indexed by sum(two(x_t) << 2t)
+// with x_0 the LAST symbol of the k-mer (the first one searched).  A group reads one parent
+// (level j-1, index p) and writes its four children p + c * 4^(j-1); child 0 overwrites the
+// parent only after the group has read it.
+__global__ __launch_bounds__(256) void k_table_level(const uint4 *__restrict__ blocks, uint4 *__restrict__ table,
+                                                     uint32_t level) {
+    const uint32_t sub = threadIdx.x & (kGroup - 1);
+    const uint64_t parents = 1ull << (2u * (level - 1u));
+    const uint64_t ngroups = (uint64_t(gridDim.x) * blockDim.x) / kGroup;
+    for (uint64_t p = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) / kGroup; p < parents; p += ngroups) {
+        const uint4 e = table[p];
+        const uint64_t l = (uint64_t(e.y) << 32) | e.x, h = (uint64_t(e.w) << 32) | e.z;
+        Range mine{0, 0};  // lane c of the group keeps child c
+        for (uint32_t c = 0; c < 4u; ++c) {
+            const uint32_t s = c == 3u ? 5u : c + 1u;  // A C G T
+            const Range r = (l == h) ? Range{0, 0} : constrain(blocks, s, l, h, sub);
+            if (sub == c) mine = r;
+        }
+        if (sub < 4u)
+            table[p + uint64_t(sub) * parents] =
+                make_uint4(uint32_t(mine.l), uint32_t(mine.l >> 32), uint32_t(mine.h), uint32_t(mine.h >> 32));
+    }
+}
+
+__global__ void k_table_root(uint4 *table, uint64_t total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) table[0] = make_uint4(0u, 0u, uint32_t(total), uint32_t(total >> 32));
 }
 
 __global__ __launch_bounds__(256) void k_constrain_ranges(const uint4 *__restrict__ blocks, uint64_t total,
@@ -112,9 +315,9 @@ __global__ __launch_bounds__(256) void k_constrain_ranges(const uint4 *__restric
     }
 }
 
-inline uint32_t grid_for(uint64_t n_groups_wanted) {
-    // 256 CUs x 8 blocks of 256 threads fill the chip; smaller batches get just enough blocks
-    const uint64_t blocks = (n_groups_wanted * kGroup + 255) / 256;
+// 256 CUs x 8 blocks of 256 threads fill the chip; smaller batches get just enough blocks
+inline uint32_t grid_for(uint64_t threads_wanted) {
+    const uint64_t blocks = (threads_wanted + 255) / 256;
     return uint32_t(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
 }
 
@@ -123,8 +326,17 @@ inline uint32_t grid_for(uint64_t n_groups_wanted) {
 hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_t k, uint64_t n,
                               uint64_t *counts, uint32_t *flags, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_count_kmers, dim3(grid_for(n)), dim3(256), 0, stream,
-                       static_cast<const uint4 *>(ix.blocks), ix.total, kmers, k, n, counts, flags);
+    const uint4 *blocks = static_cast<const uint4 *>(ix.blocks);
+    const bool aligned = (reinterpret_cast<uintptr_t>(kmers) & 15u) == 0;
+    if (k >= 1 && k <= uint32_t(kMaxShortK) && aligned) {
+        const uint64_t tiles = (n + kTile - 1) / kTile;
+        hipLaunchKernelGGL(k_count_kmers_tiled, dim3(grid_for(tiles * 64)), dim3(256), 0, stream, blocks, ix.total,
+                           static_cast<const uint4 *>(ix.table.entries), uint32_t(ix.table.depth), kmers, k, n,
+                           counts, flags);
+    } else {
+        hipLaunchKernelGGL(k_count_kmers_generic, dim3(grid_for(n * kGroup)), dim3(256), 0, stream, blocks,
+                           ix.total, kmers, k, n, counts, flags);
+    }
     return hipGetLastError();
 }
 
@@ -132,11 +344,21 @@ hipError_t launch_constrain_ranges(const IndexView &ix, const uint8_t *syms, con
                                    const uint64_t *h, uint64_t n, uint64_t *out_l, uint64_t *out_h,
                                    uint32_t *flags, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_constrain_ranges, dim3(grid_for(n)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(k_constrain_ranges, dim3(grid_for(n * kGroup)), dim3(256), 0, stream,
                        static_cast<const uint4 *>(ix.blocks), ix.total, syms, l, h, n, out_l, out_h, flags);
     return hipGetLastError();
 }
 
-hipError_t launch_build_table(const IndexView &, int, void *, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_build_table(const IndexView &ix, int depth, void *entries, hipStream_t stream) {
+    if (depth < 1 || depth > 13) return hipErrorInvalidValue;
+    uint4 *table = static_cast<uint4 *>(entries);
+    hipLaunchKernelGGL(k_table_root, dim3(1), dim3(64), 0, stream, table, ix.total);
+    for (int level = 1; level <= depth; ++level) {
+        const uint64_t parents = 1ull << (2 * (level - 1));
+        hipLaunchKernelGGL(k_table_level, dim3(grid_for(parents * kGroup)), dim3(256), 0, stream,
+                           static_cast<const uint4 *>(ix.blocks), table, uint32_t(level));
+    }
+    return hipGetLastError();
+}
 
 }  // namespace msbwt

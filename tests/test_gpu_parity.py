@@ -233,3 +233,59 @@ def test_reload_replaces_index():
     b.load_vector(msbwt.bwt_converter.convert_to_vec("TG$$CAGCCG"))
     assert b.get_total_size() == 10
     assert b.count_kmer(stoi("CG")) == 2
+
+
+@pytest.mark.parametrize("depth", [0, 1, 2, 5, 9])
+def test_suffix_table_never_changes_results(depth):
+    """The precomputed suffix table (the reference's stubbed kmer_cache idea) must be
+    invisible: same counts for every depth, for k below/at/above the depth, with $ and N."""
+    reads, rle = _real_bwt(7, 200, 70)
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    b.set_table_depth(depth)
+    assert b.get_table_depth() == depth
+    rng = np.random.default_rng(depth)
+    for k in (1, 3, 5, 9, 10, 21, 31, 32):
+        qs = [orc.convert_stoi(r[p:p + k]) for r in reads for p in (int(rng.integers(0, len(r) - k + 1)),)]
+        qs = np.concatenate([np.array(qs, dtype=np.uint8), random_kmers(k, 200, k),
+                             random_kmers(k + 7, 100, k, alphabet=(0, 1, 2, 3, 4, 5))])
+        assert np.array_equal(b.count_kmers(qs), o.count_kmers(qs)), (depth, k)
+
+
+def test_table_rebuilt_on_reload_and_auto_depth():
+    rle = random_stream(8, 60000, "short")
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    d = b.get_table_depth()
+    assert 1 <= d <= 11 and 4 ** d <= o.get_total_size()
+    qs = random_kmers(1, 3000, 12)
+    assert np.array_equal(b.count_kmers(qs), o.count_kmers(qs))
+    b.load_vector(msbwt.bwt_converter.convert_to_vec("TG$$CAGCCG"))   # tiny: table depth shrinks
+    assert b.get_table_depth() <= 1
+    assert b.count_kmer(stoi("CG")) == 2
+
+
+def test_device_pointer_api_alignment_and_ragged_tiles():
+    """Device-pointer entry point (torch only supplies HBM buffers): batch sizes around the
+    64-query tile, and a misaligned query buffer (takes the generic kernel)."""
+    torch = pytest.importorskip("torch")
+    reads, rle = _real_bwt(9, 120, 64)
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    k = 21
+    base = np.concatenate([np.array([orc.convert_stoi(r[3:3 + k]) for r in reads], dtype=np.uint8), random_kmers(3, 400, k)])
+    for n in (1, 7, 63, 64, 65, 127, 128, 129, 520):
+        for offset in (0, 5):
+            buf = torch.zeros(n * k + 64, dtype=torch.uint8, device=dev)
+            buf[offset:offset + n * k] = torch.from_numpy(base[:n].reshape(-1)).to(dev)
+            out = torch.full((n + 2,), -7, dtype=torch.int64, device=dev)
+            b.count_kmers_device(buf.data_ptr() + offset, k, n, out.data_ptr() + 8, stream)
+            b.device_status(stream)
+            got = out.cpu().numpy()
+            assert got[0] == -7 and got[-1] == -7          # nothing written outside the batch
+            assert np.array_equal(got[1:-1].astype(np.uint64), o.count_kmers(base[:n])), (n, offset)
