@@ -12,10 +12,10 @@ string_util, bwt_converter.  Everything that computes runs in libmsbwt_hip.so.
 from . import _lib
 from .msbwt_core import BWT, BWTRange, VC_LEN, LETTER_BITS, NUMBER_BITS, NUM_POWER, MASK, COUNT_MASK
 from .rle_bwt import RleBWT, MsbwtError
-from . import string_util, bwt_converter, msbwt_core, rle_bwt
+from . import string_util, bwt_converter, msbwt_core, rle_bwt, sharded
 
 __all__ = ["BWT", "BWTRange", "RleBWT", "MsbwtError", "string_util", "bwt_converter", "msbwt_core",
-           "rle_bwt", "VC_LEN", "LETTER_BITS", "NUMBER_BITS", "NUM_POWER", "MASK", "COUNT_MASK"]
+           "rle_bwt", "sharded", "VC_LEN", "LETTER_BITS", "NUMBER_BITS", "NUM_POWER", "MASK", "COUNT_MASK"]
 
 
 def version():

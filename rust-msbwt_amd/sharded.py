@@ -1,0 +1,78 @@
+"""Query sharding across the GPUs of one node.
+
+count_kmer calls are independent and read-only (`&self`, src/msbwt_core.rs:125), so the path
+shards over queries: every rank holds a replica of the index, takes a contiguous slice of the
+batch, and the per-rank counts are exchanged with ONE collective -- an all_gather over RCCL
+(xGMI) of `ceil(n/world)` u64 per rank.  No other communication exists on this path.
+
+torch / torch.distributed are plumbing here (device buffers, streams, the process group).
+"""
+import numpy as np
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous, balanced slices: the first n % world ranks get one extra query."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_capacity(n, world):
+    return -(-n // world) if world > 0 else n
+
+
+class ShardedCounter:
+    """Counts a batch that every rank can see, each rank doing its slice, all ranks ending
+    up with the whole count vector.
+
+    `count_local(kmers_slice) -> counts` is the per-rank worker; by default it runs the
+    rank's `RleBWT` on its GPU (device-pointer entry point).  Tests inject a CPU worker to
+    exercise the sharding and the collective under gloo.
+    """
+
+    def __init__(self, bwt=None, group=None, count_local=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.bwt = bwt
+        self.device = device
+        self._count_local = count_local or self._count_on_gpu
+        if count_local is None and bwt is None:
+            raise ValueError("need an RleBWT (GPU worker) or an explicit count_local")
+
+    def _count_on_gpu(self, d_kmers):
+        torch = self.torch
+        n, k = d_kmers.shape
+        out = torch.empty(n, dtype=torch.int64, device=d_kmers.device)
+        stream = torch.cuda.current_stream(d_kmers.device).cuda_stream
+        self.bwt.count_kmers_device(d_kmers.data_ptr(), k, n, out.data_ptr(), stream)
+        return out
+
+    def count_kmers(self, kmers):
+        """kmers: (n, k) uint8 tensor on this rank's device (same content on every rank).
+        Returns int64[n] on the same device (bit pattern of the u64 counts)."""
+        torch, dist = self.torch, self.dist
+        n = kmers.shape[0]
+        lo, hi = shard_bounds(n, self.world, self.rank)
+        mine = self._count_local(kmers[lo:hi].contiguous())
+        if self.world == 1:
+            return mine
+        cap = shard_capacity(n, self.world)
+        padded = torch.zeros(cap, dtype=torch.int64, device=kmers.device)
+        padded[:hi - lo] = mine
+        gathered = torch.empty(cap * self.world, dtype=torch.int64, device=kmers.device)
+        dist.all_gather_into_tensor(gathered, padded, group=self.group)
+        # drop the padding of the short shards
+        pieces = []
+        for r in range(self.world):
+            a, b = shard_bounds(n, self.world, r)
+            pieces.append(gathered[r * cap:r * cap + (b - a)])
+        return torch.cat(pieces)
+
+
+def as_u64(t):
+    """int64 tensor holding u64 bit patterns -> numpy uint64."""
+    return t.detach().cpu().numpy().view(np.uint64)

@@ -1,0 +1,65 @@
+"""The N>1 path on CPU: world_size-2 (and 3) gloo process groups exercise the shard bounds
+and the single all_gather; the per-rank worker is the CPU oracle here (the GPU worker is
+covered by the -m gpu tests and bench.py --gpus N)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import rust_msbwt_amd as msbwt
+from rust_msbwt_amd.sharded import ShardedCounter, shard_bounds, shard_capacity
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 2, 7, 64, 100, 1001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1 and max(sizes) <= shard_capacity(n, world)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n, k, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as orc
+        from rle_random import random_kmers, random_stream
+        ref = orc.OracleRleBWT()
+        ref.load_vector(random_stream(3, 5000, "short"))
+
+        def cpu_worker(kmers):
+            return torch.from_numpy(ref.count_kmers(kmers.numpy()).view(np.int64).copy())
+
+        counter = ShardedCounter(count_local=cpu_worker)
+        assert counter.world == world and counter.rank == rank
+        q = random_kmers(9, n, k, alphabet=(0, 1, 2, 3, 4, 5))
+        got = counter.count_kmers(torch.from_numpy(q))
+        exp = ref.count_kmers(q)
+        ok = np.array_equal(msbwt.sharded.as_u64(got), exp)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 1001), (2, 64), (3, 10), (2, 1)])
+def test_sharded_count_matches_single_process(world, n):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n, 6, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
