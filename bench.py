@@ -37,12 +37,51 @@ def make_queries(synth, cfg, reads, nq, k, seed, kind):
     return synth.read_kmers(reads, k, limit=nq, seed=seed)
 
 
+def walk_kmers(torch, bwt, dev, total, n, k, seed):
+    """k-mers that are present in the index, for streams that are not the BWT of known reads:
+    start at a random row r with the one-row range [r, r+1) and prepend, k times, the symbol
+    stored at that row (the one symbol whose constrain_range keeps the row) -- an LF walk run
+    with the product's own batched constrain_ranges.  Walks that meet '$' or 'N' are dropped
+    (read k-mers never contain them).  Workload generation only; outside every timed region."""
+    rng = np.random.default_rng(seed)
+    m = int(n * 1.6) + 1024
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    l = torch.from_numpy(rng.integers(0, total, size=m, dtype=np.int64)).to(dev)
+    h = l + 1
+    kmers = torch.zeros((m, k), dtype=torch.uint8, device=dev)
+    ok = torch.ones(m, dtype=torch.bool, device=dev)
+    ol = torch.empty_like(l)
+    oh = torch.empty_like(l)
+    for step in range(k):
+        nl = torch.zeros_like(l)
+        nh = torch.zeros_like(l)
+        sym_at = torch.zeros(m, dtype=torch.uint8, device=dev)
+        for s in range(6):
+            syms = torch.full((m,), s, dtype=torch.uint8, device=dev)
+            bwt.constrain_ranges_device(syms.data_ptr(), l.data_ptr(), h.data_ptr(), m, ol.data_ptr(), oh.data_ptr(), stream)
+            torch.cuda.synchronize(dev)
+            hit = (oh - ol) == 1
+            nl = torch.where(hit, ol, nl)
+            nh = torch.where(hit, oh, nh)
+            sym_at = torch.where(hit, torch.full_like(sym_at, s), sym_at)
+        kmers[:, k - 1 - step] = sym_at
+        ok &= (sym_at != 0) & (sym_at != 4)
+        l, h = nl, nh
+    bwt.device_status(stream)
+    out = kmers[ok][:n].cpu().numpy()
+    assert len(out) == n, "LF walk produced too few ACGT-only k-mers (%d of %d)" % (len(out), n)
+    return np.ascontiguousarray(out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "big"])
+    ap.add_argument("--big-symbols", type=float, default=2.0**33, help="workload big: BWT length")
+    ap.add_argument("--big-mean-run", type=float, default=6.0)
+    ap.add_argument("--stats-sample", type=int, default=0, help="queries used for the algorithmic-byte counters (0 = all)")
     ap.add_argument("--queries", type=int, default=0, help="queries per GPU per step (0 = the config's)")
     ap.add_argument("--k", type=int, default=0, help="override k")
     ap.add_argument("--query-kind", default="", choices=["", "random", "reads"])
@@ -72,31 +111,48 @@ def main():
     msbwt = importlib.import_module("rust-msbwt_amd")
     import synth
 
-    cfg = dict(synth.CONFIGS[args.workload])
+    big = args.workload == "big"
+    cfg = dict(synth.CONFIGS["c3" if big else args.workload])
     k = args.k or cfg["k"]
-    kind = args.query_kind or cfg["queries"]
-    nq = args.queries or cfg["nq"] or 20_000_000
+    kind = args.query_kind or ("walk" if big else cfg["queries"])
+    nq = args.queries or (20_000_000 if big else cfg["nq"]) or 20_000_000
     nq = int(nq * min(1.0, args.scale * 4)) if args.scale < 1.0 and not args.queries else nq
 
-    # ---- inputs: rank 0 builds (and caches) the index file, everyone loads it -------------
-    t0 = time.time()
-    if rank == 0:
-        npy, reads = synth.workload_index(args.workload, args.scale)
-    if world > 1:
-        dist.barrier()
-    if rank != 0:
-        npy, reads = synth.workload_index(args.workload, args.scale)
-    log("rank %d: index file %s ready in %.1fs" % (rank, os.path.basename(npy), time.time() - t0))
-    t0 = time.time()
     bwt = msbwt.RleBWT(device=local_rank)
     if args.table_depth > -2:
         bwt.set_table_depth(args.table_depth)
-    bwt.load_numpy_file(npy)
+    t0 = time.time()
+    if big:
+        # structure-equivalent synthetic RLE stream (NOT a real BWT): sizes that cannot be
+        # suffix-sorted here.  Same seed on every rank => identical replicas.
+        rle, _ = synth.rle_stream(int(args.big_symbols), args.big_mean_run, 77)
+        log("rank %d: synthetic RLE stream of %d bytes in %.1fs" % (rank, len(rle), time.time() - t0))
+        t0 = time.time()
+        bwt.load_vector(rle)
+        npy, reads = None, None
+    else:
+        # rank 0 builds (and caches) the index file, everyone loads it
+        if rank == 0:
+            npy, reads = synth.workload_index(args.workload, args.scale)
+        if world > 1:
+            dist.barrier()
+        if rank != 0:
+            npy, reads = synth.workload_index(args.workload, args.scale)
+        log("rank %d: index file %s ready in %.1fs" % (rank, os.path.basename(npy), time.time() - t0))
+        t0 = time.time()
+        bwt.load_numpy_file(npy)
     total = bwt.get_total_size()
     log("rank %d: %d symbols on the GPU (%.1f MB index, table depth %d) in %.1fs"
         % (rank, total, bwt.device_bytes() / 1e6, bwt.get_table_depth(), time.time() - t0))
 
-    queries = make_queries(synth, cfg, reads, nq, k, cfg["qseed"] + 1000 * rank, kind)
+    if big and kind == "walk":
+        t0 = time.time()
+        queries = walk_kmers(torch, bwt, dev, total, nq, k, 4242 + rank)
+        log("rank %d: %d present %d-mers by LF-walk on the GPU in %.1fs" % (rank, len(queries), k, time.time() - t0))
+    elif big:
+        queries = synth.random_kmers(nq, k, 4242 + 1000 * rank)
+    else:
+        queries = make_queries(synth, cfg, reads, nq, k, cfg["qseed"] + 1000 * rank, kind)
     nq = len(queries)
     d_q = torch.from_numpy(queries).to(dev)
     d_out = torch.empty(nq, dtype=torch.int64, device=dev)
@@ -147,7 +203,10 @@ def main():
         "dtype": "u64",
         "data": "synthetic",
         "config": {
-            "workload": "%s: %d synthetic %d-bp reads (%.0fx of a %d-bp random genome, %.1f%% subst.) -> MSBWT of %d symbols; "
+            "workload": ("big: structure-equivalent synthetic RLE stream (NOT a real BWT), %d symbols, mean run %.1f; "
+                         "%d %s %d-mers per GPU per step" % (total, args.big_mean_run, nq,
+                                                             "present (LF-walk)" if kind == "walk" else "random", k)) if big else
+                        "%s: %d synthetic %d-bp reads (%.0fx of a %d-bp random genome, %.1f%% subst.) -> MSBWT of %d symbols; "
                         "%d %s %d-mers per GPU per step" % (
                             args.workload, len(reads), reads.shape[1], len(reads) * reads.shape[1] / max(1, int(cfg["genome"] * args.scale)),
                             int(cfg["genome"] * args.scale), cfg["err"] * 100, total, nq,
@@ -162,7 +221,10 @@ def main():
         # ---- parity + algorithmic bytes (the oracle is the checker, never the thing timed as `value`) ----
         from oracle import oracle as orc
         ref = orc.OracleRleBWT(8)
-        ref.load_numpy_file(npy)
+        if big:
+            ref.load_vector(rle)
+        else:
+            ref.load_numpy_file(npy)
         got = d_out.cpu().numpy().astype(np.uint64)
         ns = min(nq, args.parity_sample)
         sel = np.linspace(0, nq - 1, ns).astype(np.int64)
@@ -175,10 +237,11 @@ def main():
         # algorithmic bytes of the reference algorithm for THIS query set: exact counters
         st = orc.Stats()
         ncpu = min(os.cpu_count() or 1, 16)
+        nst = min(nq, args.stats_sample) if args.stats_sample else nq
         t0 = time.time()
-        ref.count_kmers(queries, nthreads=ncpu, stats=st)
+        ref.count_kmers(queries[:nst], nthreads=ncpu, stats=st)
         t_all = time.time() - t0
-        alg_bytes = st.algorithmic_bytes(k)
+        alg_bytes = st.algorithmic_bytes(k) * (nq / nst)  # exact when nst == nq, else scaled from the sample
         kern_s = kernel_ms / 1e3 if launches else elapsed / args.steps
         achieved = alg_bytes / kern_s / 1e9
         result["roofline"] = {
@@ -187,7 +250,8 @@ def main():
             "kernel": "k_count_kmers", "kernel_ms": kernel_ms, "kernel_launches": launches,
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "algorithmic_bytes_per_query": alg_bytes / nq,
-            "mean_steps_per_query": st.steps / nq, "mean_bin_visits_per_query": st.visits / nq,
+            "mean_steps_per_query": st.steps / nst, "mean_bin_visits_per_query": st.visits / nst,
+            "stats_queries": int(nst),
         }
         if world == 1 and not args.no_cpu_baseline:
             ncs = min(nq, args.cpu_sample)
@@ -197,7 +261,7 @@ def main():
             result["cpu_baseline"] = {
                 "value": ncs / t1, "unit": "queries/s", "cores": 1, "kind": "port",
                 "sample": "first %d queries of the same batch, same comp_msbwt.npy, 1 thread (the reference is single-threaded), -O3 C restatement" % ncs,
-                "all_cores": {"value": nq / t_all, "cores": ncpu, "note": "same batch, static partition, instrumented build"},
+                "all_cores": {"value": nst / t_all, "cores": ncpu, "note": "same batch, static partition, instrumented build"},
             }
         print(json.dumps(result), flush=True)
     if world > 1:

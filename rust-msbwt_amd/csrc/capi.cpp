@@ -41,6 +41,8 @@ struct msbwt_rle {
 
 namespace {
 
+constexpr int kMaxTableDepth = 16;  // 4^16 x 16 B = 64 GiB
+
 const char *kVersion = "rust-msbwt_amd 0.1.0 (gfx950 plane-block index)";
 
 // Makes the handle's device current for the scope, restoring the caller's afterwards (the
@@ -120,12 +122,16 @@ int ensure_stage(msbwt_rle *h, size_t bytes) {
     return MSBWT_OK;
 }
 
-// Chooses the suffix-table depth: deep enough to skip the cache-friendly top of the search,
-// small enough (<= 64 MiB) to stay resident in the 256 MiB Infinity Cache next to the hot
-// blocks, and never deeper than the data warrants (4^depth <= total).
-int auto_table_depth(uint64_t total) {
+// Chooses the suffix-table depth.  Every search step is at least one random 128-byte line
+// and the memory system serves a fixed number of such lines per second whether they come
+// from HBM or the Infinity Cache (tools/ubench_gather.hip: ~41-50 G lines/s), so each table
+// level removes one or two line fetches per query for the price of memory only -- which is
+// what a 288 GB part has.  Policy: the deepest table that the data warrants (4^depth <= T)
+// within max(1 GiB, 2 x the block array), at most 15 levels (16 GiB).
+int auto_table_depth(uint64_t total, uint64_t block_bytes) {
+    const uint64_t budget = std::max<uint64_t>(uint64_t(1) << 30, 2 * block_bytes);
     int d = 0;
-    while (d < 11 && (4ull << (2 * d)) <= total) ++d;
+    while (d < 15 && (uint64_t(4) << (2 * d)) <= total && (uint64_t(64) << (2 * d)) <= budget) ++d;
     return d;
 }
 
@@ -133,7 +139,7 @@ int rebuild_table(msbwt_rle *h) {
     if (h->d_table) (void)hipFree(h->d_table);
     h->d_table = nullptr;
     h->table_depth = 0;
-    int depth = h->wanted_table_depth < 0 ? auto_table_depth(h->totals.total) : h->wanted_table_depth;
+    int depth = h->wanted_table_depth < 0 ? auto_table_depth(h->totals.total, h->nblocks * kBlockBytes) : h->wanted_table_depth;
     if (depth <= 0) return MSBWT_OK;
     const size_t bytes = (size_t(1) << (2 * depth)) * 16;
     void *tab = nullptr;
@@ -394,7 +400,7 @@ int msbwt_rle_count_kmer(const msbwt_rle *h, const uint8_t *kmer, size_t k, uint
 }
 
 int msbwt_rle_set_table_depth(msbwt_rle *h, int depth) {
-    if (!h || depth > 13) return MSBWT_ERR_INVALID_ARG;
+    if (!h || depth > kMaxTableDepth) return MSBWT_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
     h->wanted_table_depth = depth;
     if (!h->loaded) return MSBWT_OK;

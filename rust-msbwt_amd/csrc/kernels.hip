@@ -350,7 +350,7 @@ hipError_t launch_constrain_ranges(const IndexView &ix, const uint8_t *syms, con
 }
 
 hipError_t launch_build_table(const IndexView &ix, int depth, void *entries, hipStream_t stream) {
-    if (depth < 1 || depth > 13) return hipErrorInvalidValue;
+    if (depth < 1 || depth > 16) return hipErrorInvalidValue;
     uint4 *table = static_cast<uint4 *>(entries);
     hipLaunchKernelGGL(k_table_root, dim3(1), dim3(64), 0, stream, table, ix.total);
     for (int level = 1; level <= depth; ++level) {

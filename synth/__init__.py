@@ -36,8 +36,9 @@ def lib():
         L.synth_build_msbwt.restype = C.c_int
         L.synth_rle_encode.argtypes = [vp, u64, vp, u64]
         L.synth_rle_encode.restype = u64
-        L.synth_rle_stream.argtypes = [u64, C.c_double, u64, vp, u64, C.POINTER(u64)]
-        L.synth_rle_stream.restype = u64
+        L.synth_rle_stream.argtypes = [u64, C.c_double, u64, C.c_int, C.POINTER(u64), C.POINTER(u64)]
+        L.synth_rle_stream.restype = vp
+        L.synth_free.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -105,16 +106,18 @@ def rle_encode(symbols):
     return out
 
 
-def rle_stream(target_symbols, mean_run, seed):
-    """Structure-equivalent synthetic RLE stream (NOT a real BWT). Returns (bytes, total)."""
-    cap = int(target_symbols / max(mean_run, 1.0) * 1.6) + 1024
-    while True:
-        out = np.empty(cap, dtype=np.uint8)
-        total = C.c_uint64()
-        n = lib().synth_rle_stream(target_symbols, mean_run, seed, _p(out), cap, C.byref(total))
-        if n <= cap:
-            return out[:n].copy(), int(total.value)
-        cap = int(n) + 1024
+def rle_stream(target_symbols, mean_run, seed, chunks=64):
+    """Structure-equivalent synthetic RLE stream (NOT a real BWT). Returns (bytes, total).
+    Deterministic for a given (target, mean_run, seed, chunks)."""
+    nbytes, total = C.c_uint64(), C.c_uint64()
+    ptr = lib().synth_rle_stream(target_symbols, mean_run, seed, chunks, C.byref(nbytes), C.byref(total))
+    if not ptr:
+        raise MemoryError("synth_rle_stream")
+    try:
+        out = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(int(nbytes.value),)).copy()
+    finally:
+        lib().synth_free(ptr)
+    return out, int(total.value)
 
 
 def write_npy(path, rle_bytes):

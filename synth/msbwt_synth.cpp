@@ -271,35 +271,70 @@ uint64_t synth_rle_encode(const uint8_t *symbols, uint64_t n, uint8_t *out, uint
     return w;
 }
 
-// Structure-equivalent synthetic RLE stream (not a real BWT): runs over {A,C,G,T} with a few
-// '$'/'N', lengths geometric with the given mean.  Writes up to cap bytes; returns bytes
-// written and the symbol total.  Used for index sizes that cannot be suffix-sorted here.
-uint64_t synth_rle_stream(uint64_t target_symbols, double mean_run, uint64_t seed, uint8_t *out, uint64_t cap,
-                          uint64_t *out_total) {
-    uint64_t st = seed, total = 0, w = 0;
+// Structure-equivalent synthetic RLE stream (NOT a real BWT): runs over {A,C,G,T} with a few
+// '$'/'N', lengths geometric with the given mean, no two neighbouring runs of one symbol.
+// Generated in independent seeded chunks (so it parallelises and is reproducible for a
+// given chunk count), stitched so that chunk borders never merge two runs.  The returned
+// buffer is malloc'ed; free it with synth_free.  Used for index sizes that cannot be
+// suffix-sorted here.
+static void gen_chunk(uint64_t target, double mean_run, uint64_t seed, std::vector<uint8_t> *enc) {
+    uint64_t st = seed, total = 0;
     uint8_t prev = 255;
     const double p = 1.0 / (mean_run < 1.0 ? 1.0 : mean_run);
-    // geometric via inverse transform on a 53-bit uniform
     const double log1mp = p >= 1.0 ? 0.0 : __builtin_log1p(-p);
-    while (total < target_symbols) {
+    enc->reserve(size_t(double(target) * p * 1.1) + 64);
+    bool first = true;
+    while (total < target) {
         const uint64_t x = splitmix64(st);
+        const double u = double(splitmix64(st) >> 11) * (1.0 / 9007199254740992.0);
+        uint64_t len = p >= 1.0 ? 1 : 1 + uint64_t(__builtin_log(1.0 - u) / log1mp);
+        if (len > target - total) len = target - total;
+        const bool last = (total + len == target);
         uint8_t sym;
         const uint32_t pick = uint32_t(x & 1023u);
         if (pick < 8) sym = 0; else if (pick < 12) sym = 4; else sym = kBase[(x >> 10) & 3u];
-        if (sym == prev) sym = kBase[((x >> 12) & 3u)] == prev ? uint8_t(prev == 1 ? 2 : 1) : kBase[(x >> 12) & 3u];
-        const double u = double(splitmix64(st) >> 11) * (1.0 / 9007199254740992.0);
-        uint64_t len = p >= 1.0 ? 1 : 1 + uint64_t(__builtin_log(1.0 - u) / log1mp);
-        if (len > target_symbols - total) len = target_symbols - total;
-        if (len == 0) len = 1;
-        for (uint64_t l = len; l > 0; l >>= 5) {
-            if (w < cap) out[w] = uint8_t(sym | ((l & 31u) << 3));
-            ++w;
+        // chunk borders can never merge two runs: a chunk starts with G or T and ends with A or C
+        if (first) sym = (x >> 20) & 1u ? 3 : 5;
+        if (last && !(first)) sym = (x >> 21) & 1u ? 1 : 2;
+        if (sym == prev) {
+            if (last) sym = uint8_t(prev == 1 ? 2 : 1);
+            else {
+                sym = kBase[(x >> 12) & 3u];
+                if (sym == prev) sym = uint8_t(prev == 1 ? 2 : 1);
+            }
         }
+        for (uint64_t l = len; l > 0; l >>= 5) enc->push_back(uint8_t(sym | ((l & 31u) << 3)));
         total += len;
         prev = sym;
+        first = false;
     }
-    if (out_total) *out_total = total;
-    return w;
 }
+
+uint8_t *synth_rle_stream(uint64_t target_symbols, double mean_run, uint64_t seed, int chunks,
+                          uint64_t *out_bytes, uint64_t *out_total) {
+    if (chunks < 1) chunks = 1;
+    if (uint64_t(chunks) * 4 > target_symbols) chunks = 1;
+    std::vector<std::vector<uint8_t>> enc(static_cast<size_t>(chunks));
+    parallel_for(pick_threads(0), size_t(chunks), [&](int, size_t b, size_t e) {
+        for (size_t c = b; c < e; ++c) {
+            const uint64_t lo = target_symbols * c / uint64_t(chunks), hi = target_symbols * (c + 1) / uint64_t(chunks);
+            gen_chunk(hi - lo, mean_run, seed + 0x632BE59BD9B4E019ull * (c + 1), &enc[c]);
+        }
+    });
+    uint64_t bytes = 0;
+    std::vector<uint64_t> off(static_cast<size_t>(chunks) + 1, 0);
+    for (size_t c = 0; c < size_t(chunks); ++c) { off[c] = bytes; bytes += enc[c].size(); }
+    uint8_t *out = static_cast<uint8_t *>(std::malloc(bytes ? bytes : 1));
+    if (!out) return nullptr;
+    parallel_for(pick_threads(0), size_t(chunks), [&](int, size_t b, size_t e) {
+        for (size_t c = b; c < e; ++c)
+            if (!enc[c].empty()) std::memcpy(out + off[c], enc[c].data(), enc[c].size());
+    });
+    if (out_bytes) *out_bytes = bytes;
+    if (out_total) *out_total = target_symbols;
+    return out;
+}
+
+void synth_free(void *p) { std::free(p); }
 
 }  // extern "C"

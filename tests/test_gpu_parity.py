@@ -259,7 +259,7 @@ def test_table_rebuilt_on_reload_and_auto_depth():
     o.load_vector(rle)
     b = gpu_bwt(rle)
     d = b.get_table_depth()
-    assert 1 <= d <= 11 and 4 ** d <= o.get_total_size()
+    assert 1 <= d <= 15 and 4 ** d <= o.get_total_size()
     qs = random_kmers(1, 3000, 12)
     assert np.array_equal(b.count_kmers(qs), o.count_kmers(qs))
     b.load_vector(msbwt.bwt_converter.convert_to_vec("TG$$CAGCCG"))   # tiny: table depth shrinks
