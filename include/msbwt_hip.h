@@ -57,7 +57,9 @@ msbwt_rle *msbwt_rle_new_on_device(uint8_t bin_power, int device);
 void msbwt_rle_free(msbwt_rle *bwt);
 
 /* BWT::load_vector (src/msbwt_core.rs:43, src/rle_bwt.rs:59-66).  Copies: the caller keeps
- * (or drops) its Vec<u8>. */
+ * (or drops) its Vec<u8>.  The bytes are uploaded and expanded into the query layout on the
+ * device (what calculate_totals + construct_fmindex, src/rle_bwt.rs:352-467, do on the CPU);
+ * MSBWT_BUILD=host in the environment selects the host-side builder instead. */
 int msbwt_rle_load_vector(msbwt_rle *bwt, const uint8_t *rle_bytes, size_t len);
 /* BWT::load_numpy_file (src/msbwt_core.rs:58, src/rle_bwt.rs:81-155). */
 int msbwt_rle_load_numpy_file(msbwt_rle *bwt, const char *utf8_path);
@@ -110,6 +112,10 @@ const char *msbwt_rle_last_error(const msbwt_rle *bwt);
  * them to out_blocks (may be NULL), the symbol total to *out_total. SIZE_MAX on bad input. */
 size_t msbwt_build_plane_blocks(const uint8_t *rle_bytes, size_t len, void *out_blocks, size_t cap_blocks,
                                 uint64_t *out_total);
+/* Copies the index as it sits in HBM back to the host (same layout as
+ * msbwt_build_plane_blocks); returns the block count, SIZE_MAX on error.  Lets tests compare
+ * the device-side builder with the host one. */
+size_t msbwt_rle_download_blocks(const msbwt_rle *bwt, void *out_blocks, size_t cap_blocks);
 const char *msbwt_version(void);
 
 /* ---- codecs either side of the path ---- */

@@ -39,6 +39,7 @@ SIGNATURES = {
     "msbwt_rle_last_error": (C.c_char_p, [_vp]),
     "msbwt_version": (C.c_char_p, []),
     "msbwt_build_plane_blocks": (_sz, [_vp, _sz, _vp, _sz, _pu64]),
+    "msbwt_rle_download_blocks": (_sz, [_vp, _vp, _sz]),
     "msbwt_convert_to_vec": (_sz, [_vp, _sz, _vp, _sz]),
     "msbwt_save_bwt_numpy": (_int, [_vp, _sz, C.c_char_p]),
     "msbwt_save_bwt_runs_numpy": (_int, [_vp, _vp, _sz, C.c_char_p]),

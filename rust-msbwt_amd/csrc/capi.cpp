@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/msbwt_hip.h"
+#include "device_build.hpp"
 #include "kernels.hpp"
 #include "npy_io.hpp"
 #include "plane_index.hpp"
@@ -157,16 +158,12 @@ int rebuild_table(msbwt_rle *h) {
     return MSBWT_OK;
 }
 
-// Common tail of both load entry points: totals, plane blocks, upload, table.
-int install(msbwt_rle *h, const uint8_t *rle, size_t n) {
-    DeviceScope scope(h->device);
-    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
-    release_index(h);
+// Index build on the host (kept for MSBWT_BUILD=host and for cross-checking the device
+// builder): expand into pinned memory, upload.
+int build_on_host(msbwt_rle *h, const uint8_t *rle, size_t n, Totals *t_out) {
     Totals t;
     if (!compute_totals(rle, n, &t)) return fail(h, MSBWT_ERR_INVALID_SYMBOL, "RLE stream holds a symbol code >= 6");
     if (t.total > kMaxTotal) return fail(h, MSBWT_ERR_TOO_LARGE, "BWT has 2^40 symbols or more");
-    int rc = ensure_runtime(h);
-    if (rc) return rc;
     const uint64_t nblocks = plane_block_count(t.total);
     const size_t bytes = size_t(nblocks) * kBlockBytes;
     uint32_t *host = nullptr;
@@ -181,12 +178,72 @@ int install(msbwt_rle *h, const uint8_t *rle, size_t n) {
     if (e == hipSuccess) e = hipMemcpy(h->d_blocks, host, bytes, hipMemcpyHostToDevice);
     if (pinned) (void)hipHostFree(host);
     else std::free(host);
-    if (e != hipSuccess) {
+    if (e != hipSuccess) return hip_fail(h, e, "upload index");
+    *t_out = t;
+    return MSBWT_OK;
+}
+
+// Index build on the device (default): upload the RLE bytes, expand them in HBM
+// (device_build.hip).  The expanded index (0.5 B/symbol) never exists on the host.
+int build_on_device(msbwt_rle *h, const uint8_t *rle, size_t n, Totals *t_out) {
+    struct Temps {
+        void *rle = nullptr, *scratch = nullptr, *longs = nullptr;
+        ~Temps() {
+            if (rle) (void)hipFree(rle);
+            if (scratch) (void)hipFree(scratch);
+            if (longs) (void)hipFree(longs);
+        }
+    } tmp;
+    HIP_TRY(h, hipMalloc(&tmp.rle, n + 32));
+    if (n) HIP_TRY(h, hipMemcpyAsync(tmp.rle, rle, n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMalloc(&tmp.scratch, device_build_scratch_bytes(n)));
+    DeviceBuildState st;
+    HIP_TRY(h, device_build_pass1(static_cast<const uint8_t *>(tmp.rle), n, tmp.scratch, &st, h->stream));
+    uint64_t head[32];  // totals[7], start_index[6], flags, long_count, ...
+    HIP_TRY(h, hipMemcpyAsync(head, tmp.scratch, sizeof head, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const uint32_t flags = *reinterpret_cast<const uint32_t *>(&head[13]);
+    const uint64_t nlong = head[15];
+    if (flags & kBuildBadSymbol) return fail(h, MSBWT_ERR_INVALID_SYMBOL, "RLE stream holds a symbol code >= 6");
+    Totals t{};
+    uint64_t acc = 0;
+    for (int s = 0; s < kAlphabet; ++s) {
+        t.symbol_counts[s] = head[s];
+        t.start_index[s] = acc;
+        acc += head[s];
+        t.end_index[s] = acc;
+    }
+    t.total = acc;
+    if ((flags & kBuildTooLarge) || t.total > kMaxTotal || acc != head[6])
+        return fail(h, MSBWT_ERR_TOO_LARGE, "BWT has 2^40 symbols or more");
+    const uint64_t nblocks = plane_block_count(t.total);
+    const size_t bytes = size_t(nblocks) * kBlockBytes;
+    HIP_TRY(h, hipMalloc(&h->d_blocks, bytes));
+    HIP_TRY(h, hipMemsetAsync(h->d_blocks, 0, bytes, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(st.d_start_index, t.start_index, sizeof t.start_index, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMalloc(&tmp.longs, device_build_long_run_bytes(nlong)));
+    HIP_TRY(h, device_build_pass2(static_cast<const uint8_t *>(tmp.rle), n, st, tmp.longs, nlong, h->d_blocks, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *t_out = t;
+    return MSBWT_OK;
+}
+
+// Common tail of both load entry points: build the plane blocks in HBM, then the table.
+int install(msbwt_rle *h, const uint8_t *rle, size_t n) {
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    release_index(h);
+    int rc = ensure_runtime(h);
+    if (rc) return rc;
+    Totals t{};
+    const char *mode = std::getenv("MSBWT_BUILD");
+    rc = (mode && std::strcmp(mode, "host") == 0) ? build_on_host(h, rle, n, &t) : build_on_device(h, rle, n, &t);
+    if (rc) {
         release_index(h);
-        return hip_fail(h, e, "upload index");
+        return rc;
     }
     h->totals = t;
-    h->nblocks = nblocks;
+    h->nblocks = plane_block_count(t.total);
     h->loaded = true;
     rc = rebuild_table(h);
     if (rc) {
@@ -449,6 +506,18 @@ int msbwt_rle_kernel_time_ms(const msbwt_rle *ch, double *avg_ms, uint64_t *laun
 int msbwt_rle_device_ordinal(const msbwt_rle *h) { return h ? h->device : -1; }
 
 const char *msbwt_rle_last_error(const msbwt_rle *h) { return h ? h->err.c_str() : "null handle"; }
+
+size_t msbwt_rle_download_blocks(const msbwt_rle *ch, void *out_blocks, size_t cap_blocks) {
+    msbwt_rle *h = const_cast<msbwt_rle *>(ch);
+    if (!h || !h->loaded) return SIZE_MAX;
+    std::lock_guard<std::mutex> lock(h->mu);
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return SIZE_MAX;
+    if (out_blocks && cap_blocks >= h->nblocks &&
+        hipMemcpy(out_blocks, h->d_blocks, size_t(h->nblocks) * kBlockBytes, hipMemcpyDeviceToHost) != hipSuccess)
+        return SIZE_MAX;
+    return size_t(h->nblocks);
+}
 
 size_t msbwt_build_plane_blocks(const uint8_t *rle_bytes, size_t len, void *out_blocks, size_t cap_blocks,
                                 uint64_t *out_total) {

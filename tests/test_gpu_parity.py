@@ -289,3 +289,46 @@ def test_device_pointer_api_alignment_and_ragged_tiles():
             got = out.cpu().numpy()
             assert got[0] == -7 and got[-1] == -7          # nothing written outside the batch
             assert np.array_equal(got[1:-1].astype(np.uint64), o.count_kmers(base[:n])), (n, offset)
+
+
+def _download_blocks(b):
+    import ctypes as C
+    L = msbwt._lib.lib()
+    n = L.msbwt_rle_download_blocks(b._h, None, 0)
+    assert n != msbwt._lib.SIZE_MAX
+    out = np.zeros((n, 8, 4), dtype=np.uint32)
+    assert L.msbwt_rle_download_blocks(b._h, out.ctypes.data_as(C.c_void_p), n) == n
+    return out
+
+
+def _host_blocks(rle):
+    import ctypes as C
+    rle = np.ascontiguousarray(rle, dtype=np.uint8)
+    L = msbwt._lib.lib()
+    total = C.c_uint64()
+    n = L.msbwt_build_plane_blocks(rle.ctypes.data_as(C.c_void_p), rle.size, None, 0, C.byref(total))
+    out = np.zeros((n, 8, 4), dtype=np.uint32)
+    L.msbwt_build_plane_blocks(rle.ctypes.data_as(C.c_void_p), rle.size, out.ctypes.data_as(C.c_void_p), n, C.byref(total))
+    return out
+
+
+@pytest.mark.parametrize("case", ["ones", "short", "long", "mixed", "raw", "edges", "big_short"])
+def test_device_built_index_equals_host_built(case):
+    """The device-side builder (scan + atomic paint) against the host builder, word for word."""
+    if case == "raw":
+        streams = [raw_byte_stream(s, 500) for s in range(4)]
+    elif case == "edges":
+        streams = [runs_to_bytes(s, l) for s, l in [([1, 2], [256, 256]), ([0, 1], [1, 255]), ([3], [100000]),
+                                                   ([0], [512]), ([5, 0, 5], [32, 1024, 32768]), ([4, 1], [255, 1]),
+                                                   ([2], [2047]), ([2], [2048]), ([1, 2, 1], [2049, 1, 4096])]]
+        streams.append(np.zeros(0, dtype=np.uint8))
+        streams.append(orc.convert_to_vec("GTN$$ACCC$G"))
+    elif case == "big_short":
+        streams = [random_stream(12, 300000, "short")]          # many 4 KiB tiles: exercises the tile scan
+    else:
+        streams = [random_stream(31, 20000, case)]
+    for rle in streams:
+        b = gpu_bwt(rle)
+        dev, host = _download_blocks(b), _host_blocks(rle)
+        assert dev.shape == host.shape
+        assert np.array_equal(dev, host)
