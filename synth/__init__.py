@@ -5,6 +5,7 @@ under synth/cache/) the inputs of a BASELINE.json config."""
 import ctypes as C
 import os
 import subprocess
+import weakref
 
 import numpy as np
 
@@ -106,17 +107,18 @@ def rle_encode(symbols):
     return out
 
 
-def rle_stream(target_symbols, mean_run, seed, chunks=64):
+def rle_stream(target_symbols, mean_run, seed, chunks=0):
     """Structure-equivalent synthetic RLE stream (NOT a real BWT). Returns (bytes, total).
     Deterministic for a given (target, mean_run, seed, chunks)."""
+    if chunks <= 0:  # ~64 Mi symbols per chunk, at least 64 chunks (fixed rule => reproducible)
+        chunks = max(64, int(target_symbols) >> 26)
     nbytes, total = C.c_uint64(), C.c_uint64()
     ptr = lib().synth_rle_stream(target_symbols, mean_run, seed, chunks, C.byref(nbytes), C.byref(total))
     if not ptr:
         raise MemoryError("synth_rle_stream")
-    try:
-        out = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(int(nbytes.value),)).copy()
-    finally:
-        lib().synth_free(ptr)
+    # wrap the malloc'ed buffer without copying it (it is 15 GB at human scale)
+    out = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(max(int(nbytes.value), 1),))[:int(nbytes.value)]
+    weakref.finalize(out, lib().synth_free, ptr)
     return out, int(total.value)
 
 

@@ -277,17 +277,39 @@ uint64_t synth_rle_encode(const uint8_t *symbols, uint64_t n, uint8_t *out, uint
 // given chunk count), stitched so that chunk borders never merge two runs.  The returned
 // buffer is malloc'ed; free it with synth_free.  Used for index sizes that cannot be
 // suffix-sorted here.
-static void gen_chunk(uint64_t target, double mean_run, uint64_t seed, std::vector<uint8_t> *enc) {
+// Run lengths: geometric with the given mean, sampled through a 64 Ki-entry inverse-CDF
+// table (one lookup per run instead of a log()); lengths are capped at 255.
+struct GeomTable {
+    std::vector<uint8_t> len;
+    explicit GeomTable(double mean_run) : len(65536) {
+        const double p = 1.0 / (mean_run < 1.0 ? 1.0 : mean_run);
+        double cdf = 0.0, pk = p;  // P(len = k) = p (1-p)^(k-1)
+        uint32_t k = 1, filled = 0;
+        while (filled < 65536) {
+            cdf += pk;
+            const uint32_t upto = (k >= 255) ? 65536u : uint32_t(std::min(65536.0, cdf * 65536.0 + 0.5));
+            for (; filled < upto; ++filled) len[filled] = uint8_t(k);
+            pk *= (1.0 - p);
+            ++k;
+        }
+    }
+};
+
+static void gen_chunk(uint64_t target, const GeomTable &geom, double mean_run, uint64_t seed, std::vector<uint8_t> *enc) {
     uint64_t st = seed, total = 0;
     uint8_t prev = 255;
-    const double p = 1.0 / (mean_run < 1.0 ? 1.0 : mean_run);
-    const double log1mp = p >= 1.0 ? 0.0 : __builtin_log1p(-p);
-    enc->reserve(size_t(double(target) * p * 1.1) + 64);
+    enc->resize(size_t(double(target) / (mean_run < 1.0 ? 1.0 : mean_run) * 1.3) + 4096);
+    uint8_t *out = enc->data();
+    size_t w = 0, cap = enc->size();
     bool first = true;
     while (total < target) {
+        if (w + 4 > cap) {  // rare: the estimate was short
+            enc->resize(cap + cap / 4 + 4096);
+            out = enc->data();
+            cap = enc->size();
+        }
         const uint64_t x = splitmix64(st);
-        const double u = double(splitmix64(st) >> 11) * (1.0 / 9007199254740992.0);
-        uint64_t len = p >= 1.0 ? 1 : 1 + uint64_t(__builtin_log(1.0 - u) / log1mp);
+        uint64_t len = geom.len[(x >> 32) & 0xFFFFu];
         if (len > target - total) len = target - total;
         const bool last = (total + len == target);
         uint8_t sym;
@@ -295,7 +317,7 @@ static void gen_chunk(uint64_t target, double mean_run, uint64_t seed, std::vect
         if (pick < 8) sym = 0; else if (pick < 12) sym = 4; else sym = kBase[(x >> 10) & 3u];
         // chunk borders can never merge two runs: a chunk starts with G or T and ends with A or C
         if (first) sym = (x >> 20) & 1u ? 3 : 5;
-        if (last && !(first)) sym = (x >> 21) & 1u ? 1 : 2;
+        if (last && !first) sym = (x >> 21) & 1u ? 1 : 2;
         if (sym == prev) {
             if (last) sym = uint8_t(prev == 1 ? 2 : 1);
             else {
@@ -303,11 +325,12 @@ static void gen_chunk(uint64_t target, double mean_run, uint64_t seed, std::vect
                 if (sym == prev) sym = uint8_t(prev == 1 ? 2 : 1);
             }
         }
-        for (uint64_t l = len; l > 0; l >>= 5) enc->push_back(uint8_t(sym | ((l & 31u) << 3)));
+        for (uint64_t l = len; l > 0; l >>= 5) out[w++] = uint8_t(sym | ((l & 31u) << 3));
         total += len;
         prev = sym;
         first = false;
     }
+    enc->resize(w);
 }
 
 uint8_t *synth_rle_stream(uint64_t target_symbols, double mean_run, uint64_t seed, int chunks,
@@ -315,12 +338,23 @@ uint8_t *synth_rle_stream(uint64_t target_symbols, double mean_run, uint64_t see
     if (chunks < 1) chunks = 1;
     if (uint64_t(chunks) * 4 > target_symbols) chunks = 1;
     std::vector<std::vector<uint8_t>> enc(static_cast<size_t>(chunks));
-    parallel_for(pick_threads(0), size_t(chunks), [&](int, size_t b, size_t e) {
-        for (size_t c = b; c < e; ++c) {
-            const uint64_t lo = target_symbols * c / uint64_t(chunks), hi = target_symbols * (c + 1) / uint64_t(chunks);
-            gen_chunk(hi - lo, mean_run, seed + 0x632BE59BD9B4E019ull * (c + 1), &enc[c]);
-        }
-    });
+    const GeomTable geom(mean_run);
+    {   // dynamic schedule: chunk sizes are equal but first-touch page faults are not
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> pool;
+        for (int t = 0; t < pick_threads(0); ++t)
+            pool.emplace_back([&] {
+                for (;;) {
+                    const size_t c = next.fetch_add(1);
+                    if (c >= size_t(chunks)) break;
+                    // 128-bit product: target_symbols * c overflows 64 bits at human scale
+                    const uint64_t lo = uint64_t((unsigned __int128)target_symbols * c / uint64_t(chunks));
+                    const uint64_t hi = uint64_t((unsigned __int128)target_symbols * (c + 1) / uint64_t(chunks));
+                    gen_chunk(hi - lo, geom, mean_run, seed + 0x632BE59BD9B4E019ull * (c + 1), &enc[c]);
+                }
+            });
+        for (auto &th : pool) th.join();
+    }
     uint64_t bytes = 0;
     std::vector<uint64_t> off(static_cast<size_t>(chunks) + 1, 0);
     for (size_t c = 0; c < size_t(chunks); ++c) { off[c] = bytes; bytes += enc[c].size(); }
