@@ -101,6 +101,7 @@ def main():
         log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -244,10 +245,19 @@ def main():
         alg_bytes = st.algorithmic_bytes(k) * (nq / nst)  # exact when nst == nq, else scaled from the sample
         kern_s = kernel_ms / 1e3 if launches else elapsed / args.steps
         achieved = alg_bytes / kern_s / 1e9
+        traffic, traffic_src = None, None
+        try:  # PMC counters are collected in separate rocprofv3 passes; their summary is committed
+            for ent in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["entries"]:
+                if ent["workload"] == args.workload and ent["k"] == k and ent["table_depth"] == bwt.get_table_depth() \
+                        and kind == cfg["queries"] and args.scale == 1.0:
+                    traffic = ent["traffic_bytes_per_query"] * nq
+                    traffic_src = ent["source"]
+        except (OSError, KeyError, ValueError):
+            pass
         result["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "kernel": "k_count_kmers", "kernel_ms": kernel_ms, "kernel_launches": launches,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": "k_count_kmers_tiled" if 1 <= k <= 32 else "k_count_kmers_generic", "kernel_ms": kernel_ms, "kernel_launches": launches,
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "algorithmic_bytes_per_query": alg_bytes / nq,
             "mean_steps_per_query": st.steps / nst, "mean_bin_visits_per_query": st.visits / nst,
