@@ -30,6 +30,8 @@ SIGNATURES = {
     "msbwt_rle_count_kmers_device": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "msbwt_rle_constrain_ranges_device": (_int, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "msbwt_rle_device_status": (_int, [_vp, _vp]),
+    "msbwt_rle_count_read_kmers": (_int, [_vp, _vp, _sz, _sz, _sz, _int, _vp, _vp]),
+    "msbwt_rle_count_read_kmers_device": (_int, [_vp, _vp, _sz, _sz, _sz, _int, _vp, _vp, _vp]),
     "msbwt_rle_set_table_depth": (_int, [_vp, _int]),
     "msbwt_rle_get_table_depth": (_int, [_vp]),
     "msbwt_rle_device_bytes": (_u64, [_vp]),

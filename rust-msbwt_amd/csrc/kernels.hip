@@ -121,11 +121,41 @@ struct WaveScratch {
     uint64_t result[kTile];                // 512 B
 };
 
+// Where a tile's queries come from and where their counts go.
+//   matrix mode: `data` = n x k symbol codes (the batch API); counts to out_fwd[q].
+//   reads mode:  `data` = n_reads x read_len bytes; query = one k-mer window of one read, on
+//                the forward strand and/or reverse-complemented (string_util.rs:12,45-50);
+//                bytes are symbol codes or ASCII (string_util.rs:15-32 mapping).  Query
+//                preparation -- convert_stoi, windowing, reverse_complement_i -- happens here,
+//                in registers, instead of on the host.
+struct QuerySource {
+    const uint8_t *data;
+    uint64_t n;          // queries (reads mode: windows x strands)
+    uint32_t k;
+    uint32_t read_len;   // reads mode
+    uint32_t windows;    // read_len - k + 1
+    uint32_t strands;    // bit 0: forward wanted, bit 1: reverse complement wanted
+    uint32_t ascii;
+    uint64_t *out_fwd, *out_rc;
+};
+
+__device__ __forceinline__ uint32_t ascii_to_code(uint32_t c) {
+    if (c == 0x24u) return 0u;  // '$'
+    c &= 0xDFu;                 // fold lower case
+    return c == 0x41u ? 1u : c == 0x43u ? 2u : c == 0x47u ? 3u : c == 0x54u ? 5u : 4u;
+}
+__device__ __forceinline__ uint32_t complement_code(uint32_t s) {  // $ACGNT -> $TGCNA; 6,7 stay invalid
+    return s == 1u ? 5u : s == 5u ? 1u : s == 2u ? 3u : s == 3u ? 2u : s;
+}
+
+template <bool kReads>
 __global__ __launch_bounds__(256) void k_count_kmers_tiled(const uint4 *__restrict__ blocks, uint64_t total,
                                                            const uint4 *__restrict__ table, uint32_t depth,
-                                                           const uint8_t *__restrict__ kmers, uint32_t k, uint64_t n,
-                                                           uint64_t *__restrict__ counts, uint32_t *__restrict__ flags) {
+                                                           const QuerySource src, uint32_t *__restrict__ flags) {
     __shared__ WaveScratch scratch[kWavesPerBlock];
+    const uint8_t *__restrict__ kmers = src.data;
+    const uint32_t k = src.k;
+    const uint64_t n = src.n;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t sub = lane & (kGroup - 1);
     const uint32_t group_first_lane = lane & ~uint32_t(kGroup - 1);
@@ -141,7 +171,7 @@ __global__ __launch_bounds__(256) void k_count_kmers_tiled(const uint4 *__restri
         const uint64_t q0 = tile * kTile;
         const uint32_t in_tile = uint32_t(min(uint64_t(kTile), n - q0));
         // ---- phase 1a: stage the tile's bytes (contiguous, 16-byte aligned) through LDS ----
-        {
+        if (!kReads) {
             const uint8_t *src = kmers + q0 * k;
             const uint32_t nbytes = in_tile * k;
             for (uint32_t piece = lane; piece * 16u < nbytes; piece += 64u) {
@@ -165,8 +195,25 @@ __global__ __launch_bounds__(256) void k_count_kmers_tiled(const uint4 *__restri
             uint64_t lo = 0, hi = 0;  // symbol of step t (t = 0 first) at bits [3t, 3t+3) of hi:lo
             uint32_t bad = 0, acgt = 1, tidx = 0;
             const uint8_t *mine = stage_bytes + lane * k;
+            bool rc = false;
+            if (kReads) {  // window g of read r, forward or reverse-complemented
+                const uint64_t v = q0 + lane;
+                const uint64_t g = src.strands == 3u ? (v >> 1) : v;
+                rc = src.strands == 3u ? (v & 1u) != 0 : src.strands == 2u;
+                mine = kmers + (g / src.windows) * src.read_len + (g % src.windows);
+            }
+#pragma unroll 4
             for (uint32_t t = 0; t < k; ++t) {
-                const uint32_t s = mine[k - 1u - t];
+                uint32_t s;
+                if (!kReads) {
+                    s = mine[k - 1u - t];
+                } else {
+                    // the search consumes a k-mer from its last symbol: forward window -> byte k-1-t;
+                    // reverse complement q'[j] = comp(window[k-1-j]) -> step t reads comp(window[t])
+                    s = rc ? mine[t] : mine[k - 1u - t];
+                    if (src.ascii) s = ascii_to_code(s);
+                    if (rc) s = complement_code(s);
+                }
                 bad |= (s >= 6u) ? 1u : 0u;
                 const uint32_t pos = 3u * t;
                 if (pos < 64u) {
@@ -255,7 +302,15 @@ __global__ __launch_bounds__(256) void k_count_kmers_tiled(const uint4 *__restri
             }
         }
         wave_lds_sync();
-        if (lane < in_tile) counts[q0 + lane] = ws.result[lane];
+        if (lane < in_tile) {
+            if (!kReads) {
+                src.out_fwd[q0 + lane] = ws.result[lane];
+            } else {
+                const uint64_t v = q0 + lane;
+                if (src.strands == 3u) ((v & 1u) ? src.out_rc : src.out_fwd)[v >> 1] = ws.result[lane];
+                else (src.strands == 2u ? src.out_rc : src.out_fwd)[v] = ws.result[lane];
+            }
+        }
         wave_lds_sync();  // the next tile must not overwrite result[] / stage[] before this
     }
 }
@@ -330,13 +385,39 @@ hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_
     const bool aligned = (reinterpret_cast<uintptr_t>(kmers) & 15u) == 0;
     if (k >= 1 && k <= uint32_t(kMaxShortK) && aligned) {
         const uint64_t tiles = (n + kTile - 1) / kTile;
-        hipLaunchKernelGGL(k_count_kmers_tiled, dim3(grid_for(tiles * 64)), dim3(256), 0, stream, blocks, ix.total,
-                           static_cast<const uint4 *>(ix.table.entries), uint32_t(ix.table.depth), kmers, k, n,
-                           counts, flags);
+        QuerySource src{};
+        src.data = kmers;
+        src.n = n;
+        src.k = k;
+        src.out_fwd = counts;
+        hipLaunchKernelGGL(k_count_kmers_tiled<false>, dim3(grid_for(tiles * 64)), dim3(256), 0, stream, blocks,
+                           ix.total, static_cast<const uint4 *>(ix.table.entries), uint32_t(ix.table.depth), src, flags);
     } else {
         hipLaunchKernelGGL(k_count_kmers_generic, dim3(grid_for(n * kGroup)), dim3(256), 0, stream, blocks,
                            ix.total, kmers, k, n, counts, flags);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_count_read_kmers(const IndexView &ix, const uint8_t *reads, uint32_t read_len, uint64_t n_reads,
+                                   uint32_t k, bool ascii, uint64_t *out_fwd, uint64_t *out_rc, uint32_t *flags,
+                                   hipStream_t stream) {
+    if (k < 1 || k > uint32_t(kMaxShortK) || k > read_len || (!out_fwd && !out_rc)) return hipErrorInvalidValue;
+    if (n_reads == 0) return hipSuccess;
+    QuerySource src{};
+    src.data = reads;
+    src.k = k;
+    src.read_len = read_len;
+    src.windows = read_len - k + 1;
+    src.strands = (out_fwd ? 1u : 0u) | (out_rc ? 2u : 0u);
+    src.ascii = ascii ? 1u : 0u;
+    src.out_fwd = out_fwd;
+    src.out_rc = out_rc;
+    src.n = n_reads * src.windows * (src.strands == 3u ? 2u : 1u);
+    const uint64_t tiles = (src.n + kTile - 1) / kTile;
+    hipLaunchKernelGGL(k_count_kmers_tiled<true>, dim3(grid_for(tiles * 64)), dim3(256), 0, stream,
+                       static_cast<const uint4 *>(ix.blocks), ix.total, static_cast<const uint4 *>(ix.table.entries),
+                       uint32_t(ix.table.depth), src, flags);
     return hipGetLastError();
 }
 

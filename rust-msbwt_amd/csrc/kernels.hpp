@@ -28,6 +28,12 @@ struct IndexView {
 hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_t k, uint64_t n,
                               uint64_t *counts, uint32_t *flags, hipStream_t stream);
 
+// Every k-mer window of every read (n_reads x read_len bytes, symbol codes or ASCII), forward
+// and/or reverse-complemented; out_*[r * (read_len-k+1) + w].  1 <= k <= 32, k <= read_len.
+hipError_t launch_count_read_kmers(const IndexView &ix, const uint8_t *reads, uint32_t read_len, uint64_t n_reads,
+                                   uint32_t k, bool ascii, uint64_t *out_fwd, uint64_t *out_rc, uint32_t *flags,
+                                   hipStream_t stream);
+
 // (out_l[i], out_h[i]) = constrain_range(syms[i], [l[i], h[i])).
 hipError_t launch_constrain_ranges(const IndexView &ix, const uint8_t *syms, const uint64_t *l,
                                    const uint64_t *h, uint64_t n, uint64_t *out_l, uint64_t *out_h,

@@ -114,6 +114,37 @@ class RleBWT(BWT):
             _raise(rc, self._h)
         return ol, oh
 
+    def count_read_kmers(self, reads, k, ascii=None, forward=True, revcomp=False):
+        """Counts every k-mer window of every read, fused on the GPU (no n x k query matrix).
+
+        reads: (n_reads, read_len) uint8 -- symbol codes, or ASCII bytes (`ascii=True`; a list of
+        equal-length str/bytes is accepted and implies ASCII).  Returns (fwd, rc): uint64 arrays
+        of shape (n_reads, read_len - k + 1), `None` for a strand that was not requested.
+        rc[r, w] = count_kmer(reverse_complement_i(window))."""
+        if not isinstance(reads, np.ndarray):
+            reads = np.array([np.frombuffer(r.encode() if isinstance(r, str) else bytes(r), dtype=np.uint8) for r in reads])
+            ascii = True if ascii is None else ascii
+        a = np.ascontiguousarray(reads, dtype=np.uint8)
+        if a.ndim != 2:
+            raise ValueError("reads must be (n_reads, read_len)")
+        n, length = a.shape
+        w = length - k + 1
+        fwd = np.empty((n, max(w, 0)), dtype=np.uint64) if forward else None
+        rc = np.empty((n, max(w, 0)), dtype=np.uint64) if revcomp else None
+        code = _lib.lib().msbwt_rle_count_read_kmers(
+            self._h, a.ctypes.data_as(C.c_void_p), length, n, k, 1 if ascii else 0,
+            fwd.ctypes.data_as(C.c_void_p) if fwd is not None else None,
+            rc.ctypes.data_as(C.c_void_p) if rc is not None else None)
+        if code:
+            _raise(code, self._h)
+        return fwd, rc
+
+    def count_read_kmers_device(self, d_reads, read_len, n_reads, k, ascii, d_out_fwd, d_out_rc, stream=0):
+        code = _lib.lib().msbwt_rle_count_read_kmers_device(self._h, d_reads, read_len, n_reads, k,
+                                                            1 if ascii else 0, d_out_fwd, d_out_rc, stream)
+        if code:
+            _raise(code, self._h)
+
     def count_kmers_device(self, d_kmers, k, n, d_out, stream=0):
         """Device pointers (ints); asynchronous on `stream` (a hipStream_t as int)."""
         rc = _lib.lib().msbwt_rle_count_kmers_device(self._h, d_kmers, k, n, d_out, stream)

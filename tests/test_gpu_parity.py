@@ -332,3 +332,50 @@ def test_device_built_index_equals_host_built(case):
         dev, host = _download_blocks(b), _host_blocks(rle)
         assert dev.shape == host.shape
         assert np.array_equal(dev, host)
+
+
+@pytest.mark.parametrize("k", [1, 5, 21, 31, 32])
+def test_fused_read_kmers_match_host_side_preparation(k):
+    """count_read_kmers == convert_stoi -> windows -> (reverse_complement_i) -> count_kmer done
+    on the host with the reference's string_util semantics (src/string_util.rs)."""
+    reads, rle = _real_bwt(11, 90, 48)
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    rng = np.random.default_rng(k)
+    texts = [r for r in reads if len(r) == 48][:60]
+    # sprinkle lower case, N, and bytes outside the alphabet (all map to N), and a '$'
+    noisy = []
+    for t in texts:
+        t = list(t)
+        for _ in range(3):
+            p = int(rng.integers(0, len(t)))
+            t[p] = rng.choice(["a", "c", "g", "t", "n", "N", "x", "-", "$", "\x04"])
+        noisy.append("".join(t))
+    texts = texts[:30] + noisy[30:]
+    fwd, rc = b.count_read_kmers(texts, k, revcomp=True)
+    w = 48 - k + 1
+    assert fwd.shape == rc.shape == (len(texts), w)
+    for r, t in enumerate(texts):
+        codes = orc.convert_stoi(t.encode("latin1"))
+        wins = np.array([codes[i:i + k] for i in range(w)], dtype=np.uint8)
+        rcs = np.array([orc.reverse_complement_i(x) for x in wins], dtype=np.uint8)
+        assert np.array_equal(fwd[r], o.count_kmers(wins)), (k, r)
+        assert np.array_equal(rc[r], o.count_kmers(rcs)), (k, r)
+    assert fwd[:30].min() >= 1                     # clean reads: every window is present
+    # symbol-code input, single strand
+    codes = np.array([orc.convert_stoi(t.encode("latin1")) for t in texts], dtype=np.uint8)
+    f2, none = b.count_read_kmers(codes, k, ascii=False)
+    assert none is None and np.array_equal(f2, fwd)
+    none, r2 = b.count_read_kmers(codes, k, ascii=False, forward=False, revcomp=True)
+    assert none is None and np.array_equal(r2, rc)
+    with pytest.raises(msbwt.MsbwtError):
+        b.count_read_kmers(codes, 49, ascii=False)
+
+
+def test_fused_read_kmers_invalid_codes_are_flagged():
+    b = gpu_bwt(msbwt.bwt_converter.convert_to_vec("GTN$$ACCC$G"))
+    bad = np.array([[1, 2, 7, 1]], dtype=np.uint8)
+    with pytest.raises(msbwt.MsbwtError) as e:
+        b.count_read_kmers(bad, 2, ascii=False)
+    assert e.value.code == msbwt._lib.ERR_INVALID_SYMBOL
