@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--query-kind", default="", choices=["", "random", "reads"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the index (tests)")
     ap.add_argument("--table-depth", type=int, default=-2, help="-2 = library default")
+    ap.add_argument("--fused", action="store_true",
+                    help="c2/c3: queries = every k-mer window of every read, prepared in-kernel from the reads "
+                         "(msbwt_rle_count_read_kmers_device); BASELINE.json configs[2] is --workload c3 --fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-sample", type=int, default=200_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
@@ -146,7 +149,18 @@ def main():
     log("rank %d: %d symbols on the GPU (%.1f MB index, table depth %d) in %.1fs"
         % (rank, total, bwt.device_bytes() / 1e6, bwt.get_table_depth(), time.time() - t0))
 
-    if big and kind == "walk":
+    fused = args.fused and not big
+    if fused:
+        kind = "reads"
+        nread, rlen = reads.shape
+        wins = rlen - k + 1
+        nq = nread * wins
+        d_reads = torch.from_numpy(reads).to(dev)
+        # the oracle side needs explicit k-mers only for the sampled checks
+        rng = np.random.default_rng(5 + rank)
+        sample_ids = np.sort(rng.choice(nq, size=min(nq, max(args.parity_sample, args.stats_sample or 2_000_000, args.cpu_sample)), replace=False))
+        queries = np.ascontiguousarray(reads[(sample_ids // wins)[:, None], (sample_ids % wins)[:, None] + np.arange(k)[None, :]])
+    elif big and kind == "walk":
         t0 = time.time()
         queries = walk_kmers(torch, bwt, dev, total, nq, k, 4242 + rank)
         log("rank %d: %d present %d-mers by LF-walk on the GPU in %.1fs" % (rank, len(queries), k, time.time() - t0))
@@ -154,14 +168,18 @@ def main():
         queries = synth.random_kmers(nq, k, 4242 + 1000 * rank)
     else:
         queries = make_queries(synth, cfg, reads, nq, k, cfg["qseed"] + 1000 * rank, kind)
-    nq = len(queries)
-    d_q = torch.from_numpy(queries).to(dev)
+    if not fused:
+        nq = len(queries)
+        d_q = torch.from_numpy(queries).to(dev)
     d_out = torch.empty(nq, dtype=torch.int64, device=dev)
     d_all = torch.empty(nq * world, dtype=torch.int64, device=dev) if world > 1 else None
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step():
-        bwt.count_kmers_device(d_q.data_ptr(), k, nq, d_out.data_ptr(), stream)
+        if fused:
+            bwt.count_read_kmers_device(d_reads.data_ptr(), rlen, nread, k, False, d_out.data_ptr(), 0, stream)
+        else:
+            bwt.count_kmers_device(d_q.data_ptr(), k, nq, d_out.data_ptr(), stream)
         if world > 1:
             dist.all_gather_into_tensor(d_all, d_out)  # the path's one exchange step (RCCL)
 
@@ -211,7 +229,7 @@ def main():
                         "%d %s %d-mers per GPU per step" % (
                             args.workload, len(reads), reads.shape[1], len(reads) * reads.shape[1] / max(1, int(cfg["genome"] * args.scale)),
                             int(cfg["genome"] * args.scale), cfg["err"] * 100, total, nq,
-                            "random" if kind == "random" else "read-derived", k),
+                            "random" if kind == "random" else "read-derived (ALL windows of ALL reads, prepared in-kernel)" if fused else "read-derived", k),
             "k": k, "queries_per_gpu": nq, "bwt_symbols": total, "index_bytes": bwt.device_bytes(),
             "table_depth": bwt.get_table_depth(),
             "parallelism": "query-sharded x%d, index replicated, RCCL all_gather of counts" % world if world > 1 else "1 GPU",
@@ -227,6 +245,9 @@ def main():
         else:
             ref.load_numpy_file(npy)
         got = d_out.cpu().numpy().astype(np.uint64)
+        if fused:  # `queries` holds only the sampled windows; sample_ids are their positions in the output
+            got = got[sample_ids]
+            nq_all, nq = nq, len(queries)
         ns = min(nq, args.parity_sample)
         sel = np.linspace(0, nq - 1, ns).astype(np.int64)
         exp = ref.count_kmers(queries[sel], nthreads=os.cpu_count() or 1)
@@ -242,6 +263,8 @@ def main():
         t0 = time.time()
         ref.count_kmers(queries[:nst], nthreads=ncpu, stats=st)
         t_all = time.time() - t0
+        if fused:
+            nq = nq_all
         alg_bytes = st.algorithmic_bytes(k) * (nq / nst)  # exact when nst == nq, else scaled from the sample
         kern_s = kernel_ms / 1e3 if launches else elapsed / args.steps
         achieved = alg_bytes / kern_s / 1e9
@@ -249,7 +272,7 @@ def main():
         try:  # PMC counters are collected in separate rocprofv3 passes; their summary is committed
             for ent in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["entries"]:
                 if ent["workload"] == args.workload and ent["k"] == k and ent["table_depth"] == bwt.get_table_depth() \
-                        and kind == cfg["queries"] and args.scale == 1.0:
+                        and kind == cfg["queries"] and args.scale == 1.0 and not fused:
                     traffic = ent["traffic_bytes_per_query"] * nq
                     traffic_src = ent["source"]
         except (OSError, KeyError, ValueError):
@@ -257,7 +280,7 @@ def main():
         result["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "k_count_kmers_tiled" if 1 <= k <= 32 else "k_count_kmers_generic", "kernel_ms": kernel_ms, "kernel_launches": launches,
+            "kernel": "k_count_kmers_tiled<reads>" if fused else "k_count_kmers_tiled" if 1 <= k <= 32 else "k_count_kmers_generic", "kernel_ms": kernel_ms, "kernel_launches": launches,
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "algorithmic_bytes_per_query": alg_bytes / nq,
             "mean_steps_per_query": st.steps / nst, "mean_bin_visits_per_query": st.visits / nst,

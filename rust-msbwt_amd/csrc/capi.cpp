@@ -267,21 +267,30 @@ int flags_to_code(msbwt_rle *h, uint32_t flags) {
     return MSBWT_OK;
 }
 
-int launch_count(msbwt_rle *h, const uint8_t *d_kmers, size_t k, size_t n, uint64_t *d_out, hipStream_t stream) {
-    if (k > 0xFFFFFFFFull) return fail(h, MSBWT_ERR_INVALID_ARG, "k does not fit 32 bits");
+// Runs `launch` (which enqueues the count kernel on `stream`); when kernel timing is on, brackets
+// it with HIP events on that same stream (read back by msbwt_rle_kernel_time_ms).
+template <class Launch>
+int timed_launch(msbwt_rle *h, hipStream_t stream, Launch &&launch) {
     hipEvent_t start = nullptr, stop = nullptr;
     if (h->timing) {
         HIP_TRY(h, hipEventCreate(&start));
         HIP_TRY(h, hipEventCreate(&stop));
         HIP_TRY(h, hipEventRecord(start, stream));
     }
-    HIP_TRY(h, launch_count_kmers(view_of(h), d_kmers, uint32_t(k), n, d_out, h->d_flags, stream));
+    HIP_TRY(h, launch());
     if (h->timing) {
         HIP_TRY(h, hipEventRecord(stop, stream));
         h->events.push_back(start);
         h->events.push_back(stop);
     }
     return MSBWT_OK;
+}
+
+int launch_count(msbwt_rle *h, const uint8_t *d_kmers, size_t k, size_t n, uint64_t *d_out, hipStream_t stream) {
+    if (k > 0xFFFFFFFFull) return fail(h, MSBWT_ERR_INVALID_ARG, "k does not fit 32 bits");
+    return timed_launch(h, stream, [&] {
+        return launch_count_kmers(view_of(h), d_kmers, uint32_t(k), n, d_out, h->d_flags, stream);
+    });
 }
 
 }  // namespace
@@ -380,10 +389,12 @@ int msbwt_rle_count_read_kmers_device(const msbwt_rle *ch, const void *d_reads, 
         return fail(h, MSBWT_ERR_INVALID_ARG, "count_read_kmers needs 1 <= k <= min(32, read_len) and an output");
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
-    HIP_TRY(h, launch_count_read_kmers(view_of(h), static_cast<const uint8_t *>(d_reads), uint32_t(read_len), n_reads,
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    return timed_launch(h, stream, [&] {
+        return launch_count_read_kmers(view_of(h), static_cast<const uint8_t *>(d_reads), uint32_t(read_len), n_reads,
                                        uint32_t(k), ascii != 0, static_cast<uint64_t *>(d_out_fwd),
-                                       static_cast<uint64_t *>(d_out_rc), h->d_flags, static_cast<hipStream_t>(hip_stream)));
-    return MSBWT_OK;
+                                       static_cast<uint64_t *>(d_out_rc), h->d_flags, stream);
+    });
 }
 
 int msbwt_rle_count_read_kmers(const msbwt_rle *ch, const uint8_t *reads, size_t read_len, size_t n_reads, size_t k,

@@ -40,14 +40,13 @@ struct Segment {
 };
 
 // Expands the runs of one segment.  Blocks that a segment only partly covers are shared
-// with a neighbour: plane bits are OR-ed in (disjoint bit ranges), and a block's meta words
-// are written by whichever segment contains the block's first position.
-void expand_segment(const uint8_t *rle, const Segment &seg, const Totals &t, uint32_t *out,
-                    bool owns_first_block) {
+// with a neighbour: plane bits are OR-ed in (disjoint bit ranges); a block's header is written
+// whenever the running position reaches the block's first symbol.
+void expand_segment(const uint8_t *rle, const Segment &seg, const Totals &t, uint32_t *out) {
     uint64_t A[kAlphabet];
     for (int s = 0; s < kAlphabet; ++s) A[s] = t.start_index[s] + seg.occ[s];
     uint64_t pos = seg.pos;
-    if (owns_first_block && (pos & (kBlockSymbols - 1)) == 0) write_meta(out + (pos >> kBlockShift) * 32, A);
+    if ((pos & (kBlockSymbols - 1)) == 0) write_meta(out + (pos >> kBlockShift) * 32, A);
     for_each_run(rle + seg.byte_begin, seg.byte_end - seg.byte_begin, [&](uint8_t sym, uint64_t len) {
         while (len > 0) {
             const unsigned off = unsigned(pos & (kBlockSymbols - 1));
@@ -111,21 +110,16 @@ void build_plane_blocks(const uint8_t *rle, size_t n, const Totals &totals, uint
         Segment s{};
         segs.push_back(s);  // empty stream: just the header of block 0
     }
-    // Shared boundary blocks: plane words are OR-ed by two threads at most when a segment
-    // boundary falls inside a block; make those writes safe by painting boundary-adjacent
-    // segments sequentially (the segment count is tiny), the interior in parallel.
-    // Simpler and still parallel: segments paint disjoint bit ranges, but of the same 32-bit
-    // word possibly -> run odd and even segments in two phases so neighbours never overlap.
+    // Neighbouring segments paint disjoint bit ranges, but possibly of the same 32-bit word
+    // (a segment boundary inside a block), and both may write the header of a block that
+    // starts exactly on their border (same values).  Running the even and the odd segments
+    // in two phases keeps neighbours apart without any atomics.
     for (int phase = 0; phase < 2; ++phase) {
         std::vector<std::thread> pool;
         for (size_t i = size_t(phase); i < segs.size(); i += 2)
-            pool.emplace_back([&, i] { expand_segment(rle, segs[i], totals, out, true); });
+            pool.emplace_back([&, i] { expand_segment(rle, segs[i], totals, out); });
         for (auto &th : pool) th.join();
     }
-    // A zero-length stream or a segment starting mid-block never wrote block 0's header or
-    // the header of a block that begins inside a zero-length tail; block 0 is covered by the
-    // first segment (pos 0).  The final block's header is written when pos reaches a block
-    // boundary, or belongs to a block that began earlier -- nothing left to do.
 }
 
 }  // namespace msbwt

@@ -1,0 +1,63 @@
+#!/bin/bash
+# CPU-only sanitizer pass (GPU AddressSanitizer is not available on this pool): builds the
+# oracle and the product's host-side load path (codec, .npy reader, plane-block builder) with
+# -fsanitize=address,undefined and runs them over the golden fixtures and random streams.
+set -euo pipefail
+cd "$(dirname "$0")/.."
+ASAN=$(gcc -print-file-name=libasan.so)
+make -s -C oracle asan
+cp oracle/libmsbwt_oracle.so /tmp/liborc_keep.so
+cp oracle/libmsbwt_oracle_asan.so oracle/libmsbwt_oracle.so
+trap 'cp /tmp/liborc_keep.so oracle/libmsbwt_oracle.so' EXIT
+touch oracle/libmsbwt_oracle.so
+LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0 python -m pytest tests/test_oracle_golden.py tests/test_oracle_random.py -q -x -p no:cacheprovider
+cat > /tmp/host_asan_main.cpp <<'CPP'
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+#include "npy_io.hpp"
+#include "plane_index.hpp"
+#include "rle_codec.hpp"
+using namespace msbwt;
+int main(int argc, char **argv) {
+    std::mt19937_64 rng(7);
+    for (int round = 0; round < 40; ++round) {
+        std::vector<uint8_t> syms, rle;
+        std::vector<uint64_t> lens;
+        uint8_t prev = 9;
+        const int nruns = 1 + int(rng() % 3000);
+        for (int i = 0; i < nruns; ++i) {
+            uint8_t s = uint8_t(rng() % 6);
+            if (s == prev) s = uint8_t((s + 1) % 6);
+            prev = s;
+            syms.push_back(s);
+            const int kind = int(rng() % 8);
+            lens.push_back(kind == 0 ? 1 + rng() % 40000 : kind == 1 ? (1u << (5 * (1 + rng() % 3))) : 1 + rng() % 12);
+        }
+        encode_runs(syms.data(), lens.data(), syms.size(), &rle);
+        Totals t;
+        if (!compute_totals(rle.data(), rle.size(), &t)) return 1;
+        std::vector<uint32_t> blocks(plane_block_count(t.total) * 32);
+        build_plane_blocks(rle.data(), rle.size(), t, blocks.data(), 1 + round % 4);
+        std::string msg, path = "/tmp/asan_roundtrip.npy";
+        if (write_npy_payload(path, rle.data(), rle.size(), &msg) != NpyStatus::kOk) return 2;
+        std::vector<uint8_t> back;
+        if (read_npy_payload(path, &back, &msg) != NpyStatus::kOk || back != rle) return 3;
+    }
+    for (int i = 1; i < argc; ++i) {  // malformed files must be rejected cleanly
+        std::vector<uint8_t> p;
+        std::string msg;
+        (void)read_npy_payload(argv[i], &p, &msg);
+    }
+    std::puts("host asan ok");
+    return 0;
+}
+CPP
+g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -Irust-msbwt_amd/csrc \
+    /tmp/host_asan_main.cpp rust-msbwt_amd/csrc/rle_codec.cpp rust-msbwt_amd/csrc/npy_io.cpp rust-msbwt_amd/csrc/plane_index.cpp \
+    -lpthread -o /tmp/host_asan
+head -c 7 tests/golden/two_string.npy > /tmp/bad1.npy
+head -c 50 tests/golden/two_string.npy > /tmp/bad2.npy
+head -c 105 tests/golden/two_string.npy > /tmp/bad3.npy
+ASAN_OPTIONS=detect_leaks=1 /tmp/host_asan /tmp/bad1.npy /tmp/bad2.npy /tmp/bad3.npy tests/golden/two_string.npy /nonexistent.npy
