@@ -103,6 +103,14 @@ int msbwt_rle_count_read_kmers(const msbwt_rle *bwt, const uint8_t *reads, size_
                                size_t k, int ascii, uint64_t *out_fwd, uint64_t *out_rc);
 int msbwt_rle_count_read_kmers_device(const msbwt_rle *bwt, const void *d_reads, size_t read_len, size_t n_reads,
                                       size_t k, int ascii, void *d_out_fwd, void *d_out_rc, void *hip_stream);
+/* The same for reads of different lengths (host pointers): read r is
+ * reads[read_offsets[r] .. read_offsets[r+1]).  Counts are written window-major in read order:
+ * read r owns out[W_r .. W_r + max(0, len_r - k + 1)) with W_r the running sum over earlier
+ * reads; *out_windows (optional) receives the total.  out arrays must hold that many u64 --
+ * call with out_fwd == out_rc == NULL to obtain the total only. */
+int msbwt_rle_count_ragged_read_kmers(const msbwt_rle *bwt, const uint8_t *reads, const uint64_t *read_offsets,
+                                      size_t n_reads, size_t k, int ascii, uint64_t *out_fwd, uint64_t *out_rc,
+                                      uint64_t *out_windows);
 
 /* ---- tuning / introspection (no reference counterpart) ---- */
 /* Depth of the precomputed suffix table (the reference's stubbed kmer_cache,

@@ -31,6 +31,7 @@ SIGNATURES = {
     "msbwt_rle_constrain_ranges_device": (_int, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "msbwt_rle_device_status": (_int, [_vp, _vp]),
     "msbwt_rle_count_read_kmers": (_int, [_vp, _vp, _sz, _sz, _sz, _int, _vp, _vp]),
+    "msbwt_rle_count_ragged_read_kmers": (_int, [_vp, _vp, _vp, _sz, _sz, _int, _vp, _vp, _pu64]),
     "msbwt_rle_count_read_kmers_device": (_int, [_vp, _vp, _sz, _sz, _sz, _int, _vp, _vp, _vp]),
     "msbwt_rle_set_table_depth": (_int, [_vp, _int]),
     "msbwt_rle_get_table_depth": (_int, [_vp]),

@@ -442,6 +442,68 @@ int msbwt_rle_count_read_kmers(const msbwt_rle *ch, const uint8_t *reads, size_t
     return flags_to_code(h, all_flags);
 }
 
+int msbwt_rle_count_ragged_read_kmers(const msbwt_rle *ch, const uint8_t *reads, const uint64_t *read_offsets,
+                                      size_t n_reads, size_t k, int ascii, uint64_t *out_fwd, uint64_t *out_rc,
+                                      uint64_t *out_windows) {
+    msbwt_rle *h = const_cast<msbwt_rle *>(ch);
+    if (!h) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (k < 1 || k > 32 || (n_reads && (!read_offsets || !reads)))
+        return fail(h, MSBWT_ERR_INVALID_ARG, "count_ragged_read_kmers needs 1 <= k <= 32 and offsets");
+    // window prefix: read r owns [win[r], win[r+1])
+    std::vector<uint64_t> win(n_reads + 1, 0);
+    for (size_t r = 0; r < n_reads; ++r) {
+        if (read_offsets[r + 1] < read_offsets[r]) return fail(h, MSBWT_ERR_INVALID_ARG, "read offsets must not decrease");
+        const uint64_t len = read_offsets[r + 1] - read_offsets[r];
+        win[r + 1] = win[r] + (len >= k ? len - k + 1 : 0);
+    }
+    const uint64_t total_windows = win[n_reads];
+    if (out_windows) *out_windows = total_windows;
+    if (!out_fwd && !out_rc) return MSBWT_OK;
+    if (!h->loaded) return fail(h, MSBWT_ERR_NOT_LOADED, "no BWT loaded");
+    if (total_windows == 0) return MSBWT_OK;
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    // batches of whole reads holding at most ~4 Mi windows (at least one read)
+    uint32_t all_flags = 0;
+    for (size_t r0 = 0; r0 < n_reads;) {
+        size_t r1 = r0 + 1;
+        while (r1 < n_reads && win[r1 + 1] - win[r0] <= (uint64_t(1) << 22)) ++r1;
+        const uint64_t nwin = win[r1] - win[r0], nbytes = read_offsets[r1] - read_offsets[r0];
+        const size_t m = r1 - r0;
+        if (nwin) {
+            const size_t off_bytes = (m + 1) * sizeof(uint64_t);
+            const size_t read_bytes = (size_t(nbytes) + 15) / 16 * 16;
+            int rc = ensure_stage(h, read_bytes + 2 * off_bytes + 2 * nwin * sizeof(uint64_t) + 64);
+            if (rc) return rc;
+            uint8_t *d_r = static_cast<uint8_t *>(h->d_stage);
+            uint64_t *d_roff = reinterpret_cast<uint64_t *>(d_r + read_bytes);
+            uint64_t *d_woff = d_roff + (m + 1), *d_f = d_woff + (m + 1), *d_c = d_f + nwin;
+            std::vector<uint64_t> roff(m + 1), woff(m + 1);  // rebased to the batch
+            for (size_t i = 0; i <= m; ++i) {
+                roff[i] = read_offsets[r0 + i] - read_offsets[r0];
+                woff[i] = win[r0 + i] - win[r0];
+            }
+            HIP_TRY(h, hipMemcpyAsync(d_r, reads + read_offsets[r0], nbytes, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(d_roff, roff.data(), off_bytes, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(d_woff, woff.data(), off_bytes, hipMemcpyHostToDevice, h->stream));
+            rc = timed_launch(h, h->stream, [&] {
+                return launch_count_ragged_read_kmers(view_of(h), d_r, d_roff, d_woff, m, nwin, uint32_t(k), ascii != 0,
+                                                      out_fwd ? d_f : nullptr, out_rc ? d_c : nullptr, h->d_flags, h->stream);
+            });
+            if (rc) return rc;
+            if (out_fwd) HIP_TRY(h, hipMemcpyAsync(out_fwd + win[r0], d_f, nwin * 8, hipMemcpyDeviceToHost, h->stream));
+            if (out_rc) HIP_TRY(h, hipMemcpyAsync(out_rc + win[r0], d_c, nwin * 8, hipMemcpyDeviceToHost, h->stream));
+            uint32_t flags = 0;
+            rc = read_flags(h, h->stream, &flags);  // synchronises: roff/woff may go out of scope
+            if (rc) return rc;
+            all_flags |= flags;
+        }
+        r0 = r1;
+    }
+    return flags_to_code(h, all_flags);
+}
+
 int msbwt_rle_device_status(const msbwt_rle *ch, void *hip_stream) {
     msbwt_rle *h = const_cast<msbwt_rle *>(ch);
     if (!h) return MSBWT_ERR_INVALID_ARG;

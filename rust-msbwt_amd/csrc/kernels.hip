@@ -137,6 +137,10 @@ struct QuerySource {
     uint32_t strands;    // bit 0: forward wanted, bit 1: reverse complement wanted
     uint32_t ascii;
     uint64_t *out_fwd, *out_rc;
+    // ragged reads (different lengths): read r occupies data[read_off[r] .. read_off[r+1]) and
+    // owns the global windows [win_off[r], win_off[r+1]); nullptr = fixed read_len
+    const uint64_t *read_off, *win_off;
+    uint64_t n_reads;
 };
 
 __device__ __forceinline__ uint32_t ascii_to_code(uint32_t c) {
@@ -200,7 +204,16 @@ __global__ __launch_bounds__(256) void k_count_kmers_tiled(const uint4 *__restri
                 const uint64_t v = q0 + lane;
                 const uint64_t g = src.strands == 3u ? (v >> 1) : v;
                 rc = src.strands == 3u ? (v & 1u) != 0 : src.strands == 2u;
-                mine = kmers + (g / src.windows) * src.read_len + (g % src.windows);
+                if (src.win_off == nullptr) {
+                    mine = kmers + (g / src.windows) * src.read_len + (g % src.windows);
+                } else {  // last read whose first window is <= g (reads shorter than k own none)
+                    uint64_t lo = 0, hi = src.n_reads;
+                    while (hi - lo > 1) {
+                        const uint64_t mid = (lo + hi) >> 1;
+                        if (src.win_off[mid] <= g) lo = mid; else hi = mid;
+                    }
+                    mine = kmers + src.read_off[lo] + (g - src.win_off[lo]);
+                }
             }
 #pragma unroll 4
             for (uint32_t t = 0; t < k; ++t) {
@@ -414,6 +427,30 @@ hipError_t launch_count_read_kmers(const IndexView &ix, const uint8_t *reads, ui
     src.out_fwd = out_fwd;
     src.out_rc = out_rc;
     src.n = n_reads * src.windows * (src.strands == 3u ? 2u : 1u);
+    const uint64_t tiles = (src.n + kTile - 1) / kTile;
+    hipLaunchKernelGGL(k_count_kmers_tiled<true>, dim3(grid_for(tiles * 64)), dim3(256), 0, stream,
+                       static_cast<const uint4 *>(ix.blocks), ix.total, static_cast<const uint4 *>(ix.table.entries),
+                       uint32_t(ix.table.depth), src, flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_count_ragged_read_kmers(const IndexView &ix, const uint8_t *reads, const uint64_t *read_off,
+                                          const uint64_t *win_off, uint64_t n_reads, uint64_t n_windows, uint32_t k,
+                                          bool ascii, uint64_t *out_fwd, uint64_t *out_rc, uint32_t *flags,
+                                          hipStream_t stream) {
+    if (k < 1 || k > uint32_t(kMaxShortK) || (!out_fwd && !out_rc)) return hipErrorInvalidValue;
+    if (n_reads == 0 || n_windows == 0) return hipSuccess;
+    QuerySource src{};
+    src.data = reads;
+    src.k = k;
+    src.strands = (out_fwd ? 1u : 0u) | (out_rc ? 2u : 0u);
+    src.ascii = ascii ? 1u : 0u;
+    src.out_fwd = out_fwd;
+    src.out_rc = out_rc;
+    src.read_off = read_off;
+    src.win_off = win_off;
+    src.n_reads = n_reads;
+    src.n = n_windows * (src.strands == 3u ? 2u : 1u);
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
     hipLaunchKernelGGL(k_count_kmers_tiled<true>, dim3(grid_for(tiles * 64)), dim3(256), 0, stream,
                        static_cast<const uint4 *>(ix.blocks), ix.total, static_cast<const uint4 *>(ix.table.entries),

@@ -34,6 +34,14 @@ hipError_t launch_count_read_kmers(const IndexView &ix, const uint8_t *reads, ui
                                    uint32_t k, bool ascii, uint64_t *out_fwd, uint64_t *out_rc, uint32_t *flags,
                                    hipStream_t stream);
 
+// Same for reads of different lengths: read r = reads[read_off[r] .. read_off[r+1]), its
+// windows are the global windows [win_off[r], win_off[r+1]) (win_off = prefix sum of
+// max(0, len - k + 1)); all arrays on the device; out_*[global window].
+hipError_t launch_count_ragged_read_kmers(const IndexView &ix, const uint8_t *reads, const uint64_t *read_off,
+                                          const uint64_t *win_off, uint64_t n_reads, uint64_t n_windows, uint32_t k,
+                                          bool ascii, uint64_t *out_fwd, uint64_t *out_rc, uint32_t *flags,
+                                          hipStream_t stream);
+
 // (out_l[i], out_h[i]) = constrain_range(syms[i], [l[i], h[i])).
 hipError_t launch_constrain_ranges(const IndexView &ix, const uint8_t *syms, const uint64_t *l,
                                    const uint64_t *h, uint64_t n, uint64_t *out_l, uint64_t *out_h,

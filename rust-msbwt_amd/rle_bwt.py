@@ -139,6 +139,29 @@ class RleBWT(BWT):
             _raise(code, self._h)
         return fwd, rc
 
+    def count_ragged_read_kmers(self, reads, k, ascii=True, forward=True, revcomp=False):
+        """Like count_read_kmers for reads of different lengths.  `reads`: list of str/bytes (ASCII)
+        or of uint8 arrays (codes when ascii=False).  Returns (fwd, rc, window_offsets): flat
+        uint64 arrays in read order, read r owning [window_offsets[r], window_offsets[r+1])."""
+        arrs = [np.frombuffer(r.encode() if isinstance(r, str) else bytes(r), dtype=np.uint8)
+                if isinstance(r, (str, bytes, bytearray)) else np.asarray(r, dtype=np.uint8) for r in reads]
+        lens = np.array([len(a) for a in arrs], dtype=np.uint64)
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        flat = np.ascontiguousarray(np.concatenate(arrs)) if arrs else np.zeros(0, dtype=np.uint8)
+        woff = np.concatenate([[0], np.cumsum(np.where(lens >= k, lens - np.uint64(k) + np.uint64(1), 0))]).astype(np.uint64)
+        total = int(woff[-1])
+        fwd = np.empty(total, dtype=np.uint64) if forward else None
+        rc = np.empty(total, dtype=np.uint64) if revcomp else None
+        got = C.c_uint64()
+        code = _lib.lib().msbwt_rle_count_ragged_read_kmers(
+            self._h, flat.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p), len(arrs), k,
+            1 if ascii else 0, fwd.ctypes.data_as(C.c_void_p) if fwd is not None else None,
+            rc.ctypes.data_as(C.c_void_p) if rc is not None else None, C.byref(got))
+        if code:
+            _raise(code, self._h)
+        assert int(got.value) == total
+        return fwd, rc, woff
+
     def count_read_kmers_device(self, d_reads, read_len, n_reads, k, ascii, d_out_fwd, d_out_rc, stream=0):
         code = _lib.lib().msbwt_rle_count_read_kmers_device(self._h, d_reads, read_len, n_reads, k,
                                                             1 if ascii else 0, d_out_fwd, d_out_rc, stream)

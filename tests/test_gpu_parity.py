@@ -379,3 +379,33 @@ def test_fused_read_kmers_invalid_codes_are_flagged():
     with pytest.raises(msbwt.MsbwtError) as e:
         b.count_read_kmers(bad, 2, ascii=False)
     assert e.value.code == msbwt._lib.ERR_INVALID_SYMBOL
+
+
+def test_ragged_read_kmers():
+    """Reads of different lengths (some shorter than k, one empty) through the fused path."""
+    reads, rle = _real_bwt(13, 80, 40)
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    rng = np.random.default_rng(3)
+    ragged = []
+    for r in reads[:50]:
+        cut = int(rng.integers(0, len(r) + 1))
+        ragged.append(r[:cut])
+    ragged += ["", "ACG", reads[0]]
+    for k in (4, 21, 31):
+        fwd, rc, woff = b.count_ragged_read_kmers(ragged, k, revcomp=True)
+        assert len(woff) == len(ragged) + 1 and woff[-1] == len(fwd) == len(rc)
+        for i, t in enumerate(ragged):
+            n = max(0, len(t) - k + 1)
+            assert int(woff[i + 1] - woff[i]) == n
+            if n == 0:
+                continue
+            codes = orc.convert_stoi(t)
+            wins = np.array([codes[j:j + k] for j in range(n)], dtype=np.uint8)
+            rcs = np.array([orc.reverse_complement_i(x) for x in wins], dtype=np.uint8)
+            assert np.array_equal(fwd[int(woff[i]):int(woff[i + 1])], o.count_kmers(wins)), (k, i)
+            assert np.array_equal(rc[int(woff[i]):int(woff[i + 1])], o.count_kmers(rcs)), (k, i)
+    # nothing to count: every read shorter than k
+    f, r, w = b.count_ragged_read_kmers(["AC", "G"], 5)
+    assert len(f) == 0 and w.tolist() == [0, 0, 0]

@@ -92,3 +92,19 @@ def test_rle_stream_is_well_formed():
     assert len(plain) == total == 200000
     runs = 1 + int((plain[1:] != plain[:-1]).sum())
     assert 4.0 < total / runs < 8.0
+
+
+def test_workload_index_small_scale(tmp_path, monkeypatch):
+    """The bench's config builder at 0.1 % scale: the cached .npy loads in the oracle and every
+    read k-mer is present in it."""
+    monkeypatch.setattr(synth, "CACHE", str(tmp_path))
+    npy, rd = synth.workload_index("c2", scale=0.001)
+    assert rd.shape == (1000, 100)
+    o = orc.OracleRleBWT()
+    o.load_numpy_file(npy)
+    assert o.get_total_size() == 1000 * 101
+    assert o.get_symbol_count(0) == 1000
+    q = synth.read_kmers(rd, 21, limit=500, seed=1)
+    assert o.count_kmers(q).min() >= 1
+    npy2, rd2 = synth.workload_index("c2", scale=0.001)      # second call: served from the cache
+    assert npy2 == npy and np.array_equal(rd, rd2)
