@@ -119,7 +119,14 @@ int msbwt_rle_count_ragged_read_kmers(const msbwt_rle *bwt, const uint8_t *reads
  * off.  Takes effect immediately if an index is loaded.  Results never change. */
 int msbwt_rle_set_table_depth(msbwt_rle *bwt, int depth);
 int msbwt_rle_get_table_depth(const msbwt_rle *bwt);
-/* Bytes of HBM held by the index (blocks + table). */
+/* Pair index: a second block array (1 byte per symbol) that stores, next to each BWT symbol,
+ * the symbol one LF step further, so that one search step consumes TWO k-mer symbols for one
+ * line fetch per bound (maths: rust-msbwt_amd/csrc/rank_ops.hpp).  Built on the device from
+ * the loaded index.  mode 1 = on, 0 = off, -1 = on when it fits in half of the free HBM
+ * (default; MSBWT_PAIR_INDEX=0/1 in the environment overrides).  Results never change. */
+int msbwt_rle_set_pair_index(msbwt_rle *bwt, int mode);
+int msbwt_rle_get_pair_index(const msbwt_rle *bwt);
+/* Bytes of HBM held by the index (blocks + table + pair index). */
 uint64_t msbwt_rle_device_bytes(const msbwt_rle *bwt);
 /* Average duration in ms of the count kernel launches since the last reset, measured with
  * HIP events on the launch stream (bench.py's roofline uses it); resets the accumulator. */

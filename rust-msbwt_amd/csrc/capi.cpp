@@ -13,6 +13,7 @@
 #include "device_build.hpp"
 #include "kernels.hpp"
 #include "npy_io.hpp"
+#include "pair_index.hpp"
 #include "plane_index.hpp"
 #include "rle_codec.hpp"
 
@@ -25,6 +26,10 @@ struct msbwt_rle {
     Totals totals{};
     void *d_blocks = nullptr;
     uint64_t nblocks = 0;
+    void *d_pair_blocks = nullptr;  // optional pair index (two symbols per step)
+    void *d_pair_super = nullptr;
+    uint64_t pair_bytes = 0;
+    int wanted_pair = -1;           // -1 = on when it fits comfortably, 0 = off, 1 = on
     void *d_table = nullptr;
     int table_depth = 0;         // depth of the table currently in HBM
     int wanted_table_depth = -1; // -1 = pick from the index size
@@ -88,7 +93,10 @@ int hip_fail(msbwt_rle *h, hipError_t e, const char *what) {
 void release_index(msbwt_rle *h) {
     if (h->d_blocks) (void)hipFree(h->d_blocks);
     if (h->d_table) (void)hipFree(h->d_table);
-    h->d_blocks = h->d_table = nullptr;
+    if (h->d_pair_blocks) (void)hipFree(h->d_pair_blocks);
+    if (h->d_pair_super) (void)hipFree(h->d_pair_super);
+    h->d_blocks = h->d_table = h->d_pair_blocks = h->d_pair_super = nullptr;
+    h->pair_bytes = 0;
     h->nblocks = 0;
     h->table_depth = 0;
     h->loaded = false;
@@ -101,6 +109,8 @@ IndexView view_of(const msbwt_rle *h) {
     v.total = h->totals.total;
     v.table.entries = h->d_table;
     v.table.depth = h->d_table ? h->table_depth : 0;
+    v.pair_blocks = h->d_pair_blocks;
+    v.pair_super = static_cast<const uint64_t *>(h->d_pair_super);
     return v;
 }
 
@@ -155,6 +165,38 @@ int rebuild_table(msbwt_rle *h) {
     }
     h->d_table = tab;
     h->table_depth = depth;
+    return MSBWT_OK;
+}
+
+// Pair index (two symbols per step, rank_ops.hpp): 1 byte/symbol on top of the plane blocks,
+// built on the device from them.  Default policy: build it when it fits in half of what is
+// still free in HBM after the blocks (it is a pure speed-for-memory trade).
+int rebuild_pair_index(msbwt_rle *h) {
+    if (h->d_pair_blocks) (void)hipFree(h->d_pair_blocks);
+    if (h->d_pair_super) (void)hipFree(h->d_pair_super);
+    h->d_pair_blocks = h->d_pair_super = nullptr;
+    h->pair_bytes = 0;
+    if (h->wanted_pair == 0 || h->totals.total == 0) return MSBWT_OK;
+    const PairIndexSizes sz = pair_index_sizes(h->nblocks);
+    if (h->wanted_pair < 0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || sz.pair_block_bytes + sz.scratch_bytes > free_b / 2) return MSBWT_OK;
+    }
+    void *scratch = nullptr;
+    hipError_t e = hipMalloc(&h->d_pair_blocks, sz.pair_block_bytes);
+    if (e == hipSuccess) e = hipMalloc(&h->d_pair_super, sz.super_bytes);
+    if (e == hipSuccess) e = hipMalloc(&scratch, sz.scratch_bytes);
+    if (e == hipSuccess) e = build_pair_index(h->d_blocks, h->nblocks, h->totals.start_index, h->d_pair_blocks, h->d_pair_super, scratch, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (scratch) (void)hipFree(scratch);
+    if (e != hipSuccess) {
+        if (h->d_pair_blocks) (void)hipFree(h->d_pair_blocks);
+        if (h->d_pair_super) (void)hipFree(h->d_pair_super);
+        h->d_pair_blocks = h->d_pair_super = nullptr;
+        if (h->wanted_pair < 0 && e == hipErrorOutOfMemory) return MSBWT_OK;  // optional structure
+        return hip_fail(h, e, "build pair index");
+    }
+    h->pair_bytes = sz.pair_block_bytes + sz.super_bytes;
     return MSBWT_OK;
 }
 
@@ -246,6 +288,7 @@ int install(msbwt_rle *h, const uint8_t *rle, size_t n) {
     h->nblocks = plane_block_count(t.total);
     h->loaded = true;
     rc = rebuild_table(h);
+    if (!rc) rc = rebuild_pair_index(h);
     if (rc) {
         release_index(h);
         return rc;
@@ -306,6 +349,7 @@ msbwt_rle *msbwt_rle_new_on_device(uint8_t bin_power, int device) {
     if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;
     h->device = device;
     if (const char *env = std::getenv("MSBWT_TABLE_DEPTH")) h->wanted_table_depth = std::atoi(env);
+    if (const char *env = std::getenv("MSBWT_PAIR_INDEX")) h->wanted_pair = std::atoi(env) ? 1 : 0;
     return h;
 }
 
@@ -602,9 +646,21 @@ int msbwt_rle_set_table_depth(msbwt_rle *h, int depth) {
 
 int msbwt_rle_get_table_depth(const msbwt_rle *h) { return h ? h->table_depth : 0; }
 
+int msbwt_rle_set_pair_index(msbwt_rle *h, int mode) {
+    if (!h || mode < -1 || mode > 1) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->wanted_pair = mode;
+    if (!h->loaded) return MSBWT_OK;
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    return rebuild_pair_index(h);
+}
+
+int msbwt_rle_get_pair_index(const msbwt_rle *h) { return (h && h->d_pair_blocks) ? 1 : 0; }
+
 uint64_t msbwt_rle_device_bytes(const msbwt_rle *h) {
     if (!h || !h->loaded) return 0;
-    return h->nblocks * kBlockBytes + (h->d_table ? (uint64_t(16) << (2 * h->table_depth)) : 0);
+    return h->nblocks * kBlockBytes + (h->d_table ? (uint64_t(16) << (2 * h->table_depth)) : 0) + h->pair_bytes;
 }
 
 int msbwt_rle_set_kernel_timing(msbwt_rle *h, int enabled) {

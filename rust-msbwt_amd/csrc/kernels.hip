@@ -19,60 +19,14 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.hpp"
+#include "rank_ops.hpp"
 
 namespace msbwt {
 namespace {
 
-constexpr int kGroup = 8;       // lanes per query in the search phase
 constexpr int kTile = 64;       // queries per wave tile
 constexpr int kMaxShortK = 32;  // tiled kernel: symbols fit 96 bits
 constexpr int kWavesPerBlock = 4;
-
-// x (op) value of x in the lane selected by the DPP control, all 64 lanes
-template <int kCtrl>
-__device__ __forceinline__ uint32_t dpp_add(uint32_t x) {
-    return x + uint32_t(__builtin_amdgcn_update_dpp(0, int(x), kCtrl, 0xF, 0xF, true));
-}
-// Sum over each aligned group of 8 lanes; every lane of the group gets the total.
-__device__ __forceinline__ uint32_t group_sum(uint32_t x) {
-    x = dpp_add<0xB1>(x);   // quad_perm [1,0,3,2]: lane ^ 1
-    x = dpp_add<0x4E>(x);   // quad_perm [2,3,0,1]: lane ^ 2
-    x = dpp_add<0x141>(x);  // row_half_mirror: lane -> 7 - lane (the other quad of the 8)
-    return x;
-}
-
-struct Range {
-    uint64_t l, h;
-};
-
-// New range for prepending symbol s (0..5) to [l, h): start_index[s] + rank(s, l / h).
-// Called by all 8 lanes of a group with identical (s, l, h); `sub` = lane index in group.
-__device__ __forceinline__ Range constrain(const uint4 *__restrict__ blocks, uint32_t s, uint64_t l,
-                                           uint64_t h, uint32_t sub) {
-    const uint4 cl = blocks[(l >> 8) * kGroup + sub];
-    const uint4 ch = blocks[(h >> 8) * kGroup + sub];
-    // a symbol matches s iff every plane bit equals the corresponding bit of s
-    const uint32_t x0 = (s & 1u) ? 0u : ~0u, x1 = (s & 2u) ? 0u : ~0u, x2 = (s & 4u) ? 0u : ~0u;
-    const int nl = min(max(int(uint32_t(l) & 255u) - int(sub * 32u), 0), 32);
-    const int nh = min(max(int(uint32_t(h) & 255u) - int(sub * 32u), 0), 32);
-    const uint32_t ml = nl >= 32 ? ~0u : ((1u << nl) - 1u);
-    const uint32_t mh = nh >= 32 ? ~0u : ((1u << nh) - 1u);
-    const uint32_t cnt_l = __popc((cl.x ^ x0) & (cl.y ^ x1) & (cl.z ^ x2) & ml);  // <= 32, sum <= 255
-    const uint32_t cnt_h = __popc((ch.x ^ x0) & (ch.y ^ x1) & (ch.z ^ x2) & mh);
-    // the block's 40-bit bound A[s]: low word in chunk s, high byte in chunk 6 (s<4) or 7
-    const bool owns_lo = (sub == s);
-    const bool owns_hi = (sub == 6u + (s >> 2));
-    const uint32_t sh = (s & 3u) * 8u;
-    const uint32_t lo_l = owns_lo ? cl.w : 0u, lo_h = owns_lo ? ch.w : 0u;
-    const uint32_t hi_l = owns_hi ? ((cl.w >> sh) & 0xFFu) : 0u, hi_h = owns_hi ? ((ch.w >> sh) & 0xFFu) : 0u;
-    // four byte-wide fields never carry into each other: counts sum to <= 255, one lane owns hi
-    const uint32_t packed = group_sum(cnt_l | (hi_l << 8) | (cnt_h << 16) | (hi_h << 24));
-    const uint32_t base_l = group_sum(lo_l), base_h = group_sum(lo_h);
-    Range r;
-    r.l = ((uint64_t((packed >> 8) & 0xFFu) << 32) | base_l) + (packed & 0xFFu);
-    r.h = ((uint64_t(packed >> 24) << 32) | base_h) + ((packed >> 16) & 0xFFu);
-    return r;
-}
 
 // compiler-level ordering of one wave's LDS writes before its later LDS reads (the LDS
 // executes a wave's operations in issue order; no s_barrier is needed inside a wave)
@@ -153,8 +107,10 @@ __device__ __forceinline__ uint32_t complement_code(uint32_t s) {  // $ACGNT -> 
 }
 
 template <bool kReads>
-__global__ __launch_bounds__(256) void k_count_kmers_tiled(const uint4 *__restrict__ blocks, uint64_t total,
+__global__ __launch_bounds__(256, 8) void k_count_kmers_tiled(const uint4 *__restrict__ blocks, uint64_t total,
                                                            const uint4 *__restrict__ table, uint32_t depth,
+                                                           const uint4 *__restrict__ pair_blocks,
+                                                           const uint64_t *__restrict__ pair_super,
                                                            const QuerySource src, uint32_t *__restrict__ flags) {
     __shared__ WaveScratch scratch[kWavesPerBlock];
     const uint8_t *__restrict__ kmers = src.data;
@@ -300,13 +256,25 @@ __global__ __launch_bounds__(256) void k_count_kmers_tiled(const uint4 *__restri
                 next = min(nwork, next + uint32_t(__popcll(idle)));
                 if (!__any(have)) break;
                 if (have) {
-                    const Range r = constrain(blocks, w0 & 7u, l, h, sub);
-                    l = r.l;
-                    h = r.h;
-                    w0 = __builtin_amdgcn_alignbit(w1, w0, 3);
-                    w1 = __builtin_amdgcn_alignbit(w2, w1, 3);
-                    w2 >>= 3;
-                    --rem;
+                    const uint32_t s1 = w0 & 7u, s2 = (w0 >> 3) & 7u;
+                    if (pair_blocks != nullptr && rem >= 2u && is_acgt(s1) && is_acgt(s2)) {
+                        // two symbols for one line fetch per bound
+                        const Range r = constrain2(pair_blocks, pair_super, acgt_code(s1), acgt_code(s2), l, h, sub);
+                        l = r.l;
+                        h = r.h;
+                        w0 = __builtin_amdgcn_alignbit(w1, w0, 6);
+                        w1 = __builtin_amdgcn_alignbit(w2, w1, 6);
+                        w2 >>= 6;
+                        rem -= 2u;
+                    } else {
+                        const Range r = constrain(blocks, s1, l, h, sub);
+                        l = r.l;
+                        h = r.h;
+                        w0 = __builtin_amdgcn_alignbit(w1, w0, 3);
+                        w1 = __builtin_amdgcn_alignbit(w2, w1, 3);
+                        w2 >>= 3;
+                        --rem;
+                    }
                     if (rem == 0u || l == h) {
                         if (sub == 0u) ws.result[slot] = h - l;
                         have = false;
@@ -404,7 +372,8 @@ hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_
         src.k = k;
         src.out_fwd = counts;
         hipLaunchKernelGGL(k_count_kmers_tiled<false>, dim3(grid_for(tiles * 64)), dim3(256), 0, stream, blocks,
-                           ix.total, static_cast<const uint4 *>(ix.table.entries), uint32_t(ix.table.depth), src, flags);
+                           ix.total, static_cast<const uint4 *>(ix.table.entries), uint32_t(ix.table.depth),
+                           static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags);
     } else {
         hipLaunchKernelGGL(k_count_kmers_generic, dim3(grid_for(n * kGroup)), dim3(256), 0, stream, blocks,
                            ix.total, kmers, k, n, counts, flags);
@@ -430,7 +399,7 @@ hipError_t launch_count_read_kmers(const IndexView &ix, const uint8_t *reads, ui
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
     hipLaunchKernelGGL(k_count_kmers_tiled<true>, dim3(grid_for(tiles * 64)), dim3(256), 0, stream,
                        static_cast<const uint4 *>(ix.blocks), ix.total, static_cast<const uint4 *>(ix.table.entries),
-                       uint32_t(ix.table.depth), src, flags);
+                       uint32_t(ix.table.depth), static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags);
     return hipGetLastError();
 }
 
@@ -454,7 +423,7 @@ hipError_t launch_count_ragged_read_kmers(const IndexView &ix, const uint8_t *re
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
     hipLaunchKernelGGL(k_count_kmers_tiled<true>, dim3(grid_for(tiles * 64)), dim3(256), 0, stream,
                        static_cast<const uint4 *>(ix.blocks), ix.total, static_cast<const uint4 *>(ix.table.entries),
-                       uint32_t(ix.table.depth), src, flags);
+                       uint32_t(ix.table.depth), static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags);
     return hipGetLastError();
 }
 

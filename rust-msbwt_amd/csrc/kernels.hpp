@@ -21,6 +21,8 @@ struct IndexView {
     uint64_t nblocks;
     uint64_t total;
     TableView table;
+    const void *pair_blocks = nullptr;      // optional: two symbols per step (rank_ops.hpp)
+    const uint64_t *pair_super = nullptr;
 };
 
 // counts[q] = count_kmer(kmers[q*k .. q*k+k)) for q < n.  Sets kFlagInvalidSymbol in *flags

@@ -1,0 +1,111 @@
+// Device-side rank primitives shared by the query kernels (kernels.hip) and the pair-index
+// builder (pair_index.hip).  Include from HIP translation units only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace msbwt {
+namespace {
+
+constexpr int kGroup = 8;       // lanes per query in the search phase
+
+// x (op) value of x in the lane selected by the DPP control, all 64 lanes
+template <int kCtrl>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t x) {
+    return x + uint32_t(__builtin_amdgcn_update_dpp(0, int(x), kCtrl, 0xF, 0xF, true));
+}
+// Sum over each aligned group of 8 lanes; every lane of the group gets the total.
+__device__ __forceinline__ uint32_t group_sum(uint32_t x) {
+    x = dpp_add<0xB1>(x);   // quad_perm [1,0,3,2]: lane ^ 1
+    x = dpp_add<0x4E>(x);   // quad_perm [2,3,0,1]: lane ^ 2
+    x = dpp_add<0x141>(x);  // row_half_mirror: lane -> 7 - lane (the other quad of the 8)
+    return x;
+}
+
+struct Range {
+    uint64_t l, h;
+};
+
+// New range for prepending symbol s (0..5) to [l, h): start_index[s] + rank(s, l / h).
+// Called by all 8 lanes of a group with identical (s, l, h); `sub` = lane index in group.
+__device__ __forceinline__ Range constrain(const uint4 *__restrict__ blocks, uint32_t s, uint64_t l,
+                                           uint64_t h, uint32_t sub) {
+    const uint4 cl = blocks[(l >> 8) * kGroup + sub];
+    const uint4 ch = blocks[(h >> 8) * kGroup + sub];
+    // a symbol matches s iff every plane bit equals the corresponding bit of s
+    const uint32_t x0 = (s & 1u) ? 0u : ~0u, x1 = (s & 2u) ? 0u : ~0u, x2 = (s & 4u) ? 0u : ~0u;
+    const int nl = min(max(int(uint32_t(l) & 255u) - int(sub * 32u), 0), 32);
+    const int nh = min(max(int(uint32_t(h) & 255u) - int(sub * 32u), 0), 32);
+    const uint32_t ml = nl >= 32 ? ~0u : ((1u << nl) - 1u);
+    const uint32_t mh = nh >= 32 ? ~0u : ((1u << nh) - 1u);
+    const uint32_t cnt_l = __popc((cl.x ^ x0) & (cl.y ^ x1) & (cl.z ^ x2) & ml);  // <= 32, sum <= 255
+    const uint32_t cnt_h = __popc((ch.x ^ x0) & (ch.y ^ x1) & (ch.z ^ x2) & mh);
+    // the block's 40-bit bound A[s]: low word in chunk s, high byte in chunk 6 (s<4) or 7
+    const bool owns_lo = (sub == s);
+    const bool owns_hi = (sub == 6u + (s >> 2));
+    const uint32_t sh = (s & 3u) * 8u;
+    const uint32_t lo_l = owns_lo ? cl.w : 0u, lo_h = owns_lo ? ch.w : 0u;
+    const uint32_t hi_l = owns_hi ? ((cl.w >> sh) & 0xFFu) : 0u, hi_h = owns_hi ? ((ch.w >> sh) & 0xFFu) : 0u;
+    // four byte-wide fields never carry into each other: counts sum to <= 255, one lane owns hi
+    const uint32_t packed = group_sum(cnt_l | (hi_l << 8) | (cnt_h << 16) | (hi_h << 24));
+    const uint32_t base_l = group_sum(lo_l), base_h = group_sum(lo_h);
+    Range r;
+    r.l = ((uint64_t((packed >> 8) & 0xFFu) << 32) | base_l) + (packed & 0xFFu);
+    r.h = ((uint64_t(packed >> 24) << 32) | base_h) + ((packed >> 16) & 0xFFu);
+    return r;
+}
+
+
+// ---- pair blocks: two symbols per search step ------------------------------------------------
+// With S the BWT and S2[i] = S[LF(i)], two consecutive steps (first a, then b) collapse into
+//     p'' = K[a][b] + occ2(a, b, p),   K[a][b] = C[b] + occ(b, C[a]),
+//     occ2(a, b, p) = #{ i < p : S[i] = a and S2[i] = b }
+// (rows C[a] + j, j = 0.., are exactly the positions holding a, in order).  A pair block is
+// 128 bytes for 128 positions: chunk j (16 B) = { a-planes, b-planes, valid | header bits } of
+// positions 16j..16j+15, where a/b are 2-bit ACGT codes (A C G T -> 0..3) and `valid` marks
+// positions whose S and S2 are both ACGT.  The 8 x 48 header bits hold the 16 pair counts
+// occ2(.,., block start) relative to the block's 2^24-position superblock (24 bits each,
+// pairs 2j and 2j+1 in chunk j); `super` holds K + occ2(superblock start) as u64 x 16.
+constexpr int kPairShift = 7;         // 128 positions per pair block
+constexpr int kPairSuperShift = 24;   // 2^24 positions per superblock
+
+__device__ __forceinline__ uint32_t acgt_code(uint32_t s) { return s == 5u ? 3u : s - 1u; }  // s in {1,2,3,5}
+__device__ __forceinline__ bool is_acgt(uint32_t s) { return s == 5u || (s >= 1u && s <= 3u); }
+
+// matches of pair (a2, b2) among the first n (0..16) positions of one pair chunk
+__device__ __forceinline__ uint32_t pair_chunk_count(const uint4 c, uint32_t a2, uint32_t b2, int n) {
+    const uint32_t pa = ((a2 & 1u) ? 0x0000FFFFu : 0u) | ((a2 & 2u) ? 0xFFFF0000u : 0u);
+    const uint32_t pb = ((b2 & 1u) ? 0x0000FFFFu : 0u) | ((b2 & 2u) ? 0xFFFF0000u : 0u);
+    const uint32_t ea = ~(c.x ^ pa), eb = ~(c.y ^ pb);  // 1 where the plane bit equals the wanted bit
+    const uint32_t m = ea & (ea >> 16) & eb & (eb >> 16) & c.z & ((1u << n) - 1u) & 0xFFFFu;
+    return uint32_t(__popc(m));
+}
+
+// 24-bit header field of pair p held by this chunk (p>>1 must be the chunk index)
+__device__ __forceinline__ uint32_t pair_chunk_field(const uint4 c, uint32_t p) {
+    return (p & 1u) ? (c.w >> 8) : ((c.z >> 16) | ((c.w & 0xFFu) << 16));
+}
+
+// Range after prepending symbol a then symbol b (both ACGT, given as 2-bit codes).
+__device__ __forceinline__ Range constrain2(const uint4 *__restrict__ pair_blocks, const uint64_t *__restrict__ super,
+                                            uint32_t a2, uint32_t b2, uint64_t l, uint64_t h, uint32_t sub) {
+    const uint4 cl = pair_blocks[(l >> kPairShift) * kGroup + sub];
+    const uint4 ch = pair_blocks[(h >> kPairShift) * kGroup + sub];
+    const uint32_t p = a2 * 4u + b2;
+    const uint64_t kl = super[(l >> kPairSuperShift) * 16u + p];
+    const uint64_t kh = super[(h >> kPairSuperShift) * 16u + p];
+    const int nl = min(max(int(uint32_t(l) & 127u) - int(sub * 16u), 0), 16);
+    const int nh = min(max(int(uint32_t(h) & 127u) - int(sub * 16u), 0), 16);
+    const bool owner = (sub == (p >> 1));
+    // count (<= 128 summed) in the low byte, the owner's 24-bit field above it: no carries
+    const uint32_t tl = group_sum(pair_chunk_count(cl, a2, b2, nl) | (owner ? pair_chunk_field(cl, p) << 8 : 0u));
+    const uint32_t th = group_sum(pair_chunk_count(ch, a2, b2, nh) | (owner ? pair_chunk_field(ch, p) << 8 : 0u));
+    Range r;
+    r.l = kl + (tl >> 8) + (tl & 0xFFu);
+    r.h = kh + (th >> 8) + (th & 0xFFu);
+    return r;
+}
+
+}  // namespace
+}  // namespace msbwt

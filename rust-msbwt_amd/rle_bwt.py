@@ -194,6 +194,15 @@ class RleBWT(BWT):
     def get_table_depth(self):
         return int(_lib.lib().msbwt_rle_get_table_depth(self._h))
 
+    def set_pair_index(self, mode):
+        """1 = build the two-symbols-per-step index, 0 = drop it, -1 = automatic (default)."""
+        rc = _lib.lib().msbwt_rle_set_pair_index(self._h, mode)
+        if rc:
+            _raise(rc, self._h)
+
+    def get_pair_index(self):
+        return bool(_lib.lib().msbwt_rle_get_pair_index(self._h))
+
     def device_bytes(self):
         return int(_lib.lib().msbwt_rle_device_bytes(self._h))
 

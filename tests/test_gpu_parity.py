@@ -409,3 +409,47 @@ def test_ragged_read_kmers():
     # nothing to count: every read shorter than k
     f, r, w = b.count_ragged_read_kmers(["AC", "G"], 5)
     assert len(f) == 0 and w.tolist() == [0, 0, 0]
+
+
+@pytest.mark.parametrize("pair", [0, 1])
+@pytest.mark.parametrize("depth", [0, 3, 8])
+def test_pair_index_never_changes_results(pair, depth):
+    """Two-symbols-per-step blocks on/off x table depths: identical counts, for k of both
+    parities, with $ / N inside the k-mer (those steps fall back to single symbols)."""
+    reads, rle = _real_bwt(17, 220, 64)
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    b.set_table_depth(depth)
+    b.set_pair_index(pair)
+    assert b.get_pair_index() == bool(pair)
+    rng = np.random.default_rng(depth * 2 + pair)
+    for k in (1, 2, 3, 4, 9, 10, 20, 21, 31, 32):
+        qs = [orc.convert_stoi(r[p:p + k]) for r in reads if len(r) >= k for p in (int(rng.integers(0, len(r) - k + 1)),)]
+        qs = np.concatenate([np.array(qs, dtype=np.uint8), random_kmers(k, 300, k),
+                             random_kmers(k + 7, 200, k, alphabet=(0, 1, 2, 3, 4, 5))])
+        assert np.array_equal(b.count_kmers(qs), o.count_kmers(qs)), (pair, depth, k)
+    texts = [r for r in reads if len(r) == 64][:40]
+    fwd, rc = b.count_read_kmers(texts, 31, revcomp=True)
+    for r, t in enumerate(texts):
+        codes = orc.convert_stoi(t)
+        wins = np.array([codes[i:i + 31] for i in range(34)], dtype=np.uint8)
+        assert np.array_equal(fwd[r], o.count_kmers(wins))
+        assert np.array_equal(rc[r], o.count_kmers(np.array([orc.reverse_complement_i(x) for x in wins], dtype=np.uint8)))
+
+
+def test_pair_index_on_random_streams_and_superblock_borders():
+    """Synthetic streams (not BWTs): the pair identity must hold for any symbol string.  The
+    second stream is longer than one 2^24-position superblock."""
+    for rle, nq in ((random_stream(41, 50000, "short"), 4000), (random_stream(43, 2_000_000, "long"), 4000)):
+        o = orc.OracleRleBWT()
+        o.load_vector(rle)
+        b = gpu_bwt(rle)
+        b.set_table_depth(2)
+        b.set_pair_index(1)
+        for k in (6, 7, 12):
+            qs = random_kmers(k, nq, k)
+            assert np.array_equal(b.count_kmers(qs), o.count_kmers(qs)), k
+        b.set_pair_index(0)
+        qs = random_kmers(5, nq, 8)
+        assert np.array_equal(b.count_kmers(qs), o.count_kmers(qs))
