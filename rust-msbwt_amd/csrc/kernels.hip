@@ -18,6 +18,8 @@
 // Results go to LDS and leave as one coalesced 512-byte store per tile.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.hpp"
 #include "rank_ops.hpp"
 
@@ -106,8 +108,8 @@ __device__ __forceinline__ uint32_t complement_code(uint32_t s) {  // $ACGNT -> 
     return s == 1u ? 5u : s == 5u ? 1u : s == 2u ? 3u : s == 3u ? 2u : s;
 }
 
-template <bool kReads>
-__global__ __launch_bounds__(256, 8) void k_count_kmers_tiled(const uint4 *__restrict__ blocks, uint64_t total,
+template <bool kReads, int kLanes, bool kPair>
+__global__ __launch_bounds__(256, kLanes == 4 ? 6 : 8) void k_count_kmers_tiled(const uint4 *__restrict__ blocks, uint64_t total,
                                                            const uint4 *__restrict__ table, uint32_t depth,
                                                            const uint4 *__restrict__ pair_blocks,
                                                            const uint64_t *__restrict__ pair_super,
@@ -117,8 +119,8 @@ __global__ __launch_bounds__(256, 8) void k_count_kmers_tiled(const uint4 *__res
     const uint32_t k = src.k;
     const uint64_t n = src.n;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t sub = lane & (kGroup - 1);
-    const uint32_t group_first_lane = lane & ~uint32_t(kGroup - 1);
+    const uint32_t sub = lane & (kLanes - 1);
+    const uint32_t group_first_lane = lane & ~uint32_t(kLanes - 1);
     WaveScratch &ws = scratch[threadIdx.x >> 6];
     const uint8_t *stage_bytes = reinterpret_cast<const uint8_t *>(ws.stage);
 
@@ -257,9 +259,9 @@ __global__ __launch_bounds__(256, 8) void k_count_kmers_tiled(const uint4 *__res
                 if (!__any(have)) break;
                 if (have) {
                     const uint32_t s1 = w0 & 7u, s2 = (w0 >> 3) & 7u;
-                    if (pair_blocks != nullptr && rem >= 2u && is_acgt(s1) && is_acgt(s2)) {
+                    if (kPair && rem >= 2u && is_acgt(s1) && is_acgt(s2)) {
                         // two symbols for one line fetch per bound
-                        const Range r = constrain2(pair_blocks, pair_super, acgt_code(s1), acgt_code(s2), l, h, sub);
+                        const Range r = GroupOps<kLanes>::step2(pair_blocks, pair_super, acgt_code(s1), acgt_code(s2), l, h, sub);
                         l = r.l;
                         h = r.h;
                         w0 = __builtin_amdgcn_alignbit(w1, w0, 6);
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256, 8) void k_count_kmers_tiled(const uint4 *__res
                         w2 >>= 6;
                         rem -= 2u;
                     } else {
-                        const Range r = constrain(blocks, s1, l, h, sub);
+                        const Range r = GroupOps<kLanes>::step(blocks, s1, l, h, sub);
                         l = r.l;
                         h = r.h;
                         w0 = __builtin_amdgcn_alignbit(w1, w0, 3);
@@ -351,10 +353,46 @@ __global__ __launch_bounds__(256) void k_constrain_ranges(const uint4 *__restric
     }
 }
 
+// The tiled kernel comes in 2 x 2 x 2 shapes; pick one and launch it.
+template <bool kReads>
+void launch_tiled(bool quad, bool pair, dim3 grid, hipStream_t stream, const uint4 *blocks, uint64_t total,
+                  const uint4 *table, uint32_t depth, const uint4 *pair_blocks, const uint64_t *pair_super,
+                  const QuerySource &src, uint32_t *flags);
+
+// Lanes per query in the tiled kernel: 8 (default) or 4 (MSBWT_GROUP_LANES=4)
+inline bool use_quad_groups() {
+    static const bool quad = [] {
+        const char *env = std::getenv("MSBWT_GROUP_LANES");
+        return env && std::atoi(env) == 4;
+    }();
+    return quad;
+}
+
 // 256 CUs x 8 blocks of 256 threads fill the chip; smaller batches get just enough blocks
 inline uint32_t grid_for(uint64_t threads_wanted) {
     const uint64_t blocks = (threads_wanted + 255) / 256;
     return uint32_t(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
+}
+
+// Pair steps pay off when at least a few symbols remain after the table lookup; for shorter
+// tails the leaner single-step kernel is faster (C2: 21-mers behind a depth-13 table).
+inline bool use_pair_steps(const IndexView &ix, uint32_t k) {
+    const uint32_t depth = (ix.table.entries && k >= uint32_t(ix.table.depth)) ? uint32_t(ix.table.depth) : 0u;
+    return ix.pair_blocks != nullptr && k - depth >= 10u;
+}
+
+template <bool kReads>
+void launch_tiled(bool quad, bool pair, dim3 grid, hipStream_t stream, const uint4 *blocks, uint64_t total,
+                  const uint4 *table, uint32_t depth, const uint4 *pair_blocks, const uint64_t *pair_super,
+                  const QuerySource &src, uint32_t *flags) {
+#define MSBWT_LAUNCH(L, P) \
+    hipLaunchKernelGGL((k_count_kmers_tiled<kReads, L, P>), grid, dim3(256), 0, stream, blocks, total, table, depth, pair_blocks, pair_super, src, flags)
+    if (quad) {
+        if (pair) MSBWT_LAUNCH(4, true); else MSBWT_LAUNCH(4, false);
+    } else {
+        if (pair) MSBWT_LAUNCH(8, true); else MSBWT_LAUNCH(8, false);
+    }
+#undef MSBWT_LAUNCH
 }
 
 }  // namespace
@@ -366,14 +404,15 @@ hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_
     const bool aligned = (reinterpret_cast<uintptr_t>(kmers) & 15u) == 0;
     if (k >= 1 && k <= uint32_t(kMaxShortK) && aligned) {
         const uint64_t tiles = (n + kTile - 1) / kTile;
+        const bool quad = use_quad_groups();
         QuerySource src{};
         src.data = kmers;
         src.n = n;
         src.k = k;
         src.out_fwd = counts;
-        hipLaunchKernelGGL(k_count_kmers_tiled<false>, dim3(grid_for(tiles * 64)), dim3(256), 0, stream, blocks,
-                           ix.total, static_cast<const uint4 *>(ix.table.entries), uint32_t(ix.table.depth),
-                           static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags);
+        launch_tiled<false>(quad, use_pair_steps(ix, k), dim3(grid_for(tiles * 64)), stream, blocks, ix.total,
+                            static_cast<const uint4 *>(ix.table.entries), uint32_t(ix.table.depth),
+                            static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags);
     } else {
         hipLaunchKernelGGL(k_count_kmers_generic, dim3(grid_for(n * kGroup)), dim3(256), 0, stream, blocks,
                            ix.total, kmers, k, n, counts, flags);
@@ -386,6 +425,7 @@ hipError_t launch_count_read_kmers(const IndexView &ix, const uint8_t *reads, ui
                                    hipStream_t stream) {
     if (k < 1 || k > uint32_t(kMaxShortK) || k > read_len || (!out_fwd && !out_rc)) return hipErrorInvalidValue;
     if (n_reads == 0) return hipSuccess;
+    const bool quad = use_quad_groups();
     QuerySource src{};
     src.data = reads;
     src.k = k;
@@ -397,9 +437,9 @@ hipError_t launch_count_read_kmers(const IndexView &ix, const uint8_t *reads, ui
     src.out_rc = out_rc;
     src.n = n_reads * src.windows * (src.strands == 3u ? 2u : 1u);
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
-    hipLaunchKernelGGL(k_count_kmers_tiled<true>, dim3(grid_for(tiles * 64)), dim3(256), 0, stream,
-                       static_cast<const uint4 *>(ix.blocks), ix.total, static_cast<const uint4 *>(ix.table.entries),
-                       uint32_t(ix.table.depth), static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags);
+    launch_tiled<true>(quad, use_pair_steps(ix, k), dim3(grid_for(tiles * 64)), stream, static_cast<const uint4 *>(ix.blocks),
+                       ix.total, static_cast<const uint4 *>(ix.table.entries), uint32_t(ix.table.depth),
+                       static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags);
     return hipGetLastError();
 }
 
@@ -409,6 +449,7 @@ hipError_t launch_count_ragged_read_kmers(const IndexView &ix, const uint8_t *re
                                           hipStream_t stream) {
     if (k < 1 || k > uint32_t(kMaxShortK) || (!out_fwd && !out_rc)) return hipErrorInvalidValue;
     if (n_reads == 0 || n_windows == 0) return hipSuccess;
+    const bool quad = use_quad_groups();
     QuerySource src{};
     src.data = reads;
     src.k = k;
@@ -421,9 +462,9 @@ hipError_t launch_count_ragged_read_kmers(const IndexView &ix, const uint8_t *re
     src.n_reads = n_reads;
     src.n = n_windows * (src.strands == 3u ? 2u : 1u);
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
-    hipLaunchKernelGGL(k_count_kmers_tiled<true>, dim3(grid_for(tiles * 64)), dim3(256), 0, stream,
-                       static_cast<const uint4 *>(ix.blocks), ix.total, static_cast<const uint4 *>(ix.table.entries),
-                       uint32_t(ix.table.depth), static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags);
+    launch_tiled<true>(quad, use_pair_steps(ix, k), dim3(grid_for(tiles * 64)), stream, static_cast<const uint4 *>(ix.blocks),
+                       ix.total, static_cast<const uint4 *>(ix.table.entries), uint32_t(ix.table.depth),
+                       static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags);
     return hipGetLastError();
 }
 

@@ -82,9 +82,10 @@ __device__ __forceinline__ uint32_t pair_chunk_count(const uint4 c, uint32_t a2,
     return uint32_t(__popc(m));
 }
 
-// 24-bit header field of pair p held by this chunk (p>>1 must be the chunk index)
+// 24-bit header field of pair p held by this chunk (p>>1 must be the chunk index); branch-free
 __device__ __forceinline__ uint32_t pair_chunk_field(const uint4 c, uint32_t p) {
-    return (p & 1u) ? (c.w >> 8) : ((c.z >> 16) | ((c.w & 0xFFu) << 16));
+    const uint32_t even = (c.z >> 16) | ((c.w & 0xFFu) << 16), odd = c.w >> 8;
+    return (p & 1u) ? odd : even;
 }
 
 // Range after prepending symbol a then symbol b (both ACGT, given as 2-bit codes).
@@ -97,15 +98,95 @@ __device__ __forceinline__ Range constrain2(const uint4 *__restrict__ pair_block
     const uint64_t kh = super[(h >> kPairSuperShift) * 16u + p];
     const int nl = min(max(int(uint32_t(l) & 127u) - int(sub * 16u), 0), 16);
     const int nh = min(max(int(uint32_t(h) & 127u) - int(sub * 16u), 0), 16);
-    const bool owner = (sub == (p >> 1));
+    const uint32_t owner = (sub == (p >> 1)) ? ~0u : 0u;
     // count (<= 128 summed) in the low byte, the owner's 24-bit field above it: no carries
-    const uint32_t tl = group_sum(pair_chunk_count(cl, a2, b2, nl) | (owner ? pair_chunk_field(cl, p) << 8 : 0u));
-    const uint32_t th = group_sum(pair_chunk_count(ch, a2, b2, nh) | (owner ? pair_chunk_field(ch, p) << 8 : 0u));
+    const uint32_t tl = group_sum(pair_chunk_count(cl, a2, b2, nl) | ((pair_chunk_field(cl, p) << 8) & owner));
+    const uint32_t th = group_sum(pair_chunk_count(ch, a2, b2, nh) | ((pair_chunk_field(ch, p) << 8) & owner));
     Range r;
     r.l = kl + (tl >> 8) + (tl & 0xFFu);
     r.h = kh + (th >> 8) + (th & 0xFFu);
     return r;
 }
+
+// ---- the same two steps for 4-lane groups: a lane owns two adjacent chunks (32 bytes) of the
+// block, a wave carries 16 queries, and the group sum is two quad_perm steps --------------------
+__device__ __forceinline__ uint32_t quad_sum(uint32_t x) {
+    x = dpp_add<0xB1>(x);  // lane ^ 1
+    x = dpp_add<0x4E>(x);  // lane ^ 2
+    return x;
+}
+
+__device__ __forceinline__ uint32_t low_bits(int n) { return n >= 32 ? ~0u : ((1u << n) - 1u); }  // n in 0..32
+
+__device__ __forceinline__ Range constrain_quad(const uint4 *__restrict__ blocks, uint32_t s, uint64_t l, uint64_t h,
+                                                uint32_t sub) {
+    const uint4 *bl = blocks + (l >> 8) * 8 + 2u * sub;
+    const uint4 *bh = blocks + (h >> 8) * 8 + 2u * sub;
+    const uint4 l0 = bl[0], l1 = bl[1], h0 = bh[0], h1 = bh[1];
+    const uint32_t x0 = (s & 1u) ? 0u : ~0u, x1 = (s & 2u) ? 0u : ~0u, x2 = (s & 4u) ? 0u : ~0u;
+    const int rl = int(uint32_t(l) & 255u) - int(sub * 64u), rh = int(uint32_t(h) & 255u) - int(sub * 64u);
+    const uint32_t cnt_l = __popc((l0.x ^ x0) & (l0.y ^ x1) & (l0.z ^ x2) & low_bits(min(max(rl, 0), 32))) +
+                           __popc((l1.x ^ x0) & (l1.y ^ x1) & (l1.z ^ x2) & low_bits(min(max(rl - 32, 0), 32)));
+    const uint32_t cnt_h = __popc((h0.x ^ x0) & (h0.y ^ x1) & (h0.z ^ x2) & low_bits(min(max(rh, 0), 32))) +
+                           __popc((h1.x ^ x0) & (h1.y ^ x1) & (h1.z ^ x2) & low_bits(min(max(rh - 32, 0), 32)));
+    // header: low word of A[s] in chunk s = lane s>>1, its chunk s&1; high byte in chunk 6/7 = lane 3
+    const uint32_t owns_lo = (sub == (s >> 1)) ? ~0u : 0u, owns_hi = (sub == 3u) ? 0xFFu : 0u;
+    const uint32_t sh = (s & 3u) * 8u;
+    const uint32_t lo_l = ((s & 1u) ? l1.w : l0.w) & owns_lo, lo_h = ((s & 1u) ? h1.w : h0.w) & owns_lo;
+    const uint32_t hi_l = (((s >> 2) ? l1.w : l0.w) >> sh) & owns_hi, hi_h = (((s >> 2) ? h1.w : h0.w) >> sh) & owns_hi;
+    const uint32_t packed = quad_sum(cnt_l | (hi_l << 8) | (cnt_h << 16) | (hi_h << 24));  // counts sum to <= 255
+    const uint32_t base_l = quad_sum(lo_l), base_h = quad_sum(lo_h);
+    Range r;
+    r.l = ((uint64_t((packed >> 8) & 0xFFu) << 32) | base_l) + (packed & 0xFFu);
+    r.h = ((uint64_t(packed >> 24) << 32) | base_h) + ((packed >> 16) & 0xFFu);
+    return r;
+}
+
+__device__ __forceinline__ Range constrain2_quad(const uint4 *__restrict__ pair_blocks, const uint64_t *__restrict__ super,
+                                                 uint32_t a2, uint32_t b2, uint64_t l, uint64_t h, uint32_t sub) {
+    const uint4 *bl = pair_blocks + (l >> kPairShift) * 8 + 2u * sub;
+    const uint4 *bh = pair_blocks + (h >> kPairShift) * 8 + 2u * sub;
+    const uint4 l0 = bl[0], l1 = bl[1], h0 = bh[0], h1 = bh[1];
+    const uint32_t p = a2 * 4u + b2;
+    const uint64_t kl = super[(l >> kPairSuperShift) * 16u + p];
+    const uint64_t kh = super[(h >> kPairSuperShift) * 16u + p];
+    const int rl = int(uint32_t(l) & 127u) - int(sub * 32u), rh = int(uint32_t(h) & 127u) - int(sub * 32u);
+    const uint32_t cnt_l = pair_chunk_count(l0, a2, b2, min(max(rl, 0), 16)) + pair_chunk_count(l1, a2, b2, min(max(rl - 16, 0), 16));
+    const uint32_t cnt_h = pair_chunk_count(h0, a2, b2, min(max(rh, 0), 16)) + pair_chunk_count(h1, a2, b2, min(max(rh - 16, 0), 16));
+    // pair p lives in chunk p>>1 = lane p>>2, its chunk (p>>1)&1
+    const uint32_t owner = (sub == (p >> 2)) ? ~0u : 0u;
+    const bool second = ((p >> 1) & 1u) != 0;
+    const uint32_t tl = quad_sum(cnt_l | ((pair_chunk_field(second ? l1 : l0, p) << 8) & owner));
+    const uint32_t th = quad_sum(cnt_h | ((pair_chunk_field(second ? h1 : h0, p) << 8) & owner));
+    Range r;
+    r.l = kl + (tl >> 8) + (tl & 0xFFu);
+    r.h = kh + (th >> 8) + (th & 0xFFu);
+    return r;
+}
+
+// Uniform access to the two group shapes
+template <int kLanes>
+struct GroupOps;
+template <>
+struct GroupOps<8> {
+    static __device__ __forceinline__ Range step(const uint4 *b, uint32_t s, uint64_t l, uint64_t h, uint32_t sub) {
+        return constrain(b, s, l, h, sub);
+    }
+    static __device__ __forceinline__ Range step2(const uint4 *pb, const uint64_t *sup, uint32_t a2, uint32_t b2, uint64_t l,
+                                                  uint64_t h, uint32_t sub) {
+        return constrain2(pb, sup, a2, b2, l, h, sub);
+    }
+};
+template <>
+struct GroupOps<4> {
+    static __device__ __forceinline__ Range step(const uint4 *b, uint32_t s, uint64_t l, uint64_t h, uint32_t sub) {
+        return constrain_quad(b, s, l, h, sub);
+    }
+    static __device__ __forceinline__ Range step2(const uint4 *pb, const uint64_t *sup, uint32_t a2, uint32_t b2, uint64_t l,
+                                                  uint64_t h, uint32_t sub) {
+        return constrain2_quad(pb, sup, a2, b2, l, h, sub);
+    }
+};
 
 }  // namespace
 }  // namespace msbwt
