@@ -231,7 +231,7 @@ def main():
                             int(cfg["genome"] * args.scale), cfg["err"] * 100, total, nq,
                             "random" if kind == "random" else "read-derived (ALL windows of ALL reads, prepared in-kernel)" if fused else "read-derived", k),
             "k": k, "queries_per_gpu": nq, "bwt_symbols": total, "index_bytes": bwt.device_bytes(),
-            "table_depth": bwt.get_table_depth(),
+            "table_depth": bwt.get_table_depth(), "pair_index": bwt.get_pair_index(),
             "parallelism": "query-sharded x%d, index replicated, RCCL all_gather of counts" % world if world > 1 else "1 GPU",
         },
     }
@@ -272,6 +272,7 @@ def main():
         try:  # PMC counters are collected in separate rocprofv3 passes; their summary is committed
             for ent in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["entries"]:
                 if ent["workload"] == args.workload and ent["k"] == k and ent["table_depth"] == bwt.get_table_depth() \
+                        and ent.get("pair_index", False) == bwt.get_pair_index() \
                         and kind == cfg["queries"] and args.scale == 1.0 and not fused:
                     traffic = ent["traffic_bytes_per_query"] * nq
                     traffic_src = ent["source"]
