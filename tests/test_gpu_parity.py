@@ -453,3 +453,64 @@ def test_pair_index_on_random_streams_and_superblock_borders():
         b.set_pair_index(0)
         qs = random_kmers(5, nq, 8)
         assert np.array_equal(b.count_kmers(qs), o.count_kmers(qs))
+
+
+def test_too_large_index_is_rejected():
+    """A 9-digit run encodes 32^8 = 2^40 symbols: beyond the 40-bit block counters."""
+    rle = np.array([1] * 8 + [1 | (1 << 3)], dtype=np.uint8)      # A-run of exactly 2^40
+    b = RleBWT()
+    with pytest.raises(msbwt.MsbwtError) as e:
+        b.load_vector(rle)
+    assert e.value.code == msbwt._lib.ERR_TOO_LARGE
+    ok = np.array([1] * 7 + [1 | (31 << 3)], dtype=np.uint8)      # 31 * 32^7 < 2^40: fine
+    b.load_vector(ok)
+    assert b.get_total_size() == 31 * 32 ** 7
+    assert b.count_kmer([1, 1, 1]) == 31 * 32 ** 7 - 2
+    assert b.count_kmer([2]) == 0
+
+
+def test_concurrent_queries_from_host_threads():
+    """Query entry points take `&self` in the reference: several host threads may share one
+    loaded handle."""
+    import threading
+    reads, rle = _real_bwt(23, 150, 60)
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    qs = [np.concatenate([np.array([orc.convert_stoi(r[2:2 + 21]) for r in reads], dtype=np.uint8), random_kmers(t, 2000, 21)])
+          for t in range(4)]
+    exp = [o.count_kmers(q) for q in qs]
+    got = [None] * 4
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                got[i] = b.count_kmers(qs[i])
+                assert b.count_kmer(qs[i][0]) == int(exp[i][0])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for i in range(4):
+        assert np.array_equal(got[i], exp[i])
+
+
+def test_introspection():
+    rle = random_stream(2, 30000, "short")
+    b = gpu_bwt(rle)
+    blocks = b.get_total_size() // 256 + 1
+    b.set_pair_index(0)
+    b.set_table_depth(0)
+    assert b.device_bytes() == blocks * 128 and b.get_table_depth() == 0 and not b.get_pair_index()
+    b.set_table_depth(4)
+    assert b.device_bytes() == blocks * 128 + 16 * 4 ** 4
+    b.set_pair_index(1)
+    assert b.get_pair_index() and b.device_bytes() > blocks * 128 * 3
+    assert b.device_ordinal() == 0
+    assert "gfx950" in msbwt.version()
