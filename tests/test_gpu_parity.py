@@ -462,11 +462,12 @@ def test_too_large_index_is_rejected():
     with pytest.raises(msbwt.MsbwtError) as e:
         b.load_vector(rle)
     assert e.value.code == msbwt._lib.ERR_TOO_LARGE
-    ok = np.array([1] * 7 + [1 | (31 << 3)], dtype=np.uint8)      # 31 * 32^7 < 2^40: fine
-    b.load_vector(ok)
-    assert b.get_total_size() == 31 * 32 ** 7
-    assert b.count_kmer([1, 1, 1]) == 31 * 32 ** 7 - 2
-    assert b.count_kmer([2]) == 0
+    ok = np.array([1] * 6 + [1 | (1 << 3), 2 | (3 << 3)], dtype=np.uint8)  # 32^6 = 2^30 A's, then CCC
+    b.load_vector(ok)                                              # one sub-run of 2^30 symbols
+    assert b.get_total_size() == 2 ** 30 + 3
+    assert b.count_kmer([1, 1, 1]) == 2 ** 30 - 2
+    assert b.count_kmer([2]) == 3
+    assert b.constrain_range(1, BWTRange(5, 2 ** 30 + 1)) == BWTRange(5, 2 ** 30)
 
 
 def test_concurrent_queries_from_host_threads():
