@@ -464,10 +464,14 @@ def test_too_large_index_is_rejected():
     assert e.value.code == msbwt._lib.ERR_TOO_LARGE
     ok = np.array([1] * 6 + [1 | (1 << 3), 2 | (3 << 3)], dtype=np.uint8)  # 32^6 = 2^30 A's, then CCC
     b.load_vector(ok)                                              # one sub-run of 2^30 symbols
-    assert b.get_total_size() == 2 ** 30 + 3
-    assert b.count_kmer([1, 1, 1]) == 2 ** 30 - 2
-    assert b.count_kmer([2]) == 3
-    assert b.constrain_range(1, BWTRange(5, 2 ** 30 + 1)) == BWTRange(5, 2 ** 30)
+    o = orc.OracleRleBWT()
+    o.load_vector(ok)
+    assert b.get_total_size() == o.get_total_size() == 2 ** 30 + 3
+    for kmer in ([1, 1, 1], [2], [1, 2], [2, 1], [2, 2, 2], [1, 2, 2, 2]):
+        assert b.count_kmer(kmer) == o.count_kmer(kmer), kmer
+    assert b.count_kmer([1, 1, 1]) == 2 ** 30
+    got = b.constrain_range(1, BWTRange(5, 2 ** 30 + 1))
+    assert (got.l, got.h) == o.constrain_range(1, 5, 2 ** 30 + 1) == (5, 2 ** 30)
 
 
 def test_concurrent_queries_from_host_threads():
