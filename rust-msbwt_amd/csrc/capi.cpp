@@ -423,6 +423,17 @@ int msbwt_rle_constrain_ranges_device(const msbwt_rle *ch, const void *d_syms, c
     return MSBWT_OK;
 }
 
+// Enqueues the fused read -> k-mer count kernel; the caller holds h->mu and has made the
+// handle's device current.
+static int launch_read_kmers_locked(msbwt_rle *h, const void *d_reads, size_t read_len, size_t n_reads, size_t k,
+                                    int ascii, void *d_out_fwd, void *d_out_rc, hipStream_t stream) {
+    return timed_launch(h, stream, [&] {
+        return launch_count_read_kmers(view_of(h), static_cast<const uint8_t *>(d_reads), uint32_t(read_len), n_reads,
+                                       uint32_t(k), ascii != 0, static_cast<uint64_t *>(d_out_fwd),
+                                       static_cast<uint64_t *>(d_out_rc), h->d_flags, stream);
+    });
+}
+
 int msbwt_rle_count_read_kmers_device(const msbwt_rle *ch, const void *d_reads, size_t read_len, size_t n_reads,
                                       size_t k, int ascii, void *d_out_fwd, void *d_out_rc, void *hip_stream) {
     msbwt_rle *h = const_cast<msbwt_rle *>(ch);
@@ -433,22 +444,20 @@ int msbwt_rle_count_read_kmers_device(const msbwt_rle *ch, const void *d_reads, 
         return fail(h, MSBWT_ERR_INVALID_ARG, "count_read_kmers needs 1 <= k <= min(32, read_len) and an output");
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
-    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    return timed_launch(h, stream, [&] {
-        return launch_count_read_kmers(view_of(h), static_cast<const uint8_t *>(d_reads), uint32_t(read_len), n_reads,
-                                       uint32_t(k), ascii != 0, static_cast<uint64_t *>(d_out_fwd),
-                                       static_cast<uint64_t *>(d_out_rc), h->d_flags, stream);
-    });
+    return launch_read_kmers_locked(h, d_reads, read_len, n_reads, k, ascii, d_out_fwd, d_out_rc,
+                                    static_cast<hipStream_t>(hip_stream));
 }
 
 int msbwt_rle_count_read_kmers(const msbwt_rle *ch, const uint8_t *reads, size_t read_len, size_t n_reads, size_t k,
                                int ascii, uint64_t *out_fwd, uint64_t *out_rc) {
     msbwt_rle *h = const_cast<msbwt_rle *>(ch);
     if (!h) return MSBWT_ERR_INVALID_ARG;
-    if (k < 1 || k > 32 || k > read_len || (!out_fwd && !out_rc) || (n_reads && !reads)) {
-        std::lock_guard<std::mutex> lock(h->mu);
+    std::lock_guard<std::mutex> lock(h->mu);  // held throughout: the staging buffer is per handle
+    if (k < 1 || k > 32 || k > read_len || read_len > 0xFFFFFFFFull || (!out_fwd && !out_rc) || (n_reads && !reads))
         return fail(h, MSBWT_ERR_INVALID_ARG, "count_read_kmers needs 1 <= k <= min(32, read_len) and an output");
-    }
+    if (!h->loaded) return fail(h, MSBWT_ERR_NOT_LOADED, "no BWT loaded");
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
     const size_t windows = read_len - k + 1;
     // bounded staging: batches of reads whose windows number at most ~4 Mi
     const size_t batch = std::max<size_t>(1, std::min<size_t>(n_reads, (size_t(1) << 22) / windows + 1));
@@ -456,25 +465,13 @@ int msbwt_rle_count_read_kmers(const msbwt_rle *ch, const uint8_t *reads, size_t
     for (size_t done = 0; done < n_reads; done += batch) {
         const size_t m = std::min(batch, n_reads - done);
         const size_t read_bytes = (m * read_len + 15) / 16 * 16, cnt_bytes = m * windows * sizeof(uint64_t);
-        uint8_t *d_r;
-        uint64_t *d_f, *d_c;
-        {
-            std::lock_guard<std::mutex> lock(h->mu);
-            if (!h->loaded) return fail(h, MSBWT_ERR_NOT_LOADED, "no BWT loaded");
-            DeviceScope scope(h->device);
-            if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
-            int rc = ensure_stage(h, read_bytes + 2 * cnt_bytes);
-            if (rc) return rc;
-            d_r = static_cast<uint8_t *>(h->d_stage);
-            d_f = reinterpret_cast<uint64_t *>(d_r + read_bytes);
-            d_c = d_f + m * windows;
-            HIP_TRY(h, hipMemcpyAsync(d_r, reads + done * read_len, m * read_len, hipMemcpyHostToDevice, h->stream));
-        }
-        int rc = msbwt_rle_count_read_kmers_device(h, d_r, read_len, m, k, ascii, out_fwd ? d_f : nullptr,
-                                                   out_rc ? d_c : nullptr, h->stream);
+        int rc = ensure_stage(h, read_bytes + 2 * cnt_bytes);
         if (rc) return rc;
-        std::lock_guard<std::mutex> lock(h->mu);
-        DeviceScope scope(h->device);
+        uint8_t *d_r = static_cast<uint8_t *>(h->d_stage);
+        uint64_t *d_f = reinterpret_cast<uint64_t *>(d_r + read_bytes), *d_c = d_f + m * windows;
+        HIP_TRY(h, hipMemcpyAsync(d_r, reads + done * read_len, m * read_len, hipMemcpyHostToDevice, h->stream));
+        rc = launch_read_kmers_locked(h, d_r, read_len, m, k, ascii, out_fwd ? d_f : nullptr, out_rc ? d_c : nullptr, h->stream);
+        if (rc) return rc;
         if (out_fwd) HIP_TRY(h, hipMemcpyAsync(out_fwd + done * windows, d_f, cnt_bytes, hipMemcpyDeviceToHost, h->stream));
         if (out_rc) HIP_TRY(h, hipMemcpyAsync(out_rc + done * windows, d_c, cnt_bytes, hipMemcpyDeviceToHost, h->stream));
         uint32_t flags = 0;
@@ -482,7 +479,6 @@ int msbwt_rle_count_read_kmers(const msbwt_rle *ch, const uint8_t *reads, size_t
         if (rc) return rc;
         all_flags |= flags;
     }
-    std::lock_guard<std::mutex> lock(h->mu);
     return flags_to_code(h, all_flags);
 }
 

@@ -519,3 +519,19 @@ def test_introspection():
     assert b.get_pair_index() and b.device_bytes() > blocks * 128 * 3
     assert b.device_ordinal() == 0
     assert "gfx950" in msbwt.version()
+
+
+def test_sharded_counter_single_gpu_worker():
+    """ShardedCounter with its default (GPU) worker, world size 1: the per-rank path of the
+    multi-GPU bench."""
+    torch = pytest.importorskip("torch")
+    from rust_msbwt_amd.sharded import ShardedCounter, as_u64
+    reads, rle = _real_bwt(29, 100, 50)
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    q = np.concatenate([np.array([orc.convert_stoi(r[1:1 + 25]) for r in reads], dtype=np.uint8), random_kmers(5, 999, 25)])
+    counter = ShardedCounter(bwt=b)
+    got = counter.count_kmers(torch.from_numpy(q).to("cuda:0"))
+    torch.cuda.synchronize()
+    assert np.array_equal(as_u64(got), o.count_kmers(q))
