@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256, kLanes == 4 ? 6 : 8) void k_count_kmers_tiled(
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t sub = lane & (kLanes - 1);
     const uint32_t group_first_lane = lane & ~uint32_t(kLanes - 1);
+    constexpr uint64_t kGroupLeaders = kLanes == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;
     WaveScratch &ws = scratch[threadIdx.x >> 6];
     const uint8_t *stage_bytes = reinterpret_cast<const uint8_t *>(ws.stage);
 
@@ -194,9 +195,8 @@ __global__ __launch_bounds__(256, kLanes == 4 ? 6 : 8) void k_count_kmers_tiled(
                     hi |= uint64_t(s & 7u) << (pos - 64u);
                 }
                 if (t < depth) {  // table index: A C G T -> 0..3, step t at bits [2t, 2t+2)
-                    const uint32_t two = (s == 5u) ? 3u : (s - 1u);
-                    acgt &= (s == 5u || (s >= 1u && s <= 3u)) ? 1u : 0u;
-                    tidx |= (two & 3u) << (2u * t);
+                    acgt &= acgt_bit(s);
+                    tidx |= (acgt_code(s) & 3u) << (2u * t);
                 }
             }
             if (bad) {
@@ -241,25 +241,30 @@ __global__ __launch_bounds__(256, kLanes == 4 ? 6 : 8) void k_count_kmers_tiled(
             bool have = false;
             uint32_t slot = 0;
             for (;;) {
-                // hand the next items to the idle groups, in group order
-                const uint64_t idle = __ballot(!have && sub == 0u);  // one bit per idle group (its first lane)
-                const uint32_t idle_before = uint32_t(__popcll(idle & ((1ull << group_first_lane) - 1ull)));
-                if (!have && next + idle_before < nwork) {
-                    const WorkItem *it = &ws.work[next + idle_before];
-                    const uint4 a = *reinterpret_cast<const uint4 *>(it);
-                    const uint4 b = *(reinterpret_cast<const uint4 *>(it) + 1);
-                    l = (uint64_t(a.y) << 32) | a.x;
-                    h = (uint64_t(a.w) << 32) | a.z;
-                    w0 = b.x; w1 = b.y; w2 = b.z;
-                    rem = b.w & 0xFFu;
-                    slot = b.w >> 8;
-                    have = true;
+                // hand the next items to the idle groups, in group order -- only when there is
+                // an idle group and work left (wave-uniform test on the busy mask)
+                uint64_t busy = __ballot(have);
+                if (busy != ~0ull && next < nwork) {
+                    const uint64_t idle = ~busy & kGroupLeaders;  // one bit per idle group (its first lane)
+                    const uint32_t idle_before = uint32_t(__popcll(idle & ((1ull << group_first_lane) - 1ull)));
+                    if (!have && next + idle_before < nwork) {
+                        const WorkItem *it = &ws.work[next + idle_before];
+                        const uint4 a = *reinterpret_cast<const uint4 *>(it);
+                        const uint4 b = *(reinterpret_cast<const uint4 *>(it) + 1);
+                        l = (uint64_t(a.y) << 32) | a.x;
+                        h = (uint64_t(a.w) << 32) | a.z;
+                        w0 = b.x; w1 = b.y; w2 = b.z;
+                        rem = b.w & 0xFFu;
+                        slot = b.w >> 8;
+                        have = true;
+                    }
+                    next = min(nwork, next + uint32_t(__popcll(idle)));
+                    busy = __ballot(have);
                 }
-                next = min(nwork, next + uint32_t(__popcll(idle)));
-                if (!__any(have)) break;
+                if (busy == 0ull) break;
                 if (have) {
                     const uint32_t s1 = w0 & 7u, s2 = (w0 >> 3) & 7u;
-                    if (kPair && rem >= 2u && is_acgt(s1) && is_acgt(s2)) {
+                    if (kPair && rem >= 2u && (acgt_bit(s1) & acgt_bit(s2)) != 0u) {
                         // two symbols for one line fetch per bound
                         const Range r = GroupOps<kLanes>::step2(pair_blocks, pair_super, acgt_code(s1), acgt_code(s2), l, h, sub);
                         l = r.l;

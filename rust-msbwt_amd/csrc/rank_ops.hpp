@@ -70,8 +70,10 @@ __device__ __forceinline__ Range constrain(const uint4 *__restrict__ blocks, uin
 constexpr int kPairShift = 7;         // 128 positions per pair block
 constexpr int kPairSuperShift = 24;   // 2^24 positions per superblock
 
-__device__ __forceinline__ uint32_t acgt_code(uint32_t s) { return s == 5u ? 3u : s - 1u; }  // s in {1,2,3,5}
-__device__ __forceinline__ bool is_acgt(uint32_t s) { return s == 5u || (s >= 1u && s <= 3u); }
+// branch-free: codes 1,2,3,5 are bits 1,2,3,5 of 0x2E; A C G T -> 0 1 2 3 is s - 1 - (s >> 2)
+__device__ __forceinline__ uint32_t acgt_code(uint32_t s) { return s - 1u - (s >> 2); }  // s in {1,2,3,5}
+__device__ __forceinline__ uint32_t acgt_bit(uint32_t s) { return (0x2Eu >> (s & 7u)) & 1u; }
+__device__ __forceinline__ bool is_acgt(uint32_t s) { return acgt_bit(s) != 0u; }
 
 // matches of pair (a2, b2) among the first n (0..16) positions of one pair chunk
 __device__ __forceinline__ uint32_t pair_chunk_count(const uint4 c, uint32_t a2, uint32_t b2, int n) {
@@ -94,8 +96,9 @@ __device__ __forceinline__ Range constrain2(const uint4 *__restrict__ pair_block
     const uint4 cl = pair_blocks[(l >> kPairShift) * kGroup + sub];
     const uint4 ch = pair_blocks[(h >> kPairShift) * kGroup + sub];
     const uint32_t p = a2 * 4u + b2;
-    const uint64_t kl = super[(l >> kPairSuperShift) * 16u + p];
-    const uint64_t kh = super[(h >> kPairSuperShift) * 16u + p];
+    // superblock index fits 16 bits (T < 2^40): one alignbit instead of a 64-bit shift
+    const uint64_t kl = super[__builtin_amdgcn_alignbit(uint32_t(l >> 32), uint32_t(l), kPairSuperShift) * 16u + p];
+    const uint64_t kh = super[__builtin_amdgcn_alignbit(uint32_t(h >> 32), uint32_t(h), kPairSuperShift) * 16u + p];
     const int nl = min(max(int(uint32_t(l) & 127u) - int(sub * 16u), 0), 16);
     const int nh = min(max(int(uint32_t(h) & 127u) - int(sub * 16u), 0), 16);
     const uint32_t owner = (sub == (p >> 1)) ? ~0u : 0u;
@@ -103,8 +106,8 @@ __device__ __forceinline__ Range constrain2(const uint4 *__restrict__ pair_block
     const uint32_t tl = group_sum(pair_chunk_count(cl, a2, b2, nl) | ((pair_chunk_field(cl, p) << 8) & owner));
     const uint32_t th = group_sum(pair_chunk_count(ch, a2, b2, nh) | ((pair_chunk_field(ch, p) << 8) & owner));
     Range r;
-    r.l = kl + (tl >> 8) + (tl & 0xFFu);
-    r.h = kh + (th >> 8) + (th & 0xFFu);
+    r.l = kl + ((tl >> 8) + (tl & 0xFFu));
+    r.h = kh + ((th >> 8) + (th & 0xFFu));
     return r;
 }
 
