@@ -1,10 +1,12 @@
 // gfx950 (MI355X, CDNA4) kernels for batched FM-index backward search over plane blocks.
 // Integer / bit work bound by random 128-byte fetches: no MFMA anywhere.
 //
-// Rank primitive: an 8-lane group owns one query.  For a rank the group's 8 lanes load the
-// 8 x 16-byte chunks of one 128-byte block with a single coalesced global_load_dwordx4, each
-// lane popcounts its 32 symbols, and the group sums with three DPP steps (quad_perm xor 1,
-// xor 2, row_half_mirror) -- no LDS traffic, no barriers.  Block layout: plane_index.hpp.
+// Rank primitives (rank_ops.hpp): an 8-lane group owns one query.  In the search loop lanes
+// 0-3 handle bound l and lanes 4-7 bound h; a lane loads two 16-byte chunks of its bound's
+// 128-byte block (two coalesced global_load_dwordx4 per step), popcounts its symbols, and the
+// quad sums with two DPP steps plus one cross-quad exchange -- no LDS traffic, no barriers.
+// With pair blocks a step consumes two k-mer symbols.  Block layouts: plane_index.hpp,
+// rank_ops.hpp.
 //
 // count_kmers (k <= 32) works on tiles of 64 queries per wave, in two phases:
 //   1. lane-per-query setup: the tile's query bytes are staged through LDS with coalesced

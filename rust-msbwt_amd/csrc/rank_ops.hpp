@@ -167,17 +167,75 @@ __device__ __forceinline__ Range constrain2_quad(const uint4 *__restrict__ pair_
     return r;
 }
 
+// ---- 8-lane groups, one bound per quad ----------------------------------------------------------
+// Lanes 0-3 of the group work on bound l, lanes 4-7 on bound h; lane q of a quad holds chunks q
+// and q+4 of its bound's block (one load instruction fetches the first halves of both lines,
+// the other the second halves).  Each lane computes masks, header field and base for ONE bound
+// only; a two-step quad sum and one cross-quad exchange finish the step.  Fewer instructions
+// per query step than handling both bounds in every lane (the kernels are issue-bound).
+__device__ __forceinline__ uint64_t other_quad(uint64_t x) {  // value held by the group's other quad
+    const uint32_t lo = uint32_t(__builtin_amdgcn_update_dpp(0, int(uint32_t(x)), 0x141, 0xF, 0xF, true));
+    const uint32_t hi = uint32_t(__builtin_amdgcn_update_dpp(0, int(uint32_t(x >> 32)), 0x141, 0xF, 0xF, true));
+    return (uint64_t(hi) << 32) | lo;
+}
+
+__device__ __forceinline__ Range constrain_split(const uint4 *__restrict__ blocks, uint32_t s, uint64_t l, uint64_t h,
+                                                 uint32_t sub) {
+    const bool upper = (sub & 4u) != 0;
+    const uint32_t q = sub & 3u;
+    const uint64_t pos = upper ? h : l;
+    const uint4 *b = blocks + (pos >> 8) * 8 + q;
+    const uint4 c0 = b[0], c1 = b[4];
+    const uint32_t x0 = (s & 1u) ? 0u : ~0u, x1 = (s & 2u) ? 0u : ~0u, x2 = (s & 4u) ? 0u : ~0u;
+    const int r = int(uint32_t(pos) & 255u) - int(q * 32u);  // chunk q covers [32q, 32q+32), chunk q+4 is 128 further
+    const uint32_t cnt = __popc((c0.x ^ x0) & (c0.y ^ x1) & (c0.z ^ x2) & low_bits(min(max(r, 0), 32))) +
+                         __popc((c1.x ^ x0) & (c1.y ^ x1) & (c1.z ^ x2) & low_bits(min(max(r - 128, 0), 32)));
+    // header: low word of A[s] in chunk s = lane s&3, its chunk s>>2; high byte in chunk 6/7 = lane 2/3, second chunk
+    const uint32_t lo = ((s >> 2) ? c1.w : c0.w) & ((q == (s & 3u)) ? ~0u : 0u);
+    const uint32_t hi = (c1.w >> ((s & 3u) * 8u)) & ((q == 2u + (s >> 2)) ? 0xFFu : 0u);
+    const uint32_t packed = quad_sum(cnt | (hi << 8));  // count <= 255, one lane owns hi
+    const uint32_t base = quad_sum(lo);
+    const uint64_t mine = ((uint64_t(packed >> 8) << 32) | base) + (packed & 0xFFu);
+    const uint64_t theirs = other_quad(mine);
+    Range out;
+    out.l = upper ? theirs : mine;
+    out.h = upper ? mine : theirs;
+    return out;
+}
+
+__device__ __forceinline__ Range constrain2_split(const uint4 *__restrict__ pair_blocks, const uint64_t *__restrict__ super,
+                                                  uint32_t a2, uint32_t b2, uint64_t l, uint64_t h, uint32_t sub) {
+    const bool upper = (sub & 4u) != 0;
+    const uint32_t q = sub & 3u;
+    const uint64_t pos = upper ? h : l;
+    const uint4 *b = pair_blocks + (pos >> kPairShift) * 8 + q;
+    const uint4 c0 = b[0], c1 = b[4];
+    const uint32_t p = a2 * 4u + b2;
+    const uint64_t k = super[__builtin_amdgcn_alignbit(uint32_t(pos >> 32), uint32_t(pos), kPairSuperShift) * 16u + p];
+    const int r = int(uint32_t(pos) & 127u) - int(q * 16u);  // chunk q covers [16q, 16q+16), chunk q+4 is 64 further
+    const uint32_t cnt = pair_chunk_count(c0, a2, b2, min(max(r, 0), 16)) + pair_chunk_count(c1, a2, b2, min(max(r - 64, 0), 16));
+    // pair p lives in chunk p>>1 = lane (p>>1)&3, its chunk p>>3
+    const uint32_t owner = (q == ((p >> 1) & 3u)) ? ~0u : 0u;
+    const uint32_t t = quad_sum(cnt | ((pair_chunk_field((p >> 3) ? c1 : c0, p) << 8) & owner));
+    const uint64_t mine = k + ((t >> 8) + (t & 0xFFu));
+    const uint64_t theirs = other_quad(mine);
+    Range out;
+    out.l = upper ? theirs : mine;
+    out.h = upper ? mine : theirs;
+    return out;
+}
+
 // Uniform access to the two group shapes
 template <int kLanes>
 struct GroupOps;
 template <>
 struct GroupOps<8> {
     static __device__ __forceinline__ Range step(const uint4 *b, uint32_t s, uint64_t l, uint64_t h, uint32_t sub) {
-        return constrain(b, s, l, h, sub);
+        return constrain_split(b, s, l, h, sub);
     }
     static __device__ __forceinline__ Range step2(const uint4 *pb, const uint64_t *sup, uint32_t a2, uint32_t b2, uint64_t l,
                                                   uint64_t h, uint32_t sub) {
-        return constrain2(pb, sup, a2, b2, l, h, sub);
+        return constrain2_split(pb, sup, a2, b2, l, h, sub);
     }
 };
 template <>
