@@ -132,23 +132,50 @@ __global__ __launch_bounds__(256, kLanes == 4 ? 6 : 8) void k_count_kmers_tiled(
     const uint64_t nwaves = uint64_t(gridDim.x) * kWavesPerBlock;
     const bool use_table = table != nullptr && depth > 0 && k >= depth;
 
+    // Piece `piece` (16 bytes) of a tile's query bytes; the batch's ragged end is read bytewise so
+    // that nothing past the caller's buffer is touched.
+    auto load_piece = [&](uint64_t tile_q0, uint32_t nbytes, uint32_t piece) -> uint4 {
+        const uint8_t *src = kmers + tile_q0 * k;
+        if (piece * 16u + 16u <= nbytes) return *reinterpret_cast<const uint4 *>(src + piece * 16u);
+        uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+        for (uint32_t b = piece * 16u; b < nbytes; ++b) {
+            const uint32_t v = uint32_t(src[b]) << ((b & 3u) * 8u), word = (b & 15u) >> 2;
+            if (word == 0u) w0 |= v; else if (word == 1u) w1 |= v; else if (word == 2u) w2 |= v; else w3 |= v;
+        }
+        return make_uint4(w0, w1, w2, w3);
+    };
+    // A tile is at most 64 x 32 = 2048 bytes = 128 pieces: two per lane, both loads in flight at
+    // once.  In the lean variant (short searches, e.g. C2, where setup dominates) the two loads
+    // of the NEXT tile are issued before the current tile is searched, hiding their latency; the
+    // pair variant has no registers to spare for that and loads at the top of the tile.
+    constexpr bool kPrefetch = !kPair;
+    uint4 stage0 = make_uint4(0, 0, 0, 0), stage1 = make_uint4(0, 0, 0, 0);
+    if (!kReads && kPrefetch && wave_id < ntiles) {
+        const uint64_t q0 = wave_id * kTile;
+        const uint32_t nbytes = uint32_t(min(uint64_t(kTile), n - q0)) * k;
+        if (lane * 16u < nbytes) stage0 = load_piece(q0, nbytes, lane);
+        if ((lane + 64u) * 16u < nbytes) stage1 = load_piece(q0, nbytes, lane + 64u);
+    }
+
     for (uint64_t tile = wave_id; tile < ntiles; tile += nwaves) {
         const uint64_t q0 = tile * kTile;
         const uint32_t in_tile = uint32_t(min(uint64_t(kTile), n - q0));
-        // ---- phase 1a: stage the tile's bytes (contiguous, 16-byte aligned) through LDS ----
+        // ---- phase 1a: the tile's bytes (contiguous, 16-byte aligned) go through LDS ----
         if (!kReads) {
-            const uint8_t *src = kmers + q0 * k;
-            const uint32_t nbytes = in_tile * k;
-            for (uint32_t piece = lane; piece * 16u < nbytes; piece += 64u) {
-                uint4 v;
-                if (piece * 16u + 16u <= nbytes) {
-                    v = *reinterpret_cast<const uint4 *>(src + piece * 16u);
-                } else {  // ragged end of the batch: never read past the caller's buffer
-                    uint32_t w[4] = {0u, 0u, 0u, 0u};
-                    for (uint32_t b = piece * 16u; b < nbytes; ++b) w[(b & 15u) >> 2] |= uint32_t(src[b]) << ((b & 3u) * 8u);
-                    v = make_uint4(w[0], w[1], w[2], w[3]);
-                }
-                ws.stage[piece] = v;
+            if (!kPrefetch) {
+                const uint32_t nbytes = in_tile * k;
+                stage0 = stage1 = make_uint4(0, 0, 0, 0);
+                if (lane * 16u < nbytes) stage0 = load_piece(q0, nbytes, lane);
+                if ((lane + 64u) * 16u < nbytes) stage1 = load_piece(q0, nbytes, lane + 64u);
+            }
+            ws.stage[lane] = stage0;
+            ws.stage[lane + 64u] = stage1;
+            const uint64_t next_tile = tile + nwaves;
+            if (kPrefetch && next_tile < ntiles) {
+                const uint64_t nq0 = next_tile * kTile;
+                const uint32_t nbytes = uint32_t(min(uint64_t(kTile), n - nq0)) * k;
+                if (lane * 16u < nbytes) stage0 = load_piece(nq0, nbytes, lane);
+                if ((lane + 64u) * 16u < nbytes) stage1 = load_piece(nq0, nbytes, lane + 64u);
             }
         }
         wave_lds_sync();
