@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--fused", action="store_true",
                     help="c2/c3: queries = every k-mer window of every read, prepared in-kernel from the reads "
                          "(msbwt_rle_count_read_kmers_device); BASELINE.json configs[2] is --workload c3 --fused")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL over xGMI, the real thing) or gloo (rehearsal of the N>1 path on fewer GPUs: "
+                         "counts are gathered through host memory, ranks may share a GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-sample", type=int, default=200_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
@@ -110,7 +113,10 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     msbwt = importlib.import_module("rust-msbwt_amd")
     import synth
@@ -181,7 +187,12 @@ def main():
         else:
             bwt.count_kmers_device(d_q.data_ptr(), k, nq, d_out.data_ptr(), stream)
         if world > 1:
-            dist.all_gather_into_tensor(d_all, d_out)  # the path's one exchange step (RCCL)
+            if args.dist_backend == "nccl":
+                dist.all_gather_into_tensor(d_all, d_out)  # the path's one exchange step (RCCL)
+            else:
+                host_all = torch.empty(nq * world, dtype=torch.int64)
+                dist.all_gather_into_tensor(host_all, d_out.cpu())
+                d_all.copy_(host_all)
 
     def fence():
         if world > 1:
@@ -202,7 +213,7 @@ def main():
     kernel_ms, launches = bwt.kernel_time_ms()
     bwt.device_status(stream)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -232,7 +243,8 @@ def main():
                             "random" if kind == "random" else "read-derived (ALL windows of ALL reads, prepared in-kernel)" if fused else "read-derived", k),
             "k": k, "queries_per_gpu": nq, "bwt_symbols": total, "index_bytes": bwt.device_bytes(),
             "table_depth": bwt.get_table_depth(), "pair_index": bwt.get_pair_index(),
-            "parallelism": "query-sharded x%d, index replicated, RCCL all_gather of counts" % world if world > 1 else "1 GPU",
+            "parallelism": ("query-sharded x%d, index replicated, %s all_gather of counts"
+                            % (world, "RCCL" if args.dist_backend == "nccl" else "gloo (rehearsal)")) if world > 1 else "1 GPU",
         },
     }
 
