@@ -377,9 +377,9 @@ int msbwt_rle_load_vector(msbwt_rle *h, const uint8_t *rle_bytes, size_t len) {
 int msbwt_rle_load_numpy_file(msbwt_rle *h, const char *utf8_path) {
     if (!h || !utf8_path) return MSBWT_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
-    std::vector<uint8_t> payload;
+    MappedPayload payload;  // mapped, not read: the upload reads it straight from the page cache
     std::string msg;
-    switch (read_npy_payload(utf8_path, &payload, &msg)) {
+    switch (map_npy_payload(utf8_path, &payload, &msg)) {
         case NpyStatus::kOk: break;
         case NpyStatus::kIo: return fail(h, MSBWT_ERR_IO, msg);
         case NpyStatus::kUnexpectedEof: return fail(h, MSBWT_ERR_UNEXPECTED_EOF, msg);

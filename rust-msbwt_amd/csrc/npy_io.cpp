@@ -1,6 +1,9 @@
 #include "npy_io.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <cctype>
 #include <cerrno>
@@ -148,7 +151,11 @@ bool valid_utf8(const std::string &s) {
 
 }  // namespace
 
-NpyStatus read_npy_payload(const std::string &path, std::vector<uint8_t> *payload, std::string *msg) {
+namespace {
+
+// Opens `path`, validates the header exactly as the reference does (rle_bwt.rs:84-136) and
+// reports where the payload starts and how long it is.  The FILE is left positioned there.
+NpyStatus open_npy(const std::string &path, File *file, uint64_t *data_offset, uint64_t *payload_len, std::string *msg) {
     struct stat st;
     if (::stat(path.c_str(), &st) != 0) {
         *msg = "cannot stat " + path + ": " + std::strerror(errno);
@@ -167,10 +174,10 @@ NpyStatus read_npy_payload(const std::string &path, std::vector<uint8_t> *payloa
     }
     // magic, version and dtype are deliberately not checked: the reference does not either
     const size_t header_len = size_t(fixed[8]) + 256 * size_t(fixed[9]);
-    const size_t data_offset = (10 + header_len + 15) / 16 * 16;
-    std::string header(data_offset - 10, '\0');
+    const size_t offset = (10 + header_len + 15) / 16 * 16;
+    std::string header(offset - 10, '\0');
     if (std::fread(&header[0], 1, header.size(), f.get()) != header.size()) {
-        *msg = "could not read bytes 10-" + std::to_string(data_offset) + " of header for file " + path;
+        *msg = "could not read bytes 10-" + std::to_string(offset) + " of header for file " + path;
         return NpyStatus::kUnexpectedEof;
     }
     if (!valid_utf8(header)) {
@@ -189,17 +196,54 @@ NpyStatus read_npy_payload(const std::string &path, std::vector<uint8_t> *payloa
         *msg = "error while parsing header string: " + header;
         return NpyStatus::kBadHeader;
     }
-    const uint64_t on_disk = file_size - data_offset;
+    const uint64_t on_disk = file_size - offset;
     if (expected != on_disk) {
         *msg = "header indicates shape of " + std::to_string(expected) + ", but remaining file size is " + std::to_string(on_disk);
         return NpyStatus::kUnexpectedEof;
     }
+    *data_offset = offset;
+    *payload_len = on_disk;
+    *file = std::move(f);
+    return NpyStatus::kOk;
+}
+
+}  // namespace
+
+NpyStatus read_npy_payload(const std::string &path, std::vector<uint8_t> *payload, std::string *msg) {
+    File f;
+    uint64_t offset = 0, on_disk = 0;
+    const NpyStatus st = open_npy(path, &f, &offset, &on_disk, msg);
+    if (st != NpyStatus::kOk) return st;
     payload->resize(on_disk);
     const size_t got = on_disk ? std::fread(payload->data(), 1, on_disk, f.get()) : 0;
     if (got != on_disk) {
         *msg = "only read " + std::to_string(got) + " of " + std::to_string(on_disk) + " bytes of BWT body for file " + path;
         return NpyStatus::kUnexpectedEof;
     }
+    return NpyStatus::kOk;
+}
+
+MappedPayload::~MappedPayload() {
+    if (base_) ::munmap(base_, map_len_);
+}
+
+NpyStatus map_npy_payload(const std::string &path, MappedPayload *out, std::string *msg) {
+    File f;
+    uint64_t offset = 0, on_disk = 0;
+    const NpyStatus st = open_npy(path, &f, &offset, &on_disk, msg);
+    if (st != NpyStatus::kOk) return st;
+    if (on_disk == 0) return NpyStatus::kOk;  // empty BWT: nothing to map
+    const size_t len = size_t(offset + on_disk);
+    void *base = ::mmap(nullptr, len, PROT_READ, MAP_PRIVATE, ::fileno(f.get()), 0);
+    if (base == MAP_FAILED) {
+        *msg = "cannot map " + path + ": " + std::strerror(errno);
+        return NpyStatus::kIo;
+    }
+    ::madvise(base, len, MADV_SEQUENTIAL);
+    out->base_ = base;
+    out->map_len_ = len;
+    out->payload_ = static_cast<const uint8_t *>(base) + offset;
+    out->size_ = size_t(on_disk);
     return NpyStatus::kOk;
 }
 

@@ -14,6 +14,7 @@ LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0 python -m pytest tests/test_oracle_
 cat > /tmp/host_asan_main.cpp <<'CPP'
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <vector>
 #include "npy_io.hpp"
@@ -44,11 +45,16 @@ int main(int argc, char **argv) {
         if (write_npy_payload(path, rle.data(), rle.size(), &msg) != NpyStatus::kOk) return 2;
         std::vector<uint8_t> back;
         if (read_npy_payload(path, &back, &msg) != NpyStatus::kOk || back != rle) return 3;
+        MappedPayload mapped;
+        if (map_npy_payload(path, &mapped, &msg) != NpyStatus::kOk || mapped.size() != rle.size() ||
+            std::memcmp(mapped.data(), rle.data(), rle.size()) != 0) return 4;
     }
     for (int i = 1; i < argc; ++i) {  // malformed files must be rejected cleanly
         std::vector<uint8_t> p;
         std::string msg;
         (void)read_npy_payload(argv[i], &p, &msg);
+        MappedPayload m;
+        (void)map_npy_payload(argv[i], &m, &msg);
     }
     std::puts("host asan ok");
     return 0;
