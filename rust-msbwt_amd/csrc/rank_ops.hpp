@@ -179,13 +179,28 @@ __device__ __forceinline__ uint64_t other_quad(uint64_t x) {  // value held by t
     return (uint64_t(hi) << 32) | lo;
 }
 
-__device__ __forceinline__ Range constrain_split(const uint4 *__restrict__ blocks, uint32_t s, uint64_t l, uint64_t h,
-                                                 uint32_t sub) {
+// A step is split into its loads and its arithmetic so that a group can have the loads of two
+// independent queries in flight before either is consumed.
+struct StepLoads {
+    uint4 c0, c1;
+    uint64_t k;  // pair steps: superblock base; unused for single steps
+};
+
+__device__ __forceinline__ StepLoads issue_single(const uint4 *__restrict__ blocks, uint64_t l, uint64_t h, uint32_t sub) {
+    const uint64_t pos = (sub & 4u) ? h : l;
+    const uint4 *b = blocks + (pos >> 8) * 8 + (sub & 3u);
+    StepLoads L;
+    L.c0 = b[0];
+    L.c1 = b[4];
+    L.k = 0;
+    return L;
+}
+
+__device__ __forceinline__ Range finish_single(const StepLoads &L, uint32_t s, uint64_t l, uint64_t h, uint32_t sub) {
     const bool upper = (sub & 4u) != 0;
     const uint32_t q = sub & 3u;
     const uint64_t pos = upper ? h : l;
-    const uint4 *b = blocks + (pos >> 8) * 8 + q;
-    const uint4 c0 = b[0], c1 = b[4];
+    const uint4 c0 = L.c0, c1 = L.c1;
     const uint32_t x0 = (s & 1u) ? 0u : ~0u, x1 = (s & 2u) ? 0u : ~0u, x2 = (s & 4u) ? 0u : ~0u;
     const int r = int(uint32_t(pos) & 255u) - int(q * 32u);  // chunk q covers [32q, 32q+32), chunk q+4 is 128 further
     const uint32_t cnt = __popc((c0.x ^ x0) & (c0.y ^ x1) & (c0.z ^ x2) & low_bits(min(max(r, 0), 32))) +
@@ -203,26 +218,43 @@ __device__ __forceinline__ Range constrain_split(const uint4 *__restrict__ block
     return out;
 }
 
-__device__ __forceinline__ Range constrain2_split(const uint4 *__restrict__ pair_blocks, const uint64_t *__restrict__ super,
-                                                  uint32_t a2, uint32_t b2, uint64_t l, uint64_t h, uint32_t sub) {
+__device__ __forceinline__ StepLoads issue_pair(const uint4 *__restrict__ pair_blocks, const uint64_t *__restrict__ super,
+                                                uint32_t a2, uint32_t b2, uint64_t l, uint64_t h, uint32_t sub) {
+    const uint64_t pos = (sub & 4u) ? h : l;
+    const uint4 *b = pair_blocks + (pos >> kPairShift) * 8 + (sub & 3u);
+    StepLoads L;
+    L.c0 = b[0];
+    L.c1 = b[4];
+    L.k = super[__builtin_amdgcn_alignbit(uint32_t(pos >> 32), uint32_t(pos), kPairSuperShift) * 16u + (a2 * 4u + b2)];
+    return L;
+}
+
+__device__ __forceinline__ Range finish_pair(const StepLoads &L, uint32_t a2, uint32_t b2, uint64_t l, uint64_t h, uint32_t sub) {
     const bool upper = (sub & 4u) != 0;
     const uint32_t q = sub & 3u;
     const uint64_t pos = upper ? h : l;
-    const uint4 *b = pair_blocks + (pos >> kPairShift) * 8 + q;
-    const uint4 c0 = b[0], c1 = b[4];
     const uint32_t p = a2 * 4u + b2;
-    const uint64_t k = super[__builtin_amdgcn_alignbit(uint32_t(pos >> 32), uint32_t(pos), kPairSuperShift) * 16u + p];
     const int r = int(uint32_t(pos) & 127u) - int(q * 16u);  // chunk q covers [16q, 16q+16), chunk q+4 is 64 further
-    const uint32_t cnt = pair_chunk_count(c0, a2, b2, min(max(r, 0), 16)) + pair_chunk_count(c1, a2, b2, min(max(r - 64, 0), 16));
+    const uint32_t cnt = pair_chunk_count(L.c0, a2, b2, min(max(r, 0), 16)) + pair_chunk_count(L.c1, a2, b2, min(max(r - 64, 0), 16));
     // pair p lives in chunk p>>1 = lane (p>>1)&3, its chunk p>>3
     const uint32_t owner = (q == ((p >> 1) & 3u)) ? ~0u : 0u;
-    const uint32_t t = quad_sum(cnt | ((pair_chunk_field((p >> 3) ? c1 : c0, p) << 8) & owner));
-    const uint64_t mine = k + ((t >> 8) + (t & 0xFFu));
+    const uint32_t t = quad_sum(cnt | ((pair_chunk_field((p >> 3) ? L.c1 : L.c0, p) << 8) & owner));
+    const uint64_t mine = L.k + ((t >> 8) + (t & 0xFFu));
     const uint64_t theirs = other_quad(mine);
     Range out;
     out.l = upper ? theirs : mine;
     out.h = upper ? mine : theirs;
     return out;
+}
+
+__device__ __forceinline__ Range constrain_split(const uint4 *__restrict__ blocks, uint32_t s, uint64_t l, uint64_t h,
+                                                 uint32_t sub) {
+    return finish_single(issue_single(blocks, l, h, sub), s, l, h, sub);
+}
+
+__device__ __forceinline__ Range constrain2_split(const uint4 *__restrict__ pair_blocks, const uint64_t *__restrict__ super,
+                                                  uint32_t a2, uint32_t b2, uint64_t l, uint64_t h, uint32_t sub) {
+    return finish_pair(issue_pair(pair_blocks, super, a2, b2, l, h, sub), a2, b2, l, h, sub);
 }
 
 // Uniform access to the two group shapes
