@@ -177,45 +177,92 @@ def main():
     if not fused:
         nq = len(queries)
         d_q = torch.from_numpy(queries).to(dev)
-    d_out = torch.empty(nq, dtype=torch.int64, device=dev)
-    d_all = torch.empty(nq * world, dtype=torch.int64, device=dev) if world > 1 else None
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    def step():
+    def count_into(out):
         if fused:
-            bwt.count_read_kmers_device(d_reads.data_ptr(), rlen, nread, k, False, d_out.data_ptr(), 0, stream)
+            bwt.count_read_kmers_device(d_reads.data_ptr(), rlen, nread, k, False, out.data_ptr(), 0, stream)
         else:
-            bwt.count_kmers_device(d_q.data_ptr(), k, nq, d_out.data_ptr(), stream)
-        if world > 1:
-            if args.dist_backend == "nccl":
-                dist.all_gather_into_tensor(d_all, d_out)  # the path's one exchange step (RCCL)
-            else:
-                host_all = torch.empty(nq * world, dtype=torch.int64)
-                dist.all_gather_into_tensor(host_all, d_out.cpu())
-                d_all.copy_(host_all)
+            bwt.count_kmers_device(d_q.data_ptr(), k, nq, out.data_ptr(), stream)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    bwt.device_status(stream)
-    bwt.set_kernel_timing(True)
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t_start
-    bwt.set_kernel_timing(False)
-    kernel_ms, launches = bwt.kernel_time_ms()
-    bwt.device_status(stream)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # ---- the exchange step (N > 1): every rank ends each step holding ALL N x nq u64 counts ------
+    # 8 bytes per query over xGMI would cost more than the search itself (C2: 0.3 ms of kernel per
+    # 10 M queries, 80 MB of counts), so the counts travel as int16 whenever that is exact (a
+    # device-side overflow flag is kept per step and checked after the loop; any overflow re-runs
+    # the whole measurement with 64-bit payloads), the all_gather runs asynchronously on RCCL's
+    # stream and overlaps the next step's kernel (two buffers in flight), and each rank widens what
+    # it received back to u64 -- inside the timed region.
+    NARROW_MAX = 32767
+
+    def run_steps(nsteps, narrow):
+        outs = [torch.empty(nq, dtype=torch.int64, device=dev) for _ in range(2)]
+        if world == 1:
+            for _ in range(nsteps):
+                count_into(outs[0])
+            return outs[0], None, False
+        pay_dtype = torch.int16 if narrow else torch.int64
+        sends = [torch.empty(nq, dtype=pay_dtype, device=dev) for _ in range(2)]
+        recvs = [torch.empty(nq * world, dtype=pay_dtype, device=dev) for _ in range(2)]
+        d_all = torch.empty(nq * world, dtype=torch.int64, device=dev)
+        overflow = torch.zeros((), dtype=torch.bool, device=dev)
+        works = [None, None]
+
+        def finish(j):  # widen what slot j received (the collective is done once wait() returns)
+            if works[j] is not None:
+                works[j].wait()
+                d_all.copy_(recvs[j])
+                works[j] = None
+
+        for i in range(nsteps):
+            j = i & 1
+            finish(j)
+            count_into(outs[j])
+            if narrow:
+                overflow |= (outs[j] > NARROW_MAX).any() | (outs[j] < 0).any()
+            sends[j].copy_(outs[j])
+            if args.dist_backend == "nccl":
+                works[j] = dist.all_gather_into_tensor(recvs[j], sends[j], async_op=True)  # RCCL over xGMI
+            else:  # rehearsal: same logic, collective through host memory
+                host = torch.empty(nq * world, dtype=pay_dtype)
+                dist.all_gather_into_tensor(host, sends[j].cpu())
+                recvs[j].copy_(host)
+                d_all.copy_(recvs[j])
+        finish(nsteps & 1)        # the older of the two outstanding steps first
+        finish((nsteps - 1) & 1)
+        return outs[(nsteps - 1) & 1], d_all, overflow
+
+    def timed(narrow):
+        run_steps(args.warmup, narrow)
+        fence()
+        bwt.device_status(stream)
+        bwt.set_kernel_timing(True)
+        t_start = time.perf_counter()
+        d_mine, d_everything, ovf = run_steps(args.steps, narrow)
+        fence()
+        dt = time.perf_counter() - t_start
+        bwt.set_kernel_timing(False)
+        k_ms, n_launch = bwt.kernel_time_ms()
+        bwt.device_status(stream)
+        if world > 1:
+            flag = torch.tensor([1.0 if bool(ovf) else 0.0, dt], dtype=torch.float64,
+                                device=dev if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            return d_mine, d_everything, float(flag[1].item()), k_ms, n_launch, flag[0].item() > 0
+        return d_mine, d_everything, dt, k_ms, n_launch, False
+
+    narrow = world > 1
+    d_out, d_all, elapsed, kernel_ms, launches, overflowed = timed(narrow)
+    if overflowed:  # some count did not fit int16: measure again with u64 payloads (always exact)
+        log("counts exceed int16: re-running with 64-bit payloads")
+        narrow = False
+        d_out, d_all, elapsed, kernel_ms, launches, _ = timed(False)
+    if world > 1:  # the gathered vector must contain this rank's own counts where they belong
+        assert torch.equal(d_all[rank * nq:(rank + 1) * nq], d_out), "gathered counts differ from the local ones"
     ms_per_step = elapsed / args.steps * 1e3
     value = nq * world * args.steps / elapsed
 
@@ -243,8 +290,10 @@ def main():
                             "random" if kind == "random" else "read-derived (ALL windows of ALL reads, prepared in-kernel)" if fused else "read-derived", k),
             "k": k, "queries_per_gpu": nq, "bwt_symbols": total, "index_bytes": bwt.device_bytes(),
             "table_depth": bwt.get_table_depth(), "pair_index": bwt.get_pair_index(),
-            "parallelism": ("query-sharded x%d, index replicated, %s all_gather of counts"
-                            % (world, "RCCL" if args.dist_backend == "nccl" else "gloo (rehearsal)")) if world > 1 else "1 GPU",
+            "parallelism": ("query-sharded x%d, index replicated; per step one %s all_gather of all counts (%s payload, "
+                            "widened to u64 on arrival), overlapped with the next step's kernel"
+                            % (world, "RCCL" if args.dist_backend == "nccl" else "gloo (rehearsal)",
+                               "int16" if narrow else "int64")) if world > 1 else "1 GPU",
         },
     }
 
