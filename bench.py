@@ -225,11 +225,13 @@ def main():
             if narrow:
                 overflow |= (outs[j] > NARROW_MAX).any() | (outs[j] < 0).any()
             sends[j].copy_(outs[j])
+            # the payload crosses as raw bytes: neither NCCL/RCCL nor gloo has a 16-bit integer type
             if args.dist_backend == "nccl":
-                works[j] = dist.all_gather_into_tensor(recvs[j], sends[j], async_op=True)  # RCCL over xGMI
+                works[j] = dist.all_gather_into_tensor(recvs[j].view(torch.uint8), sends[j].view(torch.uint8),
+                                                       async_op=True)  # RCCL over xGMI
             else:  # rehearsal: same logic, collective through host memory
                 host = torch.empty(nq * world, dtype=pay_dtype)
-                dist.all_gather_into_tensor(host, sends[j].cpu())
+                dist.all_gather_into_tensor(host.view(torch.uint8), sends[j].cpu().view(torch.uint8))
                 recvs[j].copy_(host)
                 d_all.copy_(recvs[j])
         finish(nsteps & 1)        # the older of the two outstanding steps first
