@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI, the real thing) or gloo (rehearsal of the N>1 path on fewer GPUs: "
                          "counts are gathered through host memory, ranks may share a GPU)")
+    ap.add_argument("--payload", default="auto", choices=["auto", "int64"],
+                    help="N>1: auto = int16 counts on the wire when exact (falls back to int64), int64 = always wide")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-sample", type=int, default=200_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
@@ -257,7 +259,7 @@ def main():
             return d_mine, d_everything, float(flag[1].item()), k_ms, n_launch, flag[0].item() > 0
         return d_mine, d_everything, dt, k_ms, n_launch, False
 
-    narrow = world > 1
+    narrow = world > 1 and args.payload == "auto"
     d_out, d_all, elapsed, kernel_ms, launches, overflowed = timed(narrow)
     if overflowed:  # some count did not fit int16: measure again with u64 payloads (always exact)
         log("counts exceed int16: re-running with 64-bit payloads")

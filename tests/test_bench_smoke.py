@@ -36,7 +36,8 @@ def test_bench_contract(extra):
     assert "workload" in r["config"] and "model" not in r["config"]
 
 
-def test_bench_two_ranks_rehearsal():
+@pytest.mark.parametrize("payload", ["auto", "int64"])
+def test_bench_two_ranks_rehearsal(payload):
     """The N>1 code path of bench.py (barriers, per-rank batches, gather of all counts, max over
     ranks) with two ranks sharing this box's one GPU and gloo carrying the collective -- RCCL
     itself needs one GPU per rank and is exercised by the driver's multi-GPU runs."""
@@ -47,12 +48,13 @@ def test_bench_two_ranks_rehearsal():
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
-           "--scale", "0.003", "--steps", "2", "--warmup", "1", "--parity-sample", "5000"]
+           "--scale", "0.003", "--steps", "3", "--warmup", "1", "--parity-sample", "5000", "--payload", payload]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     r = json.loads(lines[0])
-    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["parity"]["mismatches"] == 0
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["scaling"] == "weak" and r["parity"]["mismatches"] == 0
     assert "cpu_baseline" not in r            # reported at N=1 only
     assert r["value"] > 0 and "x2" in r["config"]["parallelism"]
+    assert ("int16" if payload == "auto" else "int64") in r["config"]["parallelism"]
