@@ -31,6 +31,16 @@ def log(msg):
     print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def make_queries(synth, cfg, reads, nq, k, seed, kind):
     if kind == "random":
         return synth.random_kmers(nq, k, seed)
@@ -359,6 +369,7 @@ def main():
             t1 = time.time() - t0
             result["cpu_baseline"] = {
                 "value": ncs / t1, "unit": "queries/s", "cores": 1, "kind": "port",
+                "cpu_model": cpu_model(), "nproc": os.cpu_count(),
                 "sample": "first %d queries of the same batch, same comp_msbwt.npy, 1 thread (the reference is single-threaded), -O3 C restatement" % ncs,
                 "all_cores": {"value": nst / t_all, "cores": ncpu, "note": "same batch, static partition, instrumented build"},
             }
