@@ -100,9 +100,12 @@ class OracleRleBWT:
         self.bin_power = bin_power
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_rle_free(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().orc_rle_free(h)
+            except (TypeError, AttributeError):  # interpreter shutdown
+                pass
 
     def load_vector(self, bwt):
         a, p = _u8(bwt)

@@ -45,9 +45,12 @@ class RleBWT(BWT):
         return cls(bin_power, device)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            _lib.lib().msbwt_rle_free(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().msbwt_rle_free(h)
+            except (TypeError, AttributeError):  # interpreter shutdown: module globals already gone
+                pass
 
     # ---- trait BWT -------------------------------------------------------------------
     def load_vector(self, bwt):
