@@ -96,7 +96,7 @@ int msbwt_rle_device_status(const msbwt_rle *bwt, void *hip_stream);
  * host-side loop  convert_stoi (src/string_util.rs:63-67) -> windows -> reverse_complement_i
  * (:45-50) -> count_kmer (src/msbwt_core.rs:124-161)  that consumers of the crate write.
  * reads: n_reads x read_len bytes, ASCII (ascii != 0: A/a C/c G/g T/t $ as in
- * string_util.rs:15-32, everything else N) or symbol codes (ascii == 0).  1 <= k <= 32,
+ * string_util.rs:15-32, everything else N) or symbol codes (ascii == 0).  1 <= k <= 64,
  * k <= read_len.  out_fwd / out_rc: n_reads x (read_len - k + 1) counts; either may be NULL.
  * out_rc[r][w] is the count of reverse_complement_i(window w of read r). */
 int msbwt_rle_count_read_kmers(const msbwt_rle *bwt, const uint8_t *reads, size_t read_len, size_t n_reads,

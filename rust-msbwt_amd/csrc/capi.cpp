@@ -440,8 +440,8 @@ int msbwt_rle_count_read_kmers_device(const msbwt_rle *ch, const void *d_reads, 
     if (!h) return MSBWT_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
     if (!h->loaded) return fail(h, MSBWT_ERR_NOT_LOADED, "no BWT loaded");
-    if (k < 1 || k > 32 || k > read_len || read_len > 0xFFFFFFFFull || (!d_out_fwd && !d_out_rc) || (n_reads && !d_reads))
-        return fail(h, MSBWT_ERR_INVALID_ARG, "count_read_kmers needs 1 <= k <= min(32, read_len) and an output");
+    if (k < 1 || k > 64 || k > read_len || read_len > 0xFFFFFFFFull || (!d_out_fwd && !d_out_rc) || (n_reads && !d_reads))
+        return fail(h, MSBWT_ERR_INVALID_ARG, "count_read_kmers needs 1 <= k <= min(64, read_len) and an output");
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
     return launch_read_kmers_locked(h, d_reads, read_len, n_reads, k, ascii, d_out_fwd, d_out_rc,
@@ -453,8 +453,8 @@ int msbwt_rle_count_read_kmers(const msbwt_rle *ch, const uint8_t *reads, size_t
     msbwt_rle *h = const_cast<msbwt_rle *>(ch);
     if (!h) return MSBWT_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(h->mu);  // held throughout: the staging buffer is per handle
-    if (k < 1 || k > 32 || k > read_len || read_len > 0xFFFFFFFFull || (!out_fwd && !out_rc) || (n_reads && !reads))
-        return fail(h, MSBWT_ERR_INVALID_ARG, "count_read_kmers needs 1 <= k <= min(32, read_len) and an output");
+    if (k < 1 || k > 64 || k > read_len || read_len > 0xFFFFFFFFull || (!out_fwd && !out_rc) || (n_reads && !reads))
+        return fail(h, MSBWT_ERR_INVALID_ARG, "count_read_kmers needs 1 <= k <= min(64, read_len) and an output");
     if (!h->loaded) return fail(h, MSBWT_ERR_NOT_LOADED, "no BWT loaded");
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
@@ -488,8 +488,8 @@ int msbwt_rle_count_ragged_read_kmers(const msbwt_rle *ch, const uint8_t *reads,
     msbwt_rle *h = const_cast<msbwt_rle *>(ch);
     if (!h) return MSBWT_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
-    if (k < 1 || k > 32 || (n_reads && (!read_offsets || !reads)))
-        return fail(h, MSBWT_ERR_INVALID_ARG, "count_ragged_read_kmers needs 1 <= k <= 32 and offsets");
+    if (k < 1 || k > 64 || (n_reads && (!read_offsets || !reads)))
+        return fail(h, MSBWT_ERR_INVALID_ARG, "count_ragged_read_kmers needs 1 <= k <= 64 and offsets");
     // window prefix: read r owns [win[r], win[r+1])
     std::vector<uint64_t> win(n_reads + 1, 0);
     for (size_t r = 0; r < n_reads; ++r) {

@@ -8,7 +8,7 @@
 // With pair blocks a step consumes two k-mer symbols.  Block layouts: plane_index.hpp,
 // rank_ops.hpp.
 //
-// count_kmers (k <= 32) works on tiles of 64 queries per wave, in two phases:
+// count_kmers (k <= 64) works on tiles of 64 queries per wave, in two phases:
 //   1. lane-per-query setup: the tile's query bytes are staged through LDS with coalesced
 //      16-byte loads; every lane validates and bit-packs one query and looks its last
 //      `depth` symbols up in the suffix table (64 independent loads in flight per wave).
@@ -29,7 +29,8 @@ namespace msbwt {
 namespace {
 
 constexpr int kTile = 64;       // queries per wave tile
-constexpr int kMaxShortK = 32;  // tiled kernel: symbols fit 96 bits
+constexpr int kMaxShortK = 32;  // tiled kernel, 3 dwords of packed symbols
+constexpr int kMaxTiledK = 64;  // tiled kernel, 6 dwords
 constexpr int kWavesPerBlock = 4;
 
 // compiler-level ordering of one wave's LDS writes before its later LDS reads (the LDS
@@ -66,17 +67,21 @@ __global__ __launch_bounds__(256) void k_count_kmers_generic(const uint4 *__rest
     }
 }
 
-// ---- count_kmers, 1 <= k <= 32: tiled two-phase kernel -----------------------------------
-struct alignas(16) WorkItem {  // one undecided query of the tile, 32 bytes
+// ---- count_kmers, 1 <= k <= 64: tiled two-phase kernel -----------------------------------
+// kWords = dwords of packed symbols a query carries: 3 (k <= 32) or 6 (k <= 64).
+template <int kWords>
+struct alignas(16) WorkItemT {  // one undecided query of the tile: 32 bytes (kWords 3) or 48 (kWords 6)
     uint32_t l_lo, l_hi, h_lo, h_hi;
-    uint32_t w0, w1, w2;  // remaining symbols, 3 bits each, next step in the low bits
+    uint32_t w[kWords];   // remaining symbols, 3 bits each, next step in the low bits
     uint32_t rem_slot;    // remaining steps | slot in tile << 8
 };
 
-struct WaveScratch {
-    uint4 stage[kTile * kMaxShortK / 16];  // the tile's query bytes (2 KiB)
-    WorkItem work[kTile];                  // 2 KiB
-    uint64_t result[kTile];                // 512 B
+template <int kWords>
+struct WaveScratchT {
+    static constexpr int kMaxK = kWords * 32 / 3;  // 32 or 64
+    uint4 stage[kTile * kMaxK / 16];               // the tile's query bytes (2 or 4 KiB)
+    WorkItemT<kWords> work[kTile];                 // 2 or 3 KiB
+    uint64_t result[kTile];                        // 512 B
 };
 
 // Where a tile's queries come from and where their counts go.
@@ -110,13 +115,24 @@ __device__ __forceinline__ uint32_t complement_code(uint32_t s) {  // $ACGNT -> 
     return s == 1u ? 5u : s == 5u ? 1u : s == 2u ? 3u : s == 3u ? 2u : s;
 }
 
-template <bool kReads, int kLanes, bool kPair>
-__global__ __launch_bounds__(256, kLanes == 4 ? 6 : 8) void k_count_kmers_tiled(const uint4 *__restrict__ blocks, uint64_t total,
-                                                           const uint4 *__restrict__ table, uint32_t depth,
-                                                           const uint4 *__restrict__ pair_blocks,
-                                                           const uint64_t *__restrict__ pair_super,
-                                                           const QuerySource src, uint32_t *__restrict__ flags) {
-    __shared__ WaveScratch scratch[kWavesPerBlock];
+// drops the `bits` lowest bits of the packed symbols (3 or 6: one or two consumed symbols)
+template <int kWords>
+__device__ __forceinline__ void consume_symbols(uint32_t (&w)[kWords], int bits) {
+#pragma unroll
+    for (int i = 0; i + 1 < kWords; ++i) w[i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], bits);
+    w[kWords - 1] >>= bits;
+}
+
+template <bool kReads, int kLanes, bool kPair, int kWords>
+__global__ __launch_bounds__(256, kWords == 6 ? 5 : (kLanes == 4 ? 6 : 8)) void k_count_kmers_tiled(
+    const uint4 *__restrict__ blocks, uint64_t total, const uint4 *__restrict__ table, uint32_t depth,
+    const uint4 *__restrict__ pair_blocks, const uint64_t *__restrict__ pair_super, const QuerySource src,
+    uint32_t *__restrict__ flags) {
+    using Scratch = WaveScratchT<kWords>;
+    using WorkItem = WorkItemT<kWords>;
+    constexpr int kPieces = Scratch::kMaxK / 16;  // 16-byte pieces of a tile per lane: 2 or 4
+    constexpr int kBits = (kWords + 1) / 2;       // u64 words of packed symbols during setup
+    __shared__ Scratch scratch[kWavesPerBlock];
     const uint8_t *__restrict__ kmers = src.data;
     const uint32_t k = src.k;
     const uint64_t n = src.n;
@@ -124,7 +140,7 @@ __global__ __launch_bounds__(256, kLanes == 4 ? 6 : 8) void k_count_kmers_tiled(
     const uint32_t sub = lane & (kLanes - 1);
     const uint32_t group_first_lane = lane & ~uint32_t(kLanes - 1);
     constexpr uint64_t kGroupLeaders = kLanes == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;
-    WaveScratch &ws = scratch[threadIdx.x >> 6];
+    Scratch &ws = scratch[threadIdx.x >> 6];
     const uint8_t *stage_bytes = reinterpret_cast<const uint8_t *>(ws.stage);
 
     const uint64_t ntiles = (n + kTile - 1) / kTile;
@@ -135,26 +151,29 @@ __global__ __launch_bounds__(256, kLanes == 4 ? 6 : 8) void k_count_kmers_tiled(
     // Piece `piece` (16 bytes) of a tile's query bytes; the batch's ragged end is read bytewise so
     // that nothing past the caller's buffer is touched.
     auto load_piece = [&](uint64_t tile_q0, uint32_t nbytes, uint32_t piece) -> uint4 {
-        const uint8_t *src = kmers + tile_q0 * k;
-        if (piece * 16u + 16u <= nbytes) return *reinterpret_cast<const uint4 *>(src + piece * 16u);
+        const uint8_t *src_bytes = kmers + tile_q0 * k;
+        if (piece * 16u >= nbytes) return make_uint4(0, 0, 0, 0);
+        if (piece * 16u + 16u <= nbytes) return *reinterpret_cast<const uint4 *>(src_bytes + piece * 16u);
         uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
         for (uint32_t b = piece * 16u; b < nbytes; ++b) {
-            const uint32_t v = uint32_t(src[b]) << ((b & 3u) * 8u), word = (b & 15u) >> 2;
+            const uint32_t v = uint32_t(src_bytes[b]) << ((b & 3u) * 8u), word = (b & 15u) >> 2;
             if (word == 0u) w0 |= v; else if (word == 1u) w1 |= v; else if (word == 2u) w2 |= v; else w3 |= v;
         }
         return make_uint4(w0, w1, w2, w3);
     };
-    // A tile is at most 64 x 32 = 2048 bytes = 128 pieces: two per lane, both loads in flight at
-    // once.  In the lean variant (short searches, e.g. C2, where setup dominates) the two loads
-    // of the NEXT tile are issued before the current tile is searched, hiding their latency; the
-    // pair variant has no registers to spare for that and loads at the top of the tile.
-    constexpr bool kPrefetch = !kPair;
-    uint4 stage0 = make_uint4(0, 0, 0, 0), stage1 = make_uint4(0, 0, 0, 0);
+    // A tile is at most 64 x kMaxK bytes = kPieces pieces per lane, all loads in flight at once.
+    // In the lean k <= 32 variant (short searches, e.g. C2, where setup dominates) the loads of
+    // the NEXT tile are issued before the current tile is searched, hiding their latency; the
+    // other variants have no registers to spare for that and load at the top of the tile.
+    constexpr bool kPrefetch = !kPair && kWords == 3;
+    uint4 staged[kPieces];
+#pragma unroll
+    for (int i = 0; i < kPieces; ++i) staged[i] = make_uint4(0, 0, 0, 0);
     if (!kReads && kPrefetch && wave_id < ntiles) {
         const uint64_t q0 = wave_id * kTile;
         const uint32_t nbytes = uint32_t(min(uint64_t(kTile), n - q0)) * k;
-        if (lane * 16u < nbytes) stage0 = load_piece(q0, nbytes, lane);
-        if ((lane + 64u) * 16u < nbytes) stage1 = load_piece(q0, nbytes, lane + 64u);
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) staged[i] = load_piece(q0, nbytes, lane + 64u * i);
     }
 
     for (uint64_t tile = wave_id; tile < ntiles; tile += nwaves) {
@@ -163,28 +182,30 @@ __global__ __launch_bounds__(256, kLanes == 4 ? 6 : 8) void k_count_kmers_tiled(
         // ---- phase 1a: the tile's bytes (contiguous, 16-byte aligned) go through LDS ----
         if (!kReads) {
             if (!kPrefetch) {
-                const uint32_t nbytes = in_tile * k;
-                stage0 = stage1 = make_uint4(0, 0, 0, 0);
-                if (lane * 16u < nbytes) stage0 = load_piece(q0, nbytes, lane);
-                if ((lane + 64u) * 16u < nbytes) stage1 = load_piece(q0, nbytes, lane + 64u);
+#pragma unroll
+                for (int i = 0; i < kPieces; ++i) staged[i] = load_piece(q0, in_tile * k, lane + 64u * i);
             }
-            ws.stage[lane] = stage0;
-            ws.stage[lane + 64u] = stage1;
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i) ws.stage[lane + 64u * i] = staged[i];
             const uint64_t next_tile = tile + nwaves;
             if (kPrefetch && next_tile < ntiles) {
                 const uint64_t nq0 = next_tile * kTile;
                 const uint32_t nbytes = uint32_t(min(uint64_t(kTile), n - nq0)) * k;
-                if (lane * 16u < nbytes) stage0 = load_piece(nq0, nbytes, lane);
-                if ((lane + 64u) * 16u < nbytes) stage1 = load_piece(nq0, nbytes, lane + 64u);
+#pragma unroll
+                for (int i = 0; i < kPieces; ++i) staged[i] = load_piece(nq0, nbytes, lane + 64u * i);
             }
         }
         wave_lds_sync();
         // ---- phase 1b: one lane = one query: validate, pack, table lookup ----
         bool pending = false;
         uint64_t l = 0, h = total;
-        uint32_t w0 = 0, w1 = 0, w2 = 0, rem = k;
+        uint32_t w[kWords], rem = k;
+#pragma unroll
+        for (int i = 0; i < kWords; ++i) w[i] = 0;
         if (lane < in_tile) {
-            uint64_t lo = 0, hi = 0;  // symbol of step t (t = 0 first) at bits [3t, 3t+3) of hi:lo
+            uint64_t bits[kBits];  // symbol of step t (t = 0 first) at bits [3t, 3t+3) of the little-endian words
+#pragma unroll
+            for (int j = 0; j < kBits; ++j) bits[j] = 0;
             uint32_t bad = 0, acgt = 1, tidx = 0;
             const uint8_t *mine = stage_bytes + lane * k;
             bool rc = false;
@@ -216,12 +237,11 @@ __global__ __launch_bounds__(256, kLanes == 4 ? 6 : 8) void k_count_kmers_tiled(
                     if (rc) s = complement_code(s);
                 }
                 bad |= (s >= 6u) ? 1u : 0u;
-                const uint32_t pos = 3u * t;
-                if (pos < 64u) {
-                    lo |= uint64_t(s & 7u) << pos;
-                    if (pos > 61u) hi |= uint64_t(s & 7u) >> (64u - pos);
-                } else {
-                    hi |= uint64_t(s & 7u) << (pos - 64u);
+                const uint32_t pos = 3u * t, word = pos >> 6, off = pos & 63u;
+#pragma unroll
+                for (int j = 0; j < kBits; ++j) {
+                    if (word == uint32_t(j)) bits[j] |= uint64_t(s & 7u) << off;
+                    if (j > 0 && word == uint32_t(j - 1) && off > 61u) bits[j] |= uint64_t(s & 7u) >> (64u - off);
                 }
                 if (t < depth) {  // table index: A C G T -> 0..3, step t at bits [2t, 2t+2)
                     acgt &= acgt_bit(s);
@@ -237,17 +257,17 @@ __global__ __launch_bounds__(256, kLanes == 4 ? 6 : 8) void k_count_kmers_tiled(
                     l = (uint64_t(e.y) << 32) | e.x;
                     h = (uint64_t(e.w) << 32) | e.z;
                     rem = k - depth;
-                    const uint32_t sh = 3u * depth;  // 3..39
-                    lo = (lo >> sh) | (hi << (64u - sh));
-                    hi >>= sh;
+                    const uint32_t sh = 3u * depth;  // 3..48
+#pragma unroll
+                    for (int j = 0; j < kBits; ++j)
+                        bits[j] = (bits[j] >> sh) | (j + 1 < kBits ? bits[j + 1] << (64u - sh) : 0ull);
                 }
                 if (rem == 0u || l == h) {
                     ws.result[lane] = h - l;
                 } else {
                     pending = true;
-                    w0 = uint32_t(lo);
-                    w1 = uint32_t(lo >> 32);
-                    w2 = uint32_t(hi);
+#pragma unroll
+                    for (int i = 0; i < kWords; ++i) w[i] = uint32_t(bits[i >> 1] >> ((i & 1) * 32));
                 }
             }
         }
@@ -259,7 +279,8 @@ __global__ __launch_bounds__(256, kLanes == 4 ? 6 : 8) void k_count_kmers_tiled(
             WorkItem it;
             it.l_lo = uint32_t(l); it.l_hi = uint32_t(l >> 32);
             it.h_lo = uint32_t(h); it.h_hi = uint32_t(h >> 32);
-            it.w0 = w0; it.w1 = w1; it.w2 = w2;
+#pragma unroll
+            for (int i = 0; i < kWords; ++i) it.w[i] = w[i];
             it.rem_slot = rem | (lane << 8);
             ws.work[at] = it;
         }
@@ -277,14 +298,21 @@ __global__ __launch_bounds__(256, kLanes == 4 ? 6 : 8) void k_count_kmers_tiled(
                     const uint64_t idle = ~busy & kGroupLeaders;  // one bit per idle group (its first lane)
                     const uint32_t idle_before = uint32_t(__popcll(idle & ((1ull << group_first_lane) - 1ull)));
                     if (!have && next + idle_before < nwork) {
-                        const WorkItem *it = &ws.work[next + idle_before];
-                        const uint4 a = *reinterpret_cast<const uint4 *>(it);
-                        const uint4 b = *(reinterpret_cast<const uint4 *>(it) + 1);
+                        const uint4 *it = reinterpret_cast<const uint4 *>(&ws.work[next + idle_before]);
+                        const uint4 a = it[0], b = it[1];
                         l = (uint64_t(a.y) << 32) | a.x;
                         h = (uint64_t(a.w) << 32) | a.z;
-                        w0 = b.x; w1 = b.y; w2 = b.z;
-                        rem = b.w & 0xFFu;
-                        slot = b.w >> 8;
+                        uint32_t rem_slot;
+                        if constexpr (kWords == 3) {
+                            w[0] = b.x; w[1] = b.y; w[2] = b.z;
+                            rem_slot = b.w;
+                        } else {
+                            const uint4 c = it[2];
+                            w[0] = b.x; w[1] = b.y; w[2] = b.z; w[3] = b.w; w[4] = c.x; w[5] = c.y;
+                            rem_slot = c.z;
+                        }
+                        rem = rem_slot & 0xFFu;
+                        slot = rem_slot >> 8;
                         have = true;
                     }
                     next = min(nwork, next + uint32_t(__popcll(idle)));
@@ -292,23 +320,19 @@ __global__ __launch_bounds__(256, kLanes == 4 ? 6 : 8) void k_count_kmers_tiled(
                 }
                 if (busy == 0ull) break;
                 if (have) {
-                    const uint32_t s1 = w0 & 7u, s2 = (w0 >> 3) & 7u;
+                    const uint32_t s1 = w[0] & 7u, s2 = (w[0] >> 3) & 7u;
                     if (kPair && rem >= 2u && (acgt_bit(s1) & acgt_bit(s2)) != 0u) {
                         // two symbols for one line fetch per bound
                         const Range r = GroupOps<kLanes>::step2(pair_blocks, pair_super, acgt_code(s1), acgt_code(s2), l, h, sub);
                         l = r.l;
                         h = r.h;
-                        w0 = __builtin_amdgcn_alignbit(w1, w0, 6);
-                        w1 = __builtin_amdgcn_alignbit(w2, w1, 6);
-                        w2 >>= 6;
+                        consume_symbols<kWords>(w, 6);
                         rem -= 2u;
                     } else {
                         const Range r = GroupOps<kLanes>::step(blocks, s1, l, h, sub);
                         l = r.l;
                         h = r.h;
-                        w0 = __builtin_amdgcn_alignbit(w1, w0, 3);
-                        w1 = __builtin_amdgcn_alignbit(w2, w1, 3);
-                        w2 >>= 3;
+                        consume_symbols<kWords>(w, 3);
                         --rem;
                     }
                     if (rem == 0u || l == h) {
@@ -389,7 +413,7 @@ __global__ __launch_bounds__(256) void k_constrain_ranges(const uint4 *__restric
 
 // The tiled kernel comes in 2 x 2 x 2 shapes; pick one and launch it.
 template <bool kReads>
-void launch_tiled(bool quad, bool pair, dim3 grid, hipStream_t stream, const uint4 *blocks, uint64_t total,
+void launch_tiled(bool quad, bool pair, bool longk, dim3 grid, hipStream_t stream, const uint4 *blocks, uint64_t total,
                   const uint4 *table, uint32_t depth, const uint4 *pair_blocks, const uint64_t *pair_super,
                   const QuerySource &src, uint32_t *flags);
 
@@ -416,15 +440,17 @@ inline bool use_pair_steps(const IndexView &ix, uint32_t k) {
 }
 
 template <bool kReads>
-void launch_tiled(bool quad, bool pair, dim3 grid, hipStream_t stream, const uint4 *blocks, uint64_t total,
+void launch_tiled(bool quad, bool pair, bool longk, dim3 grid, hipStream_t stream, const uint4 *blocks, uint64_t total,
                   const uint4 *table, uint32_t depth, const uint4 *pair_blocks, const uint64_t *pair_super,
                   const QuerySource &src, uint32_t *flags) {
-#define MSBWT_LAUNCH(L, P) \
-    hipLaunchKernelGGL((k_count_kmers_tiled<kReads, L, P>), grid, dim3(256), 0, stream, blocks, total, table, depth, pair_blocks, pair_super, src, flags)
-    if (quad) {
-        if (pair) MSBWT_LAUNCH(4, true); else MSBWT_LAUNCH(4, false);
+#define MSBWT_LAUNCH(L, P, W) \
+    hipLaunchKernelGGL((k_count_kmers_tiled<kReads, L, P, W>), grid, dim3(256), 0, stream, blocks, total, table, depth, pair_blocks, pair_super, src, flags)
+    if (longk) {  // 33 <= k <= 64: 8-lane groups
+        if (pair) MSBWT_LAUNCH(8, true, 6); else MSBWT_LAUNCH(8, false, 6);
+    } else if (quad) {
+        if (pair) MSBWT_LAUNCH(4, true, 3); else MSBWT_LAUNCH(4, false, 3);
     } else {
-        if (pair) MSBWT_LAUNCH(8, true); else MSBWT_LAUNCH(8, false);
+        if (pair) MSBWT_LAUNCH(8, true, 3); else MSBWT_LAUNCH(8, false, 3);
     }
 #undef MSBWT_LAUNCH
 }
@@ -436,7 +462,7 @@ hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_
     if (n == 0) return hipSuccess;
     const uint4 *blocks = static_cast<const uint4 *>(ix.blocks);
     const bool aligned = (reinterpret_cast<uintptr_t>(kmers) & 15u) == 0;
-    if (k >= 1 && k <= uint32_t(kMaxShortK) && aligned) {
+    if (k >= 1 && k <= uint32_t(kMaxTiledK) && aligned) {
         const uint64_t tiles = (n + kTile - 1) / kTile;
         const bool quad = use_quad_groups();
         QuerySource src{};
@@ -444,7 +470,7 @@ hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_
         src.n = n;
         src.k = k;
         src.out_fwd = counts;
-        launch_tiled<false>(quad, use_pair_steps(ix, k), dim3(grid_for(tiles * 64)), stream, blocks, ix.total,
+        launch_tiled<false>(quad, use_pair_steps(ix, k), k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, blocks, ix.total,
                             static_cast<const uint4 *>(ix.table.entries), uint32_t(ix.table.depth),
                             static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags);
     } else {
@@ -457,7 +483,7 @@ hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_
 hipError_t launch_count_read_kmers(const IndexView &ix, const uint8_t *reads, uint32_t read_len, uint64_t n_reads,
                                    uint32_t k, bool ascii, uint64_t *out_fwd, uint64_t *out_rc, uint32_t *flags,
                                    hipStream_t stream) {
-    if (k < 1 || k > uint32_t(kMaxShortK) || k > read_len || (!out_fwd && !out_rc)) return hipErrorInvalidValue;
+    if (k < 1 || k > uint32_t(kMaxTiledK) || k > read_len || (!out_fwd && !out_rc)) return hipErrorInvalidValue;
     if (n_reads == 0) return hipSuccess;
     const bool quad = use_quad_groups();
     QuerySource src{};
@@ -471,7 +497,7 @@ hipError_t launch_count_read_kmers(const IndexView &ix, const uint8_t *reads, ui
     src.out_rc = out_rc;
     src.n = n_reads * src.windows * (src.strands == 3u ? 2u : 1u);
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
-    launch_tiled<true>(quad, use_pair_steps(ix, k), dim3(grid_for(tiles * 64)), stream, static_cast<const uint4 *>(ix.blocks),
+    launch_tiled<true>(quad, use_pair_steps(ix, k), k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, static_cast<const uint4 *>(ix.blocks),
                        ix.total, static_cast<const uint4 *>(ix.table.entries), uint32_t(ix.table.depth),
                        static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags);
     return hipGetLastError();
@@ -481,7 +507,7 @@ hipError_t launch_count_ragged_read_kmers(const IndexView &ix, const uint8_t *re
                                           const uint64_t *win_off, uint64_t n_reads, uint64_t n_windows, uint32_t k,
                                           bool ascii, uint64_t *out_fwd, uint64_t *out_rc, uint32_t *flags,
                                           hipStream_t stream) {
-    if (k < 1 || k > uint32_t(kMaxShortK) || (!out_fwd && !out_rc)) return hipErrorInvalidValue;
+    if (k < 1 || k > uint32_t(kMaxTiledK) || (!out_fwd && !out_rc)) return hipErrorInvalidValue;
     if (n_reads == 0 || n_windows == 0) return hipSuccess;
     const bool quad = use_quad_groups();
     QuerySource src{};
@@ -496,7 +522,7 @@ hipError_t launch_count_ragged_read_kmers(const IndexView &ix, const uint8_t *re
     src.n_reads = n_reads;
     src.n = n_windows * (src.strands == 3u ? 2u : 1u);
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
-    launch_tiled<true>(quad, use_pair_steps(ix, k), dim3(grid_for(tiles * 64)), stream, static_cast<const uint4 *>(ix.blocks),
+    launch_tiled<true>(quad, use_pair_steps(ix, k), k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, static_cast<const uint4 *>(ix.blocks),
                        ix.total, static_cast<const uint4 *>(ix.table.entries), uint32_t(ix.table.depth),
                        static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags);
     return hipGetLastError();

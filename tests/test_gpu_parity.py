@@ -149,9 +149,9 @@ def _real_bwt(seed, nreads, length):
     return reads, orc.convert_to_vec(orc.naive_bwt(reads))
 
 
-@pytest.mark.parametrize("k", [1, 2, 5, 12, 21, 31, 32, 33, 50])
+@pytest.mark.parametrize("k", [1, 2, 5, 12, 21, 31, 32, 33, 42, 43, 50, 59, 63, 64, 65, 70])
 def test_count_kmers_on_true_bwt(k):
-    reads, rle = _real_bwt(2, 150, 60)
+    reads, rle = _real_bwt(2, 150, 72)
     o = orc.OracleRleBWT()
     o.load_vector(rle)
     b = gpu_bwt(rle)
@@ -334,7 +334,7 @@ def test_device_built_index_equals_host_built(case):
         assert np.array_equal(dev, host)
 
 
-@pytest.mark.parametrize("k", [1, 5, 21, 31, 32])
+@pytest.mark.parametrize("k", [1, 5, 21, 31, 32, 33, 47])
 def test_fused_read_kmers_match_host_side_preparation(k):
     """count_read_kmers == convert_stoi -> windows -> (reverse_complement_i) -> count_kmer done
     on the host with the reference's string_util semantics (src/string_util.rs)."""
@@ -424,7 +424,7 @@ def test_pair_index_never_changes_results(pair, depth):
     b.set_pair_index(pair)
     assert b.get_pair_index() == bool(pair)
     rng = np.random.default_rng(depth * 2 + pair)
-    for k in (1, 2, 3, 4, 9, 10, 20, 21, 31, 32):
+    for k in (1, 2, 3, 4, 9, 10, 20, 21, 31, 32, 33, 48, 59, 64):
         qs = [orc.convert_stoi(r[p:p + k]) for r in reads if len(r) >= k for p in (int(rng.integers(0, len(r) - k + 1)),)]
         qs = np.concatenate([np.array(qs, dtype=np.uint8), random_kmers(k, 300, k),
                              random_kmers(k + 7, 200, k, alphabet=(0, 1, 2, 3, 4, 5))])

@@ -50,7 +50,7 @@ def main():
             depth = int(rng.integers(0, 9))
             b.set_table_depth(depth)
             b.set_pair_index(int(rng.integers(0, 2)))
-            k = int(rng.integers(1, 41))
+            k = int(rng.integers(1, 72))
             n = int(rng.integers(1, 700))
             qs = [random_kmers(int(rng.integers(0, 1 << 30)), n, k),
                   random_kmers(int(rng.integers(0, 1 << 30)), n // 3 + 1, k, alphabet=(0, 1, 2, 3, 4, 5))]
@@ -70,7 +70,7 @@ def main():
             gl, gh = b.constrain_ranges(sy, l, h)
             ol, oh = o.constrain_ranges(sy, l, h)
             assert np.array_equal(gl, ol) and np.array_equal(gh, oh), (kind, len(rle))
-            if reads is not None and 1 <= k <= 32 and reads.shape[1] >= k:
+            if reads is not None and 1 <= k <= 64 and reads.shape[1] >= k:
                 sub = reads[: min(len(reads), 40)]
                 f, r = b.count_read_kmers(sub, k, ascii=False, revcomp=True)
                 w = sub.shape[1] - k + 1
