@@ -25,6 +25,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is achievable
+RANDOM_LINE_PEAK = 4.4e10  # dependent random 128-byte lines/s, measured (tools/ubench_gather.hip, 1-200 GB tables)
 
 
 def log(msg):
@@ -359,6 +360,12 @@ def main():
             "kernel": "k_count_kmers_tiled<reads>" if fused else "k_count_kmers_tiled" if 1 <= k <= 32 else "k_count_kmers_generic", "kernel_ms": kernel_ms, "kernel_launches": launches,
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "algorithmic_bytes_per_query": alg_bytes / nq,
+            "note": "achieved = the REFERENCE algorithm's bytes for this query set / kernel time (SURVEY 8d); the suffix "
+                    "table and pair steps make the kernel move fewer bytes than that, so frac can exceed 1 -- "
+                    "`traffic` is what it really moved, `random_lines` prices that against the measured "
+                    "random-128-byte-line rate of the memory system (tools/ubench_gather.hip)",
+            "random_lines": None if traffic is None else {
+                "per_s": traffic / 128.0 / kern_s, "peak_per_s": RANDOM_LINE_PEAK, "frac": traffic / 128.0 / kern_s / RANDOM_LINE_PEAK},
             "mean_steps_per_query": st.steps / nst, "mean_bin_visits_per_query": st.visits / nst,
             "stats_queries": int(nst),
         }
