@@ -33,3 +33,27 @@ def test_reference_tests_through_cpp_mirror(tmp_path):
                        timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all C++ trait-mirror tests passed" in r.stdout
+
+
+def _build_c_example(out):
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "count_kmers.c"), "-o", out, "-L", LIBDIR, "-lmsbwt_hip",
+                           "-Wl,-rpath," + LIBDIR, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"])
+
+
+def test_c_example_compiles_as_plain_c(tmp_path):
+    """include/msbwt_hip.h is a C header: a C11 host builds against it."""
+    exe = str(tmp_path / "count_kmers")
+    _build_c_example(exe)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+
+
+@pytest.mark.gpu
+def test_c_example_counts_two_string(tmp_path):
+    exe = str(tmp_path / "count_kmers")
+    _build_c_example(exe)
+    r = subprocess.run([exe, os.path.join(GOLDEN_DIR, "two_string.npy"), "ACGT", "TGCA", "CCCC"], capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "total symbols: 10" in r.stdout and "ACGT\t1" in r.stdout and "TGCA\t1" in r.stdout and "CCCC\t0" in r.stdout
