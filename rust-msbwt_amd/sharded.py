@@ -61,10 +61,22 @@ class ShardedCounter:
         if self.world == 1:
             return mine
         cap = shard_capacity(n, self.world)
-        padded = torch.zeros(cap, dtype=torch.int64, device=kmers.device)
-        padded[:hi - lo] = mine
-        gathered = torch.empty(cap * self.world, dtype=torch.int64, device=kmers.device)
-        dist.all_gather_into_tensor(gathered, padded, group=self.group)
+        # 8 bytes per count over xGMI can cost more than computing it: agree on the narrowest
+        # integer type that holds every rank's largest count exactly, ship raw bytes (neither
+        # RCCL nor gloo has a 16-bit integer type), widen on arrival.
+        top = mine.max().reshape(1).to(torch.int64) if hi > lo else torch.zeros(1, dtype=torch.int64, device=kmers.device)
+        low = mine.min().reshape(1).to(torch.int64) if hi > lo else torch.zeros(1, dtype=torch.int64, device=kmers.device)
+        span = torch.cat([top, -low])
+        dist.all_reduce(span, op=dist.ReduceOp.MAX, group=self.group)
+        biggest, smallest = int(span[0]), -int(span[1])
+        wire = torch.int64
+        if smallest >= 0:  # u64 counts >= 2^63 look negative as int64: keep them wide
+            wire = torch.int16 if biggest < (1 << 15) else torch.int32 if biggest < (1 << 31) else torch.int64
+        padded = torch.zeros(cap, dtype=wire, device=kmers.device)
+        padded[:hi - lo] = mine.to(wire)
+        narrow = torch.empty(cap * self.world, dtype=wire, device=kmers.device)
+        dist.all_gather_into_tensor(narrow.view(torch.uint8), padded.view(torch.uint8), group=self.group)
+        gathered = narrow.to(torch.int64)
         # drop the padding of the short shards
         pieces = []
         for r in range(self.world):

@@ -51,6 +51,19 @@ def _worker(rank, world, port, n, k, ret):
         got = counter.count_kmers(torch.from_numpy(q))
         exp = ref.count_kmers(q)
         ok = np.array_equal(msbwt.sharded.as_u64(got), exp)
+        # counts that need the int32 and the int64 wire formats (1-mers of a 5000-run stream are large)
+        big = np.array([[1], [2], [3], [5], [0]], dtype=np.uint8)
+        wide_worker_calls = []
+
+        def fake_worker(kmers):  # exact but artificial magnitudes: 3, 70000, 2^40
+            vals = {1: 3, 2: 70000, 3: 1 << 40, 5: 5, 0: 0}
+            wide_worker_calls.append(len(kmers))
+            return torch.tensor([vals[int(x[0])] for x in kmers.numpy()], dtype=torch.int64)
+
+        for sel, want in (([0, 3], [3, 5]), ([0, 1, 3], [3, 70000, 5]), ([0, 1, 2, 3, 4], [3, 70000, 1 << 40, 5, 0])):
+            c2 = ShardedCounter(count_local=fake_worker)
+            out = c2.count_kmers(torch.from_numpy(big[sel]))
+            ok = ok and out.tolist() == want
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
