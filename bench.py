@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI, the real thing) or gloo (rehearsal of the N>1 path on fewer GPUs: "
                          "counts are gathered through host memory, ranks may share a GPU)")
+    ap.add_argument("--device-queries", action="store_true",
+                    help="workload big, random queries: generate the batch in HBM (torch PRNG) instead of uploading it -- "
+                         "BASELINE configs[4] asks for 1e9 queries, 31 GB that never need to exist on the host")
     ap.add_argument("--payload", default="auto", choices=["auto", "int64"],
                     help="N>1: auto = int16 counts on the wire when exact (falls back to int64), int64 = always wide")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -169,6 +172,7 @@ def main():
         % (rank, total, bwt.device_bytes() / 1e6, bwt.get_table_depth(), time.time() - t0))
 
     fused = args.fused and not big
+    device_sampled = False
     if fused:
         kind = "reads"
         nread, rlen = reads.shape
@@ -183,11 +187,27 @@ def main():
         t0 = time.time()
         queries = walk_kmers(torch, bwt, dev, total, nq, k, 4242 + rank)
         log("rank %d: %d present %d-mers by LF-walk on the GPU in %.1fs" % (rank, len(queries), k, time.time() - t0))
+    elif big and args.device_queries:
+        # uniform ACGT k-mers generated on the device; only the rows the oracle checks travel to the host
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(4242 + 1000 * rank)
+        d_q = torch.empty((nq, k), dtype=torch.uint8, device=dev)
+        chunk = 50_000_000
+        for lo_q in range(0, nq, chunk):
+            part = d_q[lo_q:lo_q + chunk]
+            part.random_(0, 4, generator=gen)      # 0..3
+            part.add_(1)                           # A C G -> 1 2 3
+            part.masked_fill_(part == 4, 5)        # T -> 5
+        rng = np.random.default_rng(7 + rank)
+        want = max(args.parity_sample, args.stats_sample or 1_000_000, args.cpu_sample)
+        sample_ids = np.sort(rng.choice(nq, size=min(nq, want), replace=False))
+        queries = d_q[torch.from_numpy(sample_ids).to(dev)].cpu().numpy()
+        device_sampled = True
     elif big:
         queries = synth.random_kmers(nq, k, 4242 + 1000 * rank)
     else:
         queries = make_queries(synth, cfg, reads, nq, k, cfg["qseed"] + 1000 * rank, kind)
-    if not fused:
+    if not fused and not device_sampled:
         nq = len(queries)
         d_q = torch.from_numpy(queries).to(dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -297,7 +317,7 @@ def main():
         "config": {
             "workload": ("big: structure-equivalent synthetic RLE stream (NOT a real BWT), %d symbols, mean run %.1f; "
                          "%d %s %d-mers per GPU per step" % (total, args.big_mean_run, nq,
-                                                             "present (LF-walk)" if kind == "walk" else "random", k)) if big else
+                                                             "present (LF-walk)" if kind == "walk" else "random, generated in HBM" if device_sampled else "random", k)) if big else
                         "%s: %d synthetic %d-bp reads (%.0fx of a %d-bp random genome, %.1f%% subst.) -> MSBWT of %d symbols; "
                         "%d %s %d-mers per GPU per step" % (
                             args.workload, len(reads), reads.shape[1], len(reads) * reads.shape[1] / max(1, int(cfg["genome"] * args.scale)),
@@ -320,10 +340,11 @@ def main():
             ref.load_vector(rle)
         else:
             ref.load_numpy_file(npy)
-        got = d_out.cpu().numpy().astype(np.uint64)
-        if fused:  # `queries` holds only the sampled windows; sample_ids are their positions in the output
-            got = got[sample_ids]
+        if fused or device_sampled:  # `queries` holds only sampled rows; sample_ids are their positions in the output
+            got = d_out[torch.from_numpy(sample_ids).to(dev)].cpu().numpy().astype(np.uint64)
             nq_all, nq = nq, len(queries)
+        else:
+            got = d_out.cpu().numpy().astype(np.uint64)
         ns = min(nq, args.parity_sample)
         sel = np.linspace(0, nq - 1, ns).astype(np.int64)
         exp = ref.count_kmers(queries[sel], nthreads=os.cpu_count() or 1)
@@ -339,7 +360,7 @@ def main():
         t0 = time.time()
         ref.count_kmers(queries[:nst], nthreads=ncpu, stats=st)
         t_all = time.time() - t0
-        if fused:
+        if fused or device_sampled:
             nq = nq_all
         alg_bytes = st.algorithmic_bytes(k) * (nq / nst)  # exact when nst == nq, else scaled from the sample
         kern_s = kernel_ms / 1e3 if launches else elapsed / args.steps
