@@ -90,27 +90,6 @@ __device__ __forceinline__ uint32_t pair_chunk_field(const uint4 c, uint32_t p) 
     return (p & 1u) ? odd : even;
 }
 
-// Range after prepending symbol a then symbol b (both ACGT, given as 2-bit codes).
-__device__ __forceinline__ Range constrain2(const uint4 *__restrict__ pair_blocks, const uint64_t *__restrict__ super,
-                                            uint32_t a2, uint32_t b2, uint64_t l, uint64_t h, uint32_t sub) {
-    const uint4 cl = pair_blocks[(l >> kPairShift) * kGroup + sub];
-    const uint4 ch = pair_blocks[(h >> kPairShift) * kGroup + sub];
-    const uint32_t p = a2 * 4u + b2;
-    // superblock index fits 16 bits (T < 2^40): one alignbit instead of a 64-bit shift
-    const uint64_t kl = super[__builtin_amdgcn_alignbit(uint32_t(l >> 32), uint32_t(l), kPairSuperShift) * 16u + p];
-    const uint64_t kh = super[__builtin_amdgcn_alignbit(uint32_t(h >> 32), uint32_t(h), kPairSuperShift) * 16u + p];
-    const int nl = min(max(int(uint32_t(l) & 127u) - int(sub * 16u), 0), 16);
-    const int nh = min(max(int(uint32_t(h) & 127u) - int(sub * 16u), 0), 16);
-    const uint32_t owner = (sub == (p >> 1)) ? ~0u : 0u;
-    // count (<= 128 summed) in the low byte, the owner's 24-bit field above it: no carries
-    const uint32_t tl = group_sum(pair_chunk_count(cl, a2, b2, nl) | ((pair_chunk_field(cl, p) << 8) & owner));
-    const uint32_t th = group_sum(pair_chunk_count(ch, a2, b2, nh) | ((pair_chunk_field(ch, p) << 8) & owner));
-    Range r;
-    r.l = kl + ((tl >> 8) + (tl & 0xFFu));
-    r.h = kh + ((th >> 8) + (th & 0xFFu));
-    return r;
-}
-
 // ---- the same two steps for 4-lane groups: a lane owns two adjacent chunks (32 bytes) of the
 // block, a wave carries 16 queries, and the group sum is two quad_perm steps --------------------
 __device__ __forceinline__ uint32_t quad_sum(uint32_t x) {
@@ -179,8 +158,8 @@ __device__ __forceinline__ uint64_t other_quad(uint64_t x) {  // value held by t
     return (uint64_t(hi) << 32) | lo;
 }
 
-// A step is split into its loads and its arithmetic so that a group can have the loads of two
-// independent queries in flight before either is consumed.
+// A step is written as its loads (issue_*) and its arithmetic (finish_*); constrain_split /
+// constrain2_split chain the two halves.
 struct StepLoads {
     uint4 c0, c1;
     uint64_t k;  // pair steps: superblock base; unused for single steps
