@@ -13,6 +13,13 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built artefacts (they are git-ignored): build them once (hipcc
+    # cross-compiles gfx950 without a GPU; gcc builds the oracle and the generators)
+    built = [os.path.join(ROOT, "rust-msbwt_amd", "libmsbwt_hip.so"), os.path.join(ROOT, "oracle", "libmsbwt_oracle.so"),
+             os.path.join(ROOT, "synth", "libmsbwt_synth.so")]
+    if not all(os.path.exists(p) for p in built):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
