@@ -116,7 +116,9 @@ int msbwt_rle_count_ragged_read_kmers(const msbwt_rle *bwt, const uint8_t *reads
 /* Depth of the precomputed suffix table (the reference's stubbed kmer_cache,
  * src/msbwt_core.rs:133-146): ranges for every ACGT suffix of length `depth` are computed
  * on the device at load time and replace the first `depth` steps of each query.  0 turns it
- * off.  Takes effect immediately if an index is loaded.  Results never change. */
+ * off, a negative value restores the automatic choice (the deepest table the data warrants
+ * within max(1 GiB, 2 x block bytes), at most 15), the maximum is 16 (64 GiB).  Takes effect
+ * immediately if an index is loaded.  Results never change. */
 int msbwt_rle_set_table_depth(msbwt_rle *bwt, int depth);
 int msbwt_rle_get_table_depth(const msbwt_rle *bwt);
 /* Pair index: a second block array (1 byte per symbol) that stores, next to each BWT symbol,
