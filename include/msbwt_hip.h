@@ -121,6 +121,14 @@ int msbwt_rle_count_ragged_read_kmers(const msbwt_rle *bwt, const uint8_t *reads
  * immediately if an index is loaded.  Results never change. */
 int msbwt_rle_set_table_depth(msbwt_rle *bwt, int depth);
 int msbwt_rle_get_table_depth(const msbwt_rle *bwt);
+/* Presence filter: one bit per ACGT suffix of length min(12, table depth), set when some table
+ * entry with that suffix is a non-empty range; at most 2 MiB, so it lives in L2 and decides
+ * absent k-mers (random queries, small genomes) without fetching the table line.  Built on the
+ * device from the table; dropped automatically when more than 90 % of its bits are set (it
+ * could reject almost nothing).  mode 0 = off, otherwise automatic (MSBWT_FILTER=0 in the
+ * environment turns it off).  get returns the filter depth, 0 if none.  Results never change. */
+int msbwt_rle_set_presence_filter(msbwt_rle *bwt, int mode);
+int msbwt_rle_get_presence_filter(const msbwt_rle *bwt);
 /* Pair index: a second block array (1 byte per symbol) that stores, next to each BWT symbol,
  * the symbol one LF step further, so that one search step consumes TWO k-mer symbols for one
  * line fetch per bound (maths: rust-msbwt_amd/csrc/rank_ops.hpp).  Built on the device from
@@ -128,7 +136,7 @@ int msbwt_rle_get_table_depth(const msbwt_rle *bwt);
  * (default; MSBWT_PAIR_INDEX=0/1 in the environment overrides).  Results never change. */
 int msbwt_rle_set_pair_index(msbwt_rle *bwt, int mode);
 int msbwt_rle_get_pair_index(const msbwt_rle *bwt);
-/* Bytes of HBM held by the index (blocks + table + pair index). */
+/* Bytes of HBM held by the index (blocks + table + filter + pair index). */
 uint64_t msbwt_rle_device_bytes(const msbwt_rle *bwt);
 /* Average duration in ms of the count kernel launches since the last reset, measured with
  * HIP events on the launch stream (bench.py's roofline uses it); resets the accumulator. */

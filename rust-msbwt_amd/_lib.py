@@ -35,6 +35,8 @@ SIGNATURES = {
     "msbwt_rle_count_read_kmers_device": (_int, [_vp, _vp, _sz, _sz, _sz, _int, _vp, _vp, _vp]),
     "msbwt_rle_set_table_depth": (_int, [_vp, _int]),
     "msbwt_rle_get_table_depth": (_int, [_vp]),
+    "msbwt_rle_set_presence_filter": (_int, [_vp, _int]),
+    "msbwt_rle_get_presence_filter": (_int, [_vp]),
     "msbwt_rle_set_pair_index": (_int, [_vp, _int]),
     "msbwt_rle_get_pair_index": (_int, [_vp]),
     "msbwt_rle_device_bytes": (_u64, [_vp]),

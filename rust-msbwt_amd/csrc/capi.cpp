@@ -32,6 +32,9 @@ struct msbwt_rle {
     int wanted_pair = -1;           // -1 = on when it fits comfortably, 0 = off, 1 = on
     void *d_table = nullptr;
     int table_depth = 0;         // depth of the table currently in HBM
+    uint32_t *d_filter = nullptr;   // presence bits over the low 2*filter_depth index bits of the table
+    int filter_depth = 0;
+    int wanted_filter = -1;         // -1 = keep it when it can reject something, 0 = off
     int wanted_table_depth = -1; // -1 = pick from the index size
     uint32_t *d_flags = nullptr;
     hipStream_t stream = nullptr;  // used by the host-pointer entry points
@@ -93,6 +96,9 @@ int hip_fail(msbwt_rle *h, hipError_t e, const char *what) {
 void release_index(msbwt_rle *h) {
     if (h->d_blocks) (void)hipFree(h->d_blocks);
     if (h->d_table) (void)hipFree(h->d_table);
+    if (h->d_filter) (void)hipFree(h->d_filter);
+    h->d_filter = nullptr;
+    h->filter_depth = 0;
     if (h->d_pair_blocks) (void)hipFree(h->d_pair_blocks);
     if (h->d_pair_super) (void)hipFree(h->d_pair_super);
     h->d_blocks = h->d_table = h->d_pair_blocks = h->d_pair_super = nullptr;
@@ -109,6 +115,8 @@ IndexView view_of(const msbwt_rle *h) {
     v.total = h->totals.total;
     v.table.entries = h->d_table;
     v.table.depth = h->d_table ? h->table_depth : 0;
+    v.table.filter = h->d_table ? h->d_filter : nullptr;
+    v.table.filter_depth = h->filter_depth;
     v.pair_blocks = h->d_pair_blocks;
     v.pair_super = static_cast<const uint64_t *>(h->d_pair_super);
     return v;
@@ -146,7 +154,42 @@ int auto_table_depth(uint64_t total, uint64_t block_bytes) {
     return d;
 }
 
+// Presence filter over the finished table: 4^min(12, depth) bits (<= 2 MiB, L2-sized).  Kept
+// only if it can reject something (less than 90 % of its bits set) -- on a large genome every
+// 12-mer occurs and the filter would be a wasted lookup.
+int rebuild_filter(msbwt_rle *h) {
+    if (h->d_filter) (void)hipFree(h->d_filter);
+    h->d_filter = nullptr;
+    h->filter_depth = 0;
+    if (!h->d_table || h->wanted_filter == 0 || h->table_depth < 6) return MSBWT_OK;
+    const int fd = std::min(12, h->table_depth);
+    const size_t words = (size_t(1) << (2 * fd)) / 32;
+    uint32_t *filter = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&filter), words * sizeof(uint32_t)));
+    hipError_t e = hipMemsetAsync(filter, 0, words * sizeof(uint32_t), h->stream);
+    if (e == hipSuccess) e = launch_build_filter(h->d_table, h->table_depth, fd, filter, h->stream);
+    std::vector<uint32_t> host(words);
+    if (e == hipSuccess) e = hipMemcpyAsync(host.data(), filter, words * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(filter);
+        return hip_fail(h, e, "build presence filter");
+    }
+    uint64_t set = 0;
+    for (uint32_t w : host) set += uint64_t(__builtin_popcount(w));
+    if (double(set) > 0.9 * double(words * 32)) {
+        (void)hipFree(filter);
+        return MSBWT_OK;
+    }
+    h->d_filter = filter;
+    h->filter_depth = fd;
+    return MSBWT_OK;
+}
+
 int rebuild_table(msbwt_rle *h) {
+    if (h->d_filter) (void)hipFree(h->d_filter);
+    h->d_filter = nullptr;
+    h->filter_depth = 0;
     if (h->d_table) (void)hipFree(h->d_table);
     h->d_table = nullptr;
     h->table_depth = 0;
@@ -165,7 +208,7 @@ int rebuild_table(msbwt_rle *h) {
     }
     h->d_table = tab;
     h->table_depth = depth;
-    return MSBWT_OK;
+    return rebuild_filter(h);
 }
 
 // Pair index (two symbols per step, rank_ops.hpp): 1 byte/symbol on top of the plane blocks,
@@ -350,6 +393,7 @@ msbwt_rle *msbwt_rle_new_on_device(uint8_t bin_power, int device) {
     h->device = device;
     if (const char *env = std::getenv("MSBWT_TABLE_DEPTH")) h->wanted_table_depth = std::atoi(env);
     if (const char *env = std::getenv("MSBWT_PAIR_INDEX")) h->wanted_pair = std::atoi(env) ? 1 : 0;
+    if (const char *env = std::getenv("MSBWT_FILTER")) h->wanted_filter = std::atoi(env) ? -1 : 0;
     return h;
 }
 
@@ -654,9 +698,22 @@ int msbwt_rle_set_pair_index(msbwt_rle *h, int mode) {
 
 int msbwt_rle_get_pair_index(const msbwt_rle *h) { return (h && h->d_pair_blocks) ? 1 : 0; }
 
+int msbwt_rle_set_presence_filter(msbwt_rle *h, int mode) {
+    if (!h || mode < -1 || mode > 1) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->wanted_filter = mode == 0 ? 0 : -1;
+    if (!h->loaded) return MSBWT_OK;
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    return rebuild_filter(h);
+}
+
+int msbwt_rle_get_presence_filter(const msbwt_rle *h) { return (h && h->d_filter) ? h->filter_depth : 0; }
+
 uint64_t msbwt_rle_device_bytes(const msbwt_rle *h) {
     if (!h || !h->loaded) return 0;
-    return h->nblocks * kBlockBytes + (h->d_table ? (uint64_t(16) << (2 * h->table_depth)) : 0) + h->pair_bytes;
+    return h->nblocks * kBlockBytes + (h->d_table ? (uint64_t(16) << (2 * h->table_depth)) : 0) + h->pair_bytes +
+           (h->d_filter ? (uint64_t(1) << (2 * h->filter_depth)) / 8 : 0);
 }
 
 int msbwt_rle_set_kernel_timing(msbwt_rle *h, int enabled) {

@@ -126,7 +126,7 @@ __device__ __forceinline__ void consume_symbols(uint32_t (&w)[kWords], int bits)
 template <bool kReads, int kLanes, bool kPair, int kWords>
 __global__ __launch_bounds__(256, kWords == 6 ? 5 : (kLanes == 4 ? 6 : 8)) void k_count_kmers_tiled(
     const uint4 *__restrict__ blocks, uint64_t total, const uint4 *__restrict__ table, uint32_t depth,
-    const uint4 *__restrict__ pair_blocks, const uint64_t *__restrict__ pair_super, const QuerySource src,
+    const uint32_t *__restrict__ filter, uint32_t filter_mask, const uint4 *__restrict__ pair_blocks, const uint64_t *__restrict__ pair_super, const QuerySource src,
     uint32_t *__restrict__ flags) {
     using Scratch = WaveScratchT<kWords>;
     using WorkItem = WorkItemT<kWords>;
@@ -253,7 +253,14 @@ __global__ __launch_bounds__(256, kWords == 6 ? 5 : (kLanes == 4 ? 6 : 8)) void 
                 atomicOr(flags, kFlagInvalidSymbol);
             } else {
                 if (use_table && acgt) {
-                    const uint4 e = table[tidx];
+                    // L2-resident presence bit first: an absent suffix never touches the table line
+                    bool maybe = true;
+                    if (filter != nullptr) {
+                        const uint32_t fi = tidx & filter_mask;
+                        maybe = ((filter[fi >> 5] >> (fi & 31u)) & 1u) != 0u;
+                    }
+                    uint4 e = make_uint4(0, 0, 0, 0);  // empty range: count 0
+                    if (maybe) e = table[tidx];
                     l = (uint64_t(e.y) << 32) | e.x;
                     h = (uint64_t(e.w) << 32) | e.z;
                     rem = k - depth;
@@ -381,6 +388,19 @@ __global__ __launch_bounds__(256) void k_table_level(const uint4 *__restrict__ b
     }
 }
 
+// bit (j & mask) of the presence filter is set when table entry j is a non-empty range
+__global__ __launch_bounds__(256) void k_table_filter(const uint4 *__restrict__ table, uint64_t entries, uint32_t mask,
+                                                      uint32_t *__restrict__ filter) {
+    const uint64_t stride = uint64_t(gridDim.x) * blockDim.x;
+    for (uint64_t j = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; j < entries; j += stride) {
+        const uint4 e = table[j];
+        if (e.x != e.z || e.y != e.w) {
+            const uint32_t i = uint32_t(j) & mask;
+            atomicOr(&filter[i >> 5], 1u << (i & 31u));
+        }
+    }
+}
+
 __global__ void k_table_root(uint4 *table, uint64_t total) {
     if (threadIdx.x == 0 && blockIdx.x == 0) table[0] = make_uint4(0u, 0u, uint32_t(total), uint32_t(total >> 32));
 }
@@ -413,8 +433,7 @@ __global__ __launch_bounds__(256) void k_constrain_ranges(const uint4 *__restric
 
 // The tiled kernel comes in 2 x 2 x 2 shapes; pick one and launch it.
 template <bool kReads>
-void launch_tiled(bool quad, bool pair, bool longk, dim3 grid, hipStream_t stream, const uint4 *blocks, uint64_t total,
-                  const uint4 *table, uint32_t depth, const uint4 *pair_blocks, const uint64_t *pair_super,
+void launch_tiled(bool quad, bool pair, bool longk, dim3 grid, hipStream_t stream, const IndexView &ix,
                   const QuerySource &src, uint32_t *flags);
 
 // Lanes per query in the tiled kernel: 8 (default) or 4 (MSBWT_GROUP_LANES=4)
@@ -440,11 +459,18 @@ inline bool use_pair_steps(const IndexView &ix, uint32_t k) {
 }
 
 template <bool kReads>
-void launch_tiled(bool quad, bool pair, bool longk, dim3 grid, hipStream_t stream, const uint4 *blocks, uint64_t total,
-                  const uint4 *table, uint32_t depth, const uint4 *pair_blocks, const uint64_t *pair_super,
+void launch_tiled(bool quad, bool pair, bool longk, dim3 grid, hipStream_t stream, const IndexView &ix,
                   const QuerySource &src, uint32_t *flags) {
+    const uint4 *blocks = static_cast<const uint4 *>(ix.blocks);
+    const uint4 *table = static_cast<const uint4 *>(ix.table.entries);
+    const uint32_t depth = uint32_t(ix.table.depth);
+    const uint32_t *filter = table ? ix.table.filter : nullptr;
+    const uint32_t filter_mask = filter ? uint32_t((1ull << (2 * ix.table.filter_depth)) - 1ull) : 0u;
+    const uint4 *pair_blocks = static_cast<const uint4 *>(ix.pair_blocks);
+    const uint64_t *pair_super = ix.pair_super;
+    const uint64_t total = ix.total;
 #define MSBWT_LAUNCH(L, P, W) \
-    hipLaunchKernelGGL((k_count_kmers_tiled<kReads, L, P, W>), grid, dim3(256), 0, stream, blocks, total, table, depth, pair_blocks, pair_super, src, flags)
+    hipLaunchKernelGGL((k_count_kmers_tiled<kReads, L, P, W>), grid, dim3(256), 0, stream, blocks, total, table, depth, filter, filter_mask, pair_blocks, pair_super, src, flags)
     if (longk) {  // 33 <= k <= 64: 8-lane groups
         if (pair) MSBWT_LAUNCH(8, true, 6); else MSBWT_LAUNCH(8, false, 6);
     } else if (quad) {
@@ -470,9 +496,7 @@ hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_
         src.n = n;
         src.k = k;
         src.out_fwd = counts;
-        launch_tiled<false>(quad, use_pair_steps(ix, k), k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, blocks, ix.total,
-                            static_cast<const uint4 *>(ix.table.entries), uint32_t(ix.table.depth),
-                            static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags);
+        launch_tiled<false>(quad, use_pair_steps(ix, k), k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, ix, src, flags);
     } else {
         hipLaunchKernelGGL(k_count_kmers_generic, dim3(grid_for(n * kGroup)), dim3(256), 0, stream, blocks,
                            ix.total, kmers, k, n, counts, flags);
@@ -497,9 +521,7 @@ hipError_t launch_count_read_kmers(const IndexView &ix, const uint8_t *reads, ui
     src.out_rc = out_rc;
     src.n = n_reads * src.windows * (src.strands == 3u ? 2u : 1u);
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
-    launch_tiled<true>(quad, use_pair_steps(ix, k), k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, static_cast<const uint4 *>(ix.blocks),
-                       ix.total, static_cast<const uint4 *>(ix.table.entries), uint32_t(ix.table.depth),
-                       static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags);
+    launch_tiled<true>(quad, use_pair_steps(ix, k), k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, ix, src, flags);
     return hipGetLastError();
 }
 
@@ -522,9 +544,7 @@ hipError_t launch_count_ragged_read_kmers(const IndexView &ix, const uint8_t *re
     src.n_reads = n_reads;
     src.n = n_windows * (src.strands == 3u ? 2u : 1u);
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
-    launch_tiled<true>(quad, use_pair_steps(ix, k), k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, static_cast<const uint4 *>(ix.blocks),
-                       ix.total, static_cast<const uint4 *>(ix.table.entries), uint32_t(ix.table.depth),
-                       static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags);
+    launch_tiled<true>(quad, use_pair_steps(ix, k), k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, ix, src, flags);
     return hipGetLastError();
 }
 
@@ -546,6 +566,14 @@ hipError_t launch_build_table(const IndexView &ix, int depth, void *entries, hip
         hipLaunchKernelGGL(k_table_level, dim3(grid_for(parents * kGroup)), dim3(256), 0, stream,
                            static_cast<const uint4 *>(ix.blocks), table, uint32_t(level));
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_build_filter(const void *entries, int depth, int filter_depth, uint32_t *filter, hipStream_t stream) {
+    if (depth < 1 || filter_depth < 1 || filter_depth > depth || filter_depth > 16) return hipErrorInvalidValue;
+    const uint64_t n = 1ull << (2 * depth);
+    const uint32_t mask = uint32_t((1ull << (2 * filter_depth)) - 1ull);
+    hipLaunchKernelGGL(k_table_filter, dim3(grid_for(n)), dim3(256), 0, stream, static_cast<const uint4 *>(entries), n, mask, filter);
     return hipGetLastError();
 }
 

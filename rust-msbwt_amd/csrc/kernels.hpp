@@ -14,6 +14,11 @@ constexpr uint32_t kFlagInvalidRange = 2u;
 struct TableView {
     const void *entries;  // uint4-aligned {l, h} pairs, 4^depth of them, or nullptr
     int depth;            // 0 = no table
+    // presence filter: bit i = "some table entry whose low 2*filter_depth index bits equal i is
+    // non-empty"; small enough (<= 2 MiB) to live in L2, it decides absent k-mers without the
+    // random table line.  nullptr = none.
+    const uint32_t *filter = nullptr;
+    int filter_depth = 0;
 };
 
 struct IndexView {
@@ -52,5 +57,7 @@ hipError_t launch_constrain_ranges(const IndexView &ix, const uint8_t *syms, con
 // Fills the suffix table of `depth` symbols (entries: 4^depth x {l,h}) by backward search
 // on the device.
 hipError_t launch_build_table(const IndexView &ix, int depth, void *entries, hipStream_t stream);
+// filter (zero-filled, 4^filter_depth bits) from a finished table of `depth` levels
+hipError_t launch_build_filter(const void *entries, int depth, int filter_depth, uint32_t *filter, hipStream_t stream);
 
 }  // namespace msbwt

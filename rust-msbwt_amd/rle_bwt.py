@@ -197,6 +197,16 @@ class RleBWT(BWT):
     def get_table_depth(self):
         return int(_lib.lib().msbwt_rle_get_table_depth(self._h))
 
+    def set_presence_filter(self, mode):
+        """0 = no presence filter, anything else = automatic (kept when it can reject something)."""
+        rc = _lib.lib().msbwt_rle_set_presence_filter(self._h, mode)
+        if rc:
+            _raise(rc, self._h)
+
+    def get_presence_filter(self):
+        """Depth of the L2-resident presence filter in front of the suffix table, 0 if none."""
+        return int(_lib.lib().msbwt_rle_get_presence_filter(self._h))
+
     def set_pair_index(self, mode):
         """1 = build the two-symbols-per-step index, 0 = drop it, -1 = automatic (default)."""
         rc = _lib.lib().msbwt_rle_set_pair_index(self._h, mode)

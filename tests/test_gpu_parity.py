@@ -513,8 +513,9 @@ def test_introspection():
     b.set_pair_index(0)
     b.set_table_depth(0)
     assert b.device_bytes() == blocks * 128 and b.get_table_depth() == 0 and not b.get_pair_index()
+    assert b.get_presence_filter() == 0
     b.set_table_depth(4)
-    assert b.device_bytes() == blocks * 128 + 16 * 4 ** 4
+    assert b.device_bytes() == blocks * 128 + 16 * 4 ** 4 and b.get_presence_filter() == 0  # table too shallow
     b.set_pair_index(1)
     assert b.get_pair_index() and b.device_bytes() > blocks * 128 * 3
     assert b.device_ordinal() == 0
@@ -535,3 +536,26 @@ def test_sharded_counter_single_gpu_worker():
     got = counter.count_kmers(torch.from_numpy(q).to("cuda:0"))
     torch.cuda.synchronize()
     assert np.array_equal(as_u64(got), o.count_kmers(q))
+
+
+@pytest.mark.parametrize("filt", [0, 1])
+def test_presence_filter_never_changes_results(filt):
+    """The L2-resident presence bitmap in front of the suffix table: on a small genome most random
+    k-mers are rejected by it, and counts stay identical with and without it."""
+    reads, rle = _real_bwt(31, 300, 64)
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    for depth in (6, 8, 9):
+        b.set_table_depth(depth)
+        b.set_presence_filter(filt)
+        assert (b.get_presence_filter() == depth) == bool(filt)      # sparse enough to be kept
+        for k in (depth, depth + 1, 21, 31, 40):
+            qs = [orc.convert_stoi(r[p:p + k]) for r in reads if len(r) >= k for p in (int(np.random.default_rng(k).integers(0, len(r) - k + 1)),)]
+            qs = np.concatenate([np.array(qs, dtype=np.uint8), random_kmers(k, 3000, k),
+                                 random_kmers(k + 3, 300, k, alphabet=(0, 1, 2, 3, 4, 5))])
+            assert np.array_equal(b.count_kmers(qs), o.count_kmers(qs)), (filt, depth, k)
+    # a saturated index (every short suffix present) drops the filter by itself
+    dense = gpu_bwt(random_stream(5, 200000, "short", alphabet=(1, 2, 3, 5)))
+    dense.set_table_depth(6)
+    assert dense.get_presence_filter() == 0

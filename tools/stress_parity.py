@@ -50,6 +50,7 @@ def main():
             depth = int(rng.integers(0, 9))
             b.set_table_depth(depth)
             b.set_pair_index(int(rng.integers(0, 2)))
+            b.set_presence_filter(int(rng.integers(0, 2)))
             k = int(rng.integers(1, 72))
             n = int(rng.integers(1, 700))
             qs = [random_kmers(int(rng.integers(0, 1 << 30)), n, k),
