@@ -176,9 +176,16 @@ __global__ __launch_bounds__(256, kWords == 6 ? 5 : (kLanes == 4 ? 6 : 8)) void 
         for (int i = 0; i < kPieces; ++i) staged[i] = load_piece(q0, nbytes, lane + 64u * i);
     }
 
+    // The presence filter only pays when it rejects queries.  Each wave watches its own pass
+    // rate: a tile in which >= 90 % of the looked-up queries passed switches the filter off for
+    // the next 7 tiles, then it is probed again (all wave-uniform).
+    uint32_t filter_pause = 0;
+
     for (uint64_t tile = wave_id; tile < ntiles; tile += nwaves) {
         const uint64_t q0 = tile * kTile;
         const uint32_t in_tile = uint32_t(min(uint64_t(kTile), n - q0));
+        const bool filter_now = filter != nullptr && filter_pause == 0;
+        bool looked_up = false, passed = false;
         // ---- phase 1a: the tile's bytes (contiguous, 16-byte aligned) go through LDS ----
         if (!kReads) {
             if (!kPrefetch) {
@@ -255,9 +262,11 @@ __global__ __launch_bounds__(256, kWords == 6 ? 5 : (kLanes == 4 ? 6 : 8)) void 
                 if (use_table && acgt) {
                     // L2-resident presence bit first: an absent suffix never touches the table line
                     bool maybe = true;
-                    if (filter != nullptr) {
+                    if (filter_now) {
                         const uint32_t fi = tidx & filter_mask;
                         maybe = ((filter[fi >> 5] >> (fi & 31u)) & 1u) != 0u;
+                        looked_up = true;
+                        passed = maybe;
                     }
                     uint4 e = make_uint4(0, 0, 0, 0);  // empty range: count 0
                     if (maybe) e = table[tidx];
@@ -276,6 +285,14 @@ __global__ __launch_bounds__(256, kWords == 6 ? 5 : (kLanes == 4 ? 6 : 8)) void 
 #pragma unroll
                     for (int i = 0; i < kWords; ++i) w[i] = uint32_t(bits[i >> 1] >> ((i & 1) * 32));
                 }
+            }
+        }
+        if (filter != nullptr) {
+            if (filter_now) {
+                const uint32_t nlook = uint32_t(__popcll(__ballot(looked_up))), npass = uint32_t(__popcll(__ballot(passed)));
+                if (nlook > 0 && npass * 10u >= nlook * 9u) filter_pause = 7;
+            } else {
+                --filter_pause;
             }
         }
         // compact the undecided queries into the work list: ballot + prefix count
