@@ -45,6 +45,7 @@ extern "C" {
 #define MSBWT_ERR_NOT_LOADED (-7)
 #define MSBWT_ERR_TOO_LARGE (-8)       /* total symbols >= 2^40 (device block counts are 40-bit) */
 #define MSBWT_ERR_INVALID_ARG (-9)
+#define MSBWT_ERR_INTERNAL (-10)       /* a device-side consistency check failed (a bug, not bad input) */
 
 typedef struct msbwt_rle msbwt_rle; /* opaque; replaces `struct RleBWT` (src/rle_bwt.rs:14-24) */
 
@@ -136,6 +137,13 @@ int msbwt_rle_get_presence_filter(const msbwt_rle *bwt);
  * (default; MSBWT_PAIR_INDEX=0/1 in the environment overrides).  Results never change. */
 int msbwt_rle_set_pair_index(msbwt_rle *bwt, int mode);
 int msbwt_rle_get_pair_index(const msbwt_rle *bwt);
+/* Search kernel for 1 <= k <= 64: 0 = automatic (default), 1 = 8 lanes per query, lines in
+ * registers (kernels.hip; best when most of a query is decided by the suffix table), 2 = one
+ * query per lane, lines staged through LDS by LDS-DMA (lanes.hip; best for long searches -- it
+ * keeps 8x more random lines in flight per wave).  MSBWT_SEARCH=groups|lanes in the environment
+ * sets the initial mode.  Results never change. */
+int msbwt_rle_set_search_kernel(msbwt_rle *bwt, int mode);
+int msbwt_rle_get_search_kernel(const msbwt_rle *bwt);
 /* Bytes of HBM held by the index (blocks + table + filter + pair index). */
 uint64_t msbwt_rle_device_bytes(const msbwt_rle *bwt);
 /* Average duration in ms of the count kernel launches since the last reset, measured with

@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(HERE, "libmsbwt_hip.so")
 
 OK = 0
 ERR_IO, ERR_UNEXPECTED_EOF, ERR_BAD_HEADER, ERR_INVALID_SYMBOL = -1, -2, -3, -4
-ERR_INVALID_RANGE, ERR_HIP, ERR_NOT_LOADED, ERR_TOO_LARGE, ERR_INVALID_ARG = -5, -6, -7, -8, -9
+ERR_INVALID_RANGE, ERR_HIP, ERR_NOT_LOADED, ERR_TOO_LARGE, ERR_INVALID_ARG, ERR_INTERNAL = -5, -6, -7, -8, -9, -10
 
 SIZE_MAX = C.c_size_t(-1).value
 
@@ -37,6 +37,8 @@ SIGNATURES = {
     "msbwt_rle_get_table_depth": (_int, [_vp]),
     "msbwt_rle_set_presence_filter": (_int, [_vp, _int]),
     "msbwt_rle_get_presence_filter": (_int, [_vp]),
+    "msbwt_rle_set_search_kernel": (_int, [_vp, _int]),
+    "msbwt_rle_get_search_kernel": (_int, [_vp]),
     "msbwt_rle_set_pair_index": (_int, [_vp, _int]),
     "msbwt_rle_get_pair_index": (_int, [_vp]),
     "msbwt_rle_device_bytes": (_u64, [_vp]),

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -36,6 +37,10 @@ struct msbwt_rle {
     int filter_depth = 0;
     int wanted_filter = -1;         // -1 = keep it when it can reject something, 0 = off
     int wanted_table_depth = -1; // -1 = pick from the index size
+    int search_kernel = kSearchAuto;
+    // device status block (128 bytes): word 0 = flags of the host-pointer entry points (handle
+    // stream), word 1 = flags of the *_device entry points (caller streams; read and cleared only by
+    // msbwt_rle_device_status), bytes 64.. = 8 x u64 record of a failed device consistency check
     uint32_t *d_flags = nullptr;
     hipStream_t stream = nullptr;  // used by the host-pointer entry points
     void *d_stage = nullptr;
@@ -51,6 +56,8 @@ struct msbwt_rle {
 namespace {
 
 constexpr int kMaxTableDepth = 16;  // 4^16 x 16 B = 64 GiB
+constexpr size_t kStatusBytes = 128;
+constexpr int kHostFlags = 0, kDeviceFlags = 1;  // words of the status block
 
 const char *kVersion = "rust-msbwt_amd 0.1.0 (gfx950 plane-block index)";
 
@@ -119,14 +126,16 @@ IndexView view_of(const msbwt_rle *h) {
     v.table.filter_depth = h->filter_depth;
     v.pair_blocks = h->d_pair_blocks;
     v.pair_super = static_cast<const uint64_t *>(h->d_pair_super);
+    v.search_kernel = h->search_kernel;
+    v.debug = h->d_flags ? reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(h->d_flags) + 64) : nullptr;
     return v;
 }
 
 int ensure_runtime(msbwt_rle *h) {
     if (!h->stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     if (!h->d_flags) {
-        HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_flags), sizeof(uint32_t)));
-        HIP_TRY(h, hipMemset(h->d_flags, 0, sizeof(uint32_t)));
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_flags), kStatusBytes));
+        HIP_TRY(h, hipMemset(h->d_flags, 0, kStatusBytes));
     }
     return MSBWT_OK;
 }
@@ -340,14 +349,25 @@ int install(msbwt_rle *h, const uint8_t *rle, size_t n) {
     return MSBWT_OK;
 }
 
-int read_flags(msbwt_rle *h, hipStream_t stream, uint32_t *flags) {
-    HIP_TRY(h, hipMemcpyAsync(flags, h->d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(h, hipMemsetAsync(h->d_flags, 0, sizeof(uint32_t), stream));
+// Reads and clears one flag word of the status block on `stream` (synchronises it).
+int read_flags(msbwt_rle *h, hipStream_t stream, int which, uint32_t *flags) {
+    HIP_TRY(h, hipMemcpyAsync(flags, h->d_flags + which, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_flags + which, 0, sizeof(uint32_t), stream));
     HIP_TRY(h, hipStreamSynchronize(stream));
     return MSBWT_OK;
 }
 
 int flags_to_code(msbwt_rle *h, uint32_t flags) {
+    if (flags & kFlagInternal) {
+        uint64_t rec[8] = {0};
+        (void)hipMemcpy(rec, reinterpret_cast<char *>(h->d_flags) + 64, sizeof rec, hipMemcpyDeviceToHost);
+        (void)hipMemset(reinterpret_cast<char *>(h->d_flags) + 64, 0, sizeof rec);
+        char buf[256];
+        std::snprintf(buf, sizeof buf, "device consistency check failed: range [%llu, %llu) outside the index (rem|slot %#llx, symbols %#llx, wave|lane %#llx)",
+                      (unsigned long long)rec[1], (unsigned long long)rec[2], (unsigned long long)rec[3], (unsigned long long)rec[4],
+                      (unsigned long long)rec[5]);
+        return fail(h, MSBWT_ERR_INTERNAL, buf);
+    }
     if (flags & kFlagInvalidSymbol) return fail(h, MSBWT_ERR_INVALID_SYMBOL, "a query holds a symbol code >= 6");
     if (flags & kFlagInvalidRange) return fail(h, MSBWT_ERR_INVALID_RANGE, "a range has l > h or h > total size");
     return MSBWT_OK;
@@ -372,10 +392,10 @@ int timed_launch(msbwt_rle *h, hipStream_t stream, Launch &&launch) {
     return MSBWT_OK;
 }
 
-int launch_count(msbwt_rle *h, const uint8_t *d_kmers, size_t k, size_t n, uint64_t *d_out, hipStream_t stream) {
+int launch_count(msbwt_rle *h, const uint8_t *d_kmers, size_t k, size_t n, uint64_t *d_out, hipStream_t stream, int which) {
     if (k > 0xFFFFFFFFull) return fail(h, MSBWT_ERR_INVALID_ARG, "k does not fit 32 bits");
     return timed_launch(h, stream, [&] {
-        return launch_count_kmers(view_of(h), d_kmers, uint32_t(k), n, d_out, h->d_flags, stream);
+        return launch_count_kmers(view_of(h), d_kmers, uint32_t(k), n, d_out, h->d_flags + which, stream);
     });
 }
 
@@ -394,6 +414,8 @@ msbwt_rle *msbwt_rle_new_on_device(uint8_t bin_power, int device) {
     if (const char *env = std::getenv("MSBWT_TABLE_DEPTH")) h->wanted_table_depth = std::atoi(env);
     if (const char *env = std::getenv("MSBWT_PAIR_INDEX")) h->wanted_pair = std::atoi(env) ? 1 : 0;
     if (const char *env = std::getenv("MSBWT_FILTER")) h->wanted_filter = std::atoi(env) ? -1 : 0;
+    if (const char *env = std::getenv("MSBWT_SEARCH"))
+        h->search_kernel = std::strcmp(env, "groups") == 0 ? kSearchGroups : std::strcmp(env, "lanes") == 0 ? kSearchLanes : kSearchAuto;
     return h;
 }
 
@@ -448,7 +470,7 @@ int msbwt_rle_count_kmers_device(const msbwt_rle *ch, const void *d_kmers, size_
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
     return launch_count(h, static_cast<const uint8_t *>(d_kmers), k, n, static_cast<uint64_t *>(d_out_counts),
-                        static_cast<hipStream_t>(hip_stream));
+                        static_cast<hipStream_t>(hip_stream), kDeviceFlags);
 }
 
 int msbwt_rle_constrain_ranges_device(const msbwt_rle *ch, const void *d_syms, const void *d_l, const void *d_h,
@@ -463,18 +485,18 @@ int msbwt_rle_constrain_ranges_device(const msbwt_rle *ch, const void *d_syms, c
     HIP_TRY(h, launch_constrain_ranges(view_of(h), static_cast<const uint8_t *>(d_syms),
                                        static_cast<const uint64_t *>(d_l), static_cast<const uint64_t *>(d_h), n,
                                        static_cast<uint64_t *>(d_out_l), static_cast<uint64_t *>(d_out_h),
-                                       h->d_flags, static_cast<hipStream_t>(hip_stream)));
+                                       h->d_flags + kDeviceFlags, static_cast<hipStream_t>(hip_stream)));
     return MSBWT_OK;
 }
 
 // Enqueues the fused read -> k-mer count kernel; the caller holds h->mu and has made the
 // handle's device current.
 static int launch_read_kmers_locked(msbwt_rle *h, const void *d_reads, size_t read_len, size_t n_reads, size_t k,
-                                    int ascii, void *d_out_fwd, void *d_out_rc, hipStream_t stream) {
+                                    int ascii, void *d_out_fwd, void *d_out_rc, hipStream_t stream, int which) {
     return timed_launch(h, stream, [&] {
         return launch_count_read_kmers(view_of(h), static_cast<const uint8_t *>(d_reads), uint32_t(read_len), n_reads,
                                        uint32_t(k), ascii != 0, static_cast<uint64_t *>(d_out_fwd),
-                                       static_cast<uint64_t *>(d_out_rc), h->d_flags, stream);
+                                       static_cast<uint64_t *>(d_out_rc), h->d_flags + which, stream);
     });
 }
 
@@ -489,7 +511,7 @@ int msbwt_rle_count_read_kmers_device(const msbwt_rle *ch, const void *d_reads, 
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
     return launch_read_kmers_locked(h, d_reads, read_len, n_reads, k, ascii, d_out_fwd, d_out_rc,
-                                    static_cast<hipStream_t>(hip_stream));
+                                    static_cast<hipStream_t>(hip_stream), kDeviceFlags);
 }
 
 int msbwt_rle_count_read_kmers(const msbwt_rle *ch, const uint8_t *reads, size_t read_len, size_t n_reads, size_t k,
@@ -514,12 +536,12 @@ int msbwt_rle_count_read_kmers(const msbwt_rle *ch, const uint8_t *reads, size_t
         uint8_t *d_r = static_cast<uint8_t *>(h->d_stage);
         uint64_t *d_f = reinterpret_cast<uint64_t *>(d_r + read_bytes), *d_c = d_f + m * windows;
         HIP_TRY(h, hipMemcpyAsync(d_r, reads + done * read_len, m * read_len, hipMemcpyHostToDevice, h->stream));
-        rc = launch_read_kmers_locked(h, d_r, read_len, m, k, ascii, out_fwd ? d_f : nullptr, out_rc ? d_c : nullptr, h->stream);
+        rc = launch_read_kmers_locked(h, d_r, read_len, m, k, ascii, out_fwd ? d_f : nullptr, out_rc ? d_c : nullptr, h->stream, kHostFlags);
         if (rc) return rc;
         if (out_fwd) HIP_TRY(h, hipMemcpyAsync(out_fwd + done * windows, d_f, cnt_bytes, hipMemcpyDeviceToHost, h->stream));
         if (out_rc) HIP_TRY(h, hipMemcpyAsync(out_rc + done * windows, d_c, cnt_bytes, hipMemcpyDeviceToHost, h->stream));
         uint32_t flags = 0;
-        rc = read_flags(h, h->stream, &flags);
+        rc = read_flags(h, h->stream, kHostFlags, &flags);
         if (rc) return rc;
         all_flags |= flags;
     }
@@ -579,7 +601,7 @@ int msbwt_rle_count_ragged_read_kmers(const msbwt_rle *ch, const uint8_t *reads,
             if (out_fwd) HIP_TRY(h, hipMemcpyAsync(out_fwd + win[r0], d_f, nwin * 8, hipMemcpyDeviceToHost, h->stream));
             if (out_rc) HIP_TRY(h, hipMemcpyAsync(out_rc + win[r0], d_c, nwin * 8, hipMemcpyDeviceToHost, h->stream));
             uint32_t flags = 0;
-            rc = read_flags(h, h->stream, &flags);  // synchronises: roff/woff may go out of scope
+            rc = read_flags(h, h->stream, kHostFlags, &flags);  // synchronises: roff/woff may go out of scope
             if (rc) return rc;
             all_flags |= flags;
         }
@@ -596,7 +618,7 @@ int msbwt_rle_device_status(const msbwt_rle *ch, void *hip_stream) {
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
     uint32_t flags = 0;
-    int rc = read_flags(h, static_cast<hipStream_t>(hip_stream), &flags);
+    int rc = read_flags(h, static_cast<hipStream_t>(hip_stream), kDeviceFlags, &flags);
     return rc ? rc : flags_to_code(h, flags);
 }
 
@@ -619,11 +641,11 @@ int msbwt_rle_count_kmers(const msbwt_rle *ch, const uint8_t *kmers, size_t k, s
     for (size_t done = 0; done < n; done += chunk) {
         const size_t m = std::min(chunk, n - done);
         if (k) HIP_TRY(h, hipMemcpyAsync(d_k, kmers + done * k, m * k, hipMemcpyHostToDevice, h->stream));
-        rc = launch_count(h, d_k, k, m, d_c, h->stream);
+        rc = launch_count(h, d_k, k, m, d_c, h->stream, kHostFlags);
         if (rc) return rc;
         HIP_TRY(h, hipMemcpyAsync(out_counts + done, d_c, m * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
         uint32_t flags = 0;
-        rc = read_flags(h, h->stream, &flags);
+        rc = read_flags(h, h->stream, kHostFlags, &flags);
         if (rc) return rc;
         all_flags |= flags;
     }
@@ -656,7 +678,7 @@ int msbwt_rle_constrain_ranges(const msbwt_rle *ch, const uint8_t *syms, const u
         HIP_TRY(h, hipMemcpyAsync(out_l + done, d_ol, m * 8, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipMemcpyAsync(out_h + done, d_oh, m * 8, hipMemcpyDeviceToHost, h->stream));
         uint32_t flags = 0;
-        rc = read_flags(h, h->stream, &flags);
+        rc = read_flags(h, h->stream, kHostFlags, &flags);
         if (rc) return rc;
         all_flags |= flags;
     }
@@ -710,6 +732,15 @@ int msbwt_rle_set_presence_filter(msbwt_rle *h, int mode) {
 
 int msbwt_rle_get_presence_filter(const msbwt_rle *h) { return (h && h->d_filter) ? h->filter_depth : 0; }
 
+int msbwt_rle_set_search_kernel(msbwt_rle *h, int mode) {
+    if (!h || mode < kSearchAuto || mode > kSearchLanes) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->search_kernel = mode;
+    return MSBWT_OK;
+}
+
+int msbwt_rle_get_search_kernel(const msbwt_rle *h) { return h ? h->search_kernel : 0; }
+
 uint64_t msbwt_rle_device_bytes(const msbwt_rle *h) {
     if (!h || !h->loaded) return 0;
     return h->nblocks * kBlockBytes + (h->d_table ? (uint64_t(16) << (2 * h->table_depth)) : 0) + h->pair_bytes +
@@ -748,7 +779,16 @@ int msbwt_rle_kernel_time_ms(const msbwt_rle *ch, double *avg_ms, uint64_t *laun
 
 int msbwt_rle_device_ordinal(const msbwt_rle *h) { return h ? h->device : -1; }
 
-const char *msbwt_rle_last_error(const msbwt_rle *h) { return h ? h->err.c_str() : "null handle"; }
+const char *msbwt_rle_last_error(const msbwt_rle *ch) {
+    msbwt_rle *h = const_cast<msbwt_rle *>(ch);
+    if (!h) return "null handle";
+    // query threads may be failing into h->err right now: copy it under the handle lock into a
+    // buffer owned by the calling thread (valid until this thread's next call)
+    thread_local std::string mine;
+    std::lock_guard<std::mutex> lock(h->mu);
+    mine = h->err;
+    return mine.c_str();
+}
 
 size_t msbwt_rle_download_blocks(const msbwt_rle *ch, void *out_blocks, size_t cap_blocks) {
     msbwt_rle *h = const_cast<msbwt_rle *>(ch);

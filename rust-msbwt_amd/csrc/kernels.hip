@@ -24,22 +24,12 @@
 
 #include "kernels.hpp"
 #include "rank_ops.hpp"
+#include "search_common.hpp"
 
 namespace msbwt {
 namespace {
 
-constexpr int kTile = 64;       // queries per wave tile
-constexpr int kMaxShortK = 32;  // tiled kernel, 3 dwords of packed symbols
-constexpr int kMaxTiledK = 64;  // tiled kernel, 6 dwords
 constexpr int kWavesPerBlock = 4;
-
-// compiler-level ordering of one wave's LDS writes before its later LDS reads (the LDS
-// executes a wave's operations in issue order; no s_barrier is needed inside a wave)
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // ---- count_kmers, any k: one query per group at a time, symbols read as needed ----------
 __global__ __launch_bounds__(256) void k_count_kmers_generic(const uint4 *__restrict__ blocks, uint64_t total,
@@ -68,14 +58,6 @@ __global__ __launch_bounds__(256) void k_count_kmers_generic(const uint4 *__rest
 }
 
 // ---- count_kmers, 1 <= k <= 64: tiled two-phase kernel -----------------------------------
-// kWords = dwords of packed symbols a query carries: 3 (k <= 32) or 6 (k <= 64).
-template <int kWords>
-struct alignas(16) WorkItemT {  // one undecided query of the tile: 32 bytes (kWords 3) or 48 (kWords 6)
-    uint32_t l_lo, l_hi, h_lo, h_hi;
-    uint32_t w[kWords];   // remaining symbols, 3 bits each, next step in the low bits
-    uint32_t rem_slot;    // remaining steps | slot in tile << 8
-};
-
 template <int kWords>
 struct WaveScratchT {
     static constexpr int kMaxK = kWords * 32 / 3;  // 32 or 64
@@ -83,45 +65,6 @@ struct WaveScratchT {
     WorkItemT<kWords> work[kTile];                 // 2 or 3 KiB
     uint64_t result[kTile];                        // 512 B
 };
-
-// Where a tile's queries come from and where their counts go.
-//   matrix mode: `data` = n x k symbol codes (the batch API); counts to out_fwd[q].
-//   reads mode:  `data` = n_reads x read_len bytes; query = one k-mer window of one read, on
-//                the forward strand and/or reverse-complemented (string_util.rs:12,45-50);
-//                bytes are symbol codes or ASCII (string_util.rs:15-32 mapping).  Query
-//                preparation -- convert_stoi, windowing, reverse_complement_i -- happens here,
-//                in registers, instead of on the host.
-struct QuerySource {
-    const uint8_t *data;
-    uint64_t n;          // queries (reads mode: windows x strands)
-    uint32_t k;
-    uint32_t read_len;   // reads mode
-    uint32_t windows;    // read_len - k + 1
-    uint32_t strands;    // bit 0: forward wanted, bit 1: reverse complement wanted
-    uint32_t ascii;
-    uint64_t *out_fwd, *out_rc;
-    // ragged reads (different lengths): read r occupies data[read_off[r] .. read_off[r+1]) and
-    // owns the global windows [win_off[r], win_off[r+1]); nullptr = fixed read_len
-    const uint64_t *read_off, *win_off;
-    uint64_t n_reads;
-};
-
-__device__ __forceinline__ uint32_t ascii_to_code(uint32_t c) {
-    if (c == 0x24u) return 0u;  // '$'
-    c &= 0xDFu;                 // fold lower case
-    return c == 0x41u ? 1u : c == 0x43u ? 2u : c == 0x47u ? 3u : c == 0x54u ? 5u : 4u;
-}
-__device__ __forceinline__ uint32_t complement_code(uint32_t s) {  // $ACGNT -> $TGCNA; 6,7 stay invalid
-    return s == 1u ? 5u : s == 5u ? 1u : s == 2u ? 3u : s == 3u ? 2u : s;
-}
-
-// drops the `bits` lowest bits of the packed symbols (3 or 6: one or two consumed symbols)
-template <int kWords>
-__device__ __forceinline__ void consume_symbols(uint32_t (&w)[kWords], int bits) {
-#pragma unroll
-    for (int i = 0; i + 1 < kWords; ++i) w[i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], bits);
-    w[kWords - 1] >>= bits;
-}
 
 template <bool kReads, int kLanes, bool kPair, int kWords>
 __global__ __launch_bounds__(256, kWords == 6 ? 5 : (kLanes == 4 ? 6 : 8)) void k_count_kmers_tiled(
@@ -131,7 +74,6 @@ __global__ __launch_bounds__(256, kWords == 6 ? 5 : (kLanes == 4 ? 6 : 8)) void 
     using Scratch = WaveScratchT<kWords>;
     using WorkItem = WorkItemT<kWords>;
     constexpr int kPieces = Scratch::kMaxK / 16;  // 16-byte pieces of a tile per lane: 2 or 4
-    constexpr int kBits = (kWords + 1) / 2;       // u64 words of packed symbols during setup
     __shared__ Scratch scratch[kWavesPerBlock];
     const uint8_t *__restrict__ kmers = src.data;
     const uint32_t k = src.k;
@@ -148,19 +90,7 @@ __global__ __launch_bounds__(256, kWords == 6 ? 5 : (kLanes == 4 ? 6 : 8)) void 
     const uint64_t nwaves = uint64_t(gridDim.x) * kWavesPerBlock;
     const bool use_table = table != nullptr && depth > 0 && k >= depth;
 
-    // Piece `piece` (16 bytes) of a tile's query bytes; the batch's ragged end is read bytewise so
-    // that nothing past the caller's buffer is touched.
-    auto load_piece = [&](uint64_t tile_q0, uint32_t nbytes, uint32_t piece) -> uint4 {
-        const uint8_t *src_bytes = kmers + tile_q0 * k;
-        if (piece * 16u >= nbytes) return make_uint4(0, 0, 0, 0);
-        if (piece * 16u + 16u <= nbytes) return *reinterpret_cast<const uint4 *>(src_bytes + piece * 16u);
-        uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-        for (uint32_t b = piece * 16u; b < nbytes; ++b) {
-            const uint32_t v = uint32_t(src_bytes[b]) << ((b & 3u) * 8u), word = (b & 15u) >> 2;
-            if (word == 0u) w0 |= v; else if (word == 1u) w1 |= v; else if (word == 2u) w2 |= v; else w3 |= v;
-        }
-        return make_uint4(w0, w1, w2, w3);
-    };
+    const TableEnv env{table, depth, use_table, filter, filter_mask, total};
     // A tile is at most 64 x kMaxK bytes = kPieces pieces per lane, all loads in flight at once.
     // In the lean k <= 32 variant (short searches, e.g. C2, where setup dominates) the loads of
     // the NEXT tile are issued before the current tile is searched, hiding their latency; the
@@ -173,7 +103,7 @@ __global__ __launch_bounds__(256, kWords == 6 ? 5 : (kLanes == 4 ? 6 : 8)) void 
         const uint64_t q0 = wave_id * kTile;
         const uint32_t nbytes = uint32_t(min(uint64_t(kTile), n - q0)) * k;
 #pragma unroll
-        for (int i = 0; i < kPieces; ++i) staged[i] = load_piece(q0, nbytes, lane + 64u * i);
+        for (int i = 0; i < kPieces; ++i) staged[i] = load_piece(kmers + q0 * k, nbytes, lane + 64u * i);
     }
 
     // The presence filter only pays when it rejects queries.  Each wave watches its own pass
@@ -190,7 +120,7 @@ __global__ __launch_bounds__(256, kWords == 6 ? 5 : (kLanes == 4 ? 6 : 8)) void 
         if (!kReads) {
             if (!kPrefetch) {
 #pragma unroll
-                for (int i = 0; i < kPieces; ++i) staged[i] = load_piece(q0, in_tile * k, lane + 64u * i);
+                for (int i = 0; i < kPieces; ++i) staged[i] = load_piece(kmers + q0 * k, in_tile * k, lane + 64u * i);
             }
 #pragma unroll
             for (int i = 0; i < kPieces; ++i) ws.stage[lane + 64u * i] = staged[i];
@@ -199,7 +129,7 @@ __global__ __launch_bounds__(256, kWords == 6 ? 5 : (kLanes == 4 ? 6 : 8)) void 
                 const uint64_t nq0 = next_tile * kTile;
                 const uint32_t nbytes = uint32_t(min(uint64_t(kTile), n - nq0)) * k;
 #pragma unroll
-                for (int i = 0; i < kPieces; ++i) staged[i] = load_piece(nq0, nbytes, lane + 64u * i);
+                for (int i = 0; i < kPieces; ++i) staged[i] = load_piece(kmers + nq0 * k, nbytes, lane + 64u * i);
             }
         }
         wave_lds_sync();
@@ -210,82 +140,10 @@ __global__ __launch_bounds__(256, kWords == 6 ? 5 : (kLanes == 4 ? 6 : 8)) void 
 #pragma unroll
         for (int i = 0; i < kWords; ++i) w[i] = 0;
         if (lane < in_tile) {
-            uint64_t bits[kBits];  // symbol of step t (t = 0 first) at bits [3t, 3t+3) of the little-endian words
-#pragma unroll
-            for (int j = 0; j < kBits; ++j) bits[j] = 0;
-            uint32_t bad = 0, acgt = 1, tidx = 0;
-            const uint8_t *mine = stage_bytes + lane * k;
-            bool rc = false;
-            if (kReads) {  // window g of read r, forward or reverse-complemented
-                const uint64_t v = q0 + lane;
-                const uint64_t g = src.strands == 3u ? (v >> 1) : v;
-                rc = src.strands == 3u ? (v & 1u) != 0 : src.strands == 2u;
-                if (src.win_off == nullptr) {
-                    mine = kmers + (g / src.windows) * src.read_len + (g % src.windows);
-                } else {  // last read whose first window is <= g (reads shorter than k own none)
-                    uint64_t lo = 0, hi = src.n_reads;
-                    while (hi - lo > 1) {
-                        const uint64_t mid = (lo + hi) >> 1;
-                        if (src.win_off[mid] <= g) lo = mid; else hi = mid;
-                    }
-                    mine = kmers + src.read_off[lo] + (g - src.win_off[lo]);
-                }
-            }
-#pragma unroll 4
-            for (uint32_t t = 0; t < k; ++t) {
-                uint32_t s;
-                if (!kReads) {
-                    s = mine[k - 1u - t];
-                } else {
-                    // the search consumes a k-mer from its last symbol: forward window -> byte k-1-t;
-                    // reverse complement q'[j] = comp(window[k-1-j]) -> step t reads comp(window[t])
-                    s = rc ? mine[t] : mine[k - 1u - t];
-                    if (src.ascii) s = ascii_to_code(s);
-                    if (rc) s = complement_code(s);
-                }
-                bad |= (s >= 6u) ? 1u : 0u;
-                const uint32_t pos = 3u * t, word = pos >> 6, off = pos & 63u;
-#pragma unroll
-                for (int j = 0; j < kBits; ++j) {
-                    if (word == uint32_t(j)) bits[j] |= uint64_t(s & 7u) << off;
-                    if (j > 0 && word == uint32_t(j - 1) && off > 61u) bits[j] |= uint64_t(s & 7u) >> (64u - off);
-                }
-                if (t < depth) {  // table index: A C G T -> 0..3, step t at bits [2t, 2t+2)
-                    acgt &= acgt_bit(s);
-                    tidx |= (acgt_code(s) & 3u) << (2u * t);
-                }
-            }
-            if (bad) {
-                ws.result[lane] = ~0ull;
-                atomicOr(flags, kFlagInvalidSymbol);
-            } else {
-                if (use_table && acgt) {
-                    // L2-resident presence bit first: an absent suffix never touches the table line
-                    bool maybe = true;
-                    if (filter_now) {
-                        const uint32_t fi = tidx & filter_mask;
-                        maybe = ((filter[fi >> 5] >> (fi & 31u)) & 1u) != 0u;
-                        looked_up = true;
-                        passed = maybe;
-                    }
-                    uint4 e = make_uint4(0, 0, 0, 0);  // empty range: count 0
-                    if (maybe) e = table[tidx];
-                    l = (uint64_t(e.y) << 32) | e.x;
-                    h = (uint64_t(e.w) << 32) | e.z;
-                    rem = k - depth;
-                    const uint32_t sh = 3u * depth;  // 3..48
-#pragma unroll
-                    for (int j = 0; j < kBits; ++j)
-                        bits[j] = (bits[j] >> sh) | (j + 1 < kBits ? bits[j + 1] << (64u - sh) : 0ull);
-                }
-                if (rem == 0u || l == h) {
-                    ws.result[lane] = h - l;
-                } else {
-                    pending = true;
-#pragma unroll
-                    for (int i = 0; i < kWords; ++i) w[i] = uint32_t(bits[i >> 1] >> ((i & 1) * 32));
-                }
-            }
+            uint64_t result = 0;
+            pending = prepare_query<kReads, kWords>(src, env, stage_bytes + lane * k, q0 + lane, filter_now, flags, l, h, w, rem,
+                                                    result, looked_up, passed);
+            if (!pending) ws.result[lane] = result;
         }
         if (filter != nullptr) {
             if (filter_now) {
@@ -367,15 +225,7 @@ __global__ __launch_bounds__(256, kWords == 6 ? 5 : (kLanes == 4 ? 6 : 8)) void 
             }
         }
         wave_lds_sync();
-        if (lane < in_tile) {
-            if (!kReads) {
-                src.out_fwd[q0 + lane] = ws.result[lane];
-            } else {
-                const uint64_t v = q0 + lane;
-                if (src.strands == 3u) ((v & 1u) ? src.out_rc : src.out_fwd)[v >> 1] = ws.result[lane];
-                else (src.strands == 2u ? src.out_rc : src.out_fwd)[v] = ws.result[lane];
-            }
-        }
+        if (lane < in_tile) store_count<kReads>(src, q0 + lane, ws.result[lane]);
         wave_lds_sync();  // the next tile must not overwrite result[] / stage[] before this
     }
 }
@@ -462,17 +312,19 @@ inline bool use_quad_groups() {
     return quad;
 }
 
-// 256 CUs x 8 blocks of 256 threads fill the chip; smaller batches get just enough blocks
-inline uint32_t grid_for(uint64_t threads_wanted) {
-    const uint64_t blocks = (threads_wanted + 255) / 256;
-    return uint32_t(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
-}
-
+// Which search kernel (IndexView::search_kernel, msbwt_rle_set_search_kernel): the one-query-
+// per-lane kernel (lanes.hip) for long searches -- many symbols left after the table, throughput
+// set by random lines in flight -- and the 8-lane-group kernel above for short ones, where setup
+// (staging, table lookups) dominates and its 32 waves per CU hide that latency better.
 // Pair steps pay off when at least a few symbols remain after the table lookup; for shorter
 // tails the leaner single-step kernel is faster (C2: 21-mers behind a depth-13 table).
 inline bool use_pair_steps(const IndexView &ix, uint32_t k) {
     const uint32_t depth = (ix.table.entries && k >= uint32_t(ix.table.depth)) ? uint32_t(ix.table.depth) : 0u;
     return ix.pair_blocks != nullptr && k - depth >= 10u;
+}
+
+inline bool use_lanes_kernel(const IndexView &ix, uint32_t k) {
+    return ix.search_kernel == kSearchLanes || (ix.search_kernel == kSearchAuto && use_pair_steps(ix, k));
 }
 
 template <bool kReads>
@@ -513,6 +365,7 @@ hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_
         src.n = n;
         src.k = k;
         src.out_fwd = counts;
+        if (use_lanes_kernel(ix, k)) return launch_lanes(ix, src, false, use_pair_steps(ix, k), flags, stream);
         launch_tiled<false>(quad, use_pair_steps(ix, k), k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, ix, src, flags);
     } else {
         hipLaunchKernelGGL(k_count_kmers_generic, dim3(grid_for(n * kGroup)), dim3(256), 0, stream, blocks,
@@ -537,6 +390,7 @@ hipError_t launch_count_read_kmers(const IndexView &ix, const uint8_t *reads, ui
     src.out_fwd = out_fwd;
     src.out_rc = out_rc;
     src.n = n_reads * src.windows * (src.strands == 3u ? 2u : 1u);
+    if (use_lanes_kernel(ix, k)) return launch_lanes(ix, src, true, use_pair_steps(ix, k), flags, stream);
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
     launch_tiled<true>(quad, use_pair_steps(ix, k), k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, ix, src, flags);
     return hipGetLastError();
@@ -560,6 +414,7 @@ hipError_t launch_count_ragged_read_kmers(const IndexView &ix, const uint8_t *re
     src.win_off = win_off;
     src.n_reads = n_reads;
     src.n = n_windows * (src.strands == 3u ? 2u : 1u);
+    if (use_lanes_kernel(ix, k)) return launch_lanes(ix, src, true, use_pair_steps(ix, k), flags, stream);
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
     launch_tiled<true>(quad, use_pair_steps(ix, k), k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, ix, src, flags);
     return hipGetLastError();

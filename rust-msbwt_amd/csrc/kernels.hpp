@@ -9,6 +9,7 @@ namespace msbwt {
 // bits of the device status word
 constexpr uint32_t kFlagInvalidSymbol = 1u;
 constexpr uint32_t kFlagInvalidRange = 2u;
+constexpr uint32_t kFlagInternal = 4u;  // a device-side consistency check failed (never on a well-formed index)
 
 // One entry of the suffix table: the range after the last `depth` symbols of a k-mer.
 struct TableView {
@@ -21,6 +22,9 @@ struct TableView {
     int filter_depth = 0;
 };
 
+// which count_kmers kernel serves 1 <= k <= 64 (kernels.hip / lanes.hip)
+constexpr int kSearchAuto = 0, kSearchGroups = 1, kSearchLanes = 2;
+
 struct IndexView {
     const void *blocks;  // plane blocks, 128 B each
     uint64_t nblocks;
@@ -28,6 +32,8 @@ struct IndexView {
     TableView table;
     const void *pair_blocks = nullptr;      // optional: two symbols per step (rank_ops.hpp)
     const uint64_t *pair_super = nullptr;
+    int search_kernel = kSearchAuto;
+    uint64_t *debug = nullptr;  // 8 words: [0] != 0 once a consistency check has recorded its values in [1..]
 };
 
 // counts[q] = count_kmer(kmers[q*k .. q*k+k)) for q < n.  Sets kFlagInvalidSymbol in *flags

@@ -1,0 +1,216 @@
+// Device code shared by the two count_kmers kernels (kernels.hip: 8-lane groups, lanes.hip: one
+// query per lane): where a tile's queries come from, how one lane validates / packs its query
+// and looks it up in the suffix table, and where counts go.  HIP translation units only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "kernels.hpp"
+#include "rank_ops.hpp"
+
+namespace msbwt {
+
+// Where a tile's queries come from and where their counts go.
+//   matrix mode: `data` = n x k symbol codes (the batch API); counts to out_fwd[q].
+//   reads mode:  `data` = n_reads x read_len bytes; query = one k-mer window of one read, on
+//                the forward strand and/or reverse-complemented (string_util.rs:12,45-50);
+//                bytes are symbol codes or ASCII (string_util.rs:15-32 mapping).  Query
+//                preparation -- convert_stoi, windowing, reverse_complement_i -- happens here,
+//                in registers, instead of on the host.
+struct QuerySource {
+    const uint8_t *data;
+    uint64_t n;          // queries (reads mode: windows x strands)
+    uint32_t k;
+    uint32_t read_len;   // reads mode
+    uint32_t windows;    // read_len - k + 1
+    uint32_t strands;    // bit 0: forward wanted, bit 1: reverse complement wanted
+    uint32_t ascii;
+    uint64_t *out_fwd, *out_rc;
+    // ragged reads (different lengths): read r occupies data[read_off[r] .. read_off[r+1]) and
+    // owns the global windows [win_off[r], win_off[r+1]); nullptr = fixed read_len
+    const uint64_t *read_off, *win_off;
+    uint64_t n_reads;
+};
+
+namespace {
+
+constexpr int kTile = 64;       // queries per wave tile
+constexpr int kMaxShortK = 32;  // 3 dwords of packed symbols
+constexpr int kMaxTiledK = 64;  // 6 dwords
+
+// compiler-level ordering of one wave's LDS writes before its later LDS reads (the LDS
+// executes a wave's operations in issue order; no s_barrier is needed inside a wave)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// kWords = dwords of packed symbols a query carries: 3 (k <= 32) or 6 (k <= 64).
+template <int kWords>
+struct alignas(16) WorkItemT {  // one undecided query: 32 bytes (kWords 3) or 48 (kWords 6)
+    uint32_t l_lo, l_hi, h_lo, h_hi;
+    uint32_t w[kWords];   // remaining symbols, 3 bits each, next step in the low bits
+    uint32_t rem_slot;    // remaining steps | slot << 8
+};
+
+// the suffix table and its presence filter as the setup code sees them
+struct TableEnv {
+    const uint4 *table;
+    uint32_t depth;
+    bool use_table;        // table present and k >= depth
+    const uint32_t *filter;
+    uint32_t filter_mask;
+    uint64_t total;
+};
+
+__device__ __forceinline__ uint32_t ascii_to_code(uint32_t c) {
+    if (c == 0x24u) return 0u;  // '$'
+    c &= 0xDFu;                 // fold lower case
+    return c == 0x41u ? 1u : c == 0x43u ? 2u : c == 0x47u ? 3u : c == 0x54u ? 5u : 4u;
+}
+__device__ __forceinline__ uint32_t complement_code(uint32_t s) {  // $ACGNT -> $TGCNA; 6,7 stay invalid
+    return s == 1u ? 5u : s == 5u ? 1u : s == 2u ? 3u : s == 3u ? 2u : s;
+}
+
+// drops the `bits` lowest bits of the packed symbols (3 or 6: one or two consumed symbols)
+template <int kWords>
+__device__ __forceinline__ void consume_symbols(uint32_t (&w)[kWords], int bits) {
+#pragma unroll
+    for (int i = 0; i + 1 < kWords; ++i) w[i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], bits);
+    w[kWords - 1] >>= bits;
+}
+
+// Piece `piece` (16 bytes) of a tile's `nbytes` contiguous query bytes starting at src_bytes
+// (16-byte aligned); the batch's ragged end is read bytewise so that nothing past the caller's
+// buffer is touched.
+__device__ __forceinline__ uint4 load_piece(const uint8_t *__restrict__ src_bytes, uint32_t nbytes, uint32_t piece) {
+    if (piece * 16u >= nbytes) return make_uint4(0, 0, 0, 0);
+    if (piece * 16u + 16u <= nbytes) return *reinterpret_cast<const uint4 *>(src_bytes + piece * 16u);
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    for (uint32_t b = piece * 16u; b < nbytes; ++b) {
+        const uint32_t v = uint32_t(src_bytes[b]) << ((b & 3u) * 8u), word = (b & 15u) >> 2;
+        if (word == 0u) w0 |= v; else if (word == 1u) w1 |= v; else if (word == 2u) w2 |= v; else w3 |= v;
+    }
+    return make_uint4(w0, w1, w2, w3);
+}
+
+// count of query v (global index) goes to its place in the caller's output
+template <bool kReads>
+__device__ __forceinline__ void store_count(const QuerySource &src, uint64_t v, uint64_t value) {
+    if (!kReads) {
+        src.out_fwd[v] = value;
+    } else if (src.strands == 3u) {
+        ((v & 1u) ? src.out_rc : src.out_fwd)[v >> 1] = value;
+    } else {
+        (src.strands == 2u ? src.out_rc : src.out_fwd)[v] = value;
+    }
+}
+
+// One lane = one query: validate (symbols >= 6 -> result u64::MAX + status flag, the reference
+// asserts, msbwt_core.rs:127), pack 3 bits/symbol in search order, look the last `depth` symbols
+// up in the suffix table (behind the presence filter when filter_now).  Returns true when a
+// search is still needed (l, h, w, rem filled), false when `result` already is the count.
+// Matrix mode: `staged` = this lane's k bytes in LDS; reads mode: v = global query index.
+template <bool kReads, int kWords>
+__device__ __forceinline__ bool prepare_query(const QuerySource &src, const TableEnv &env, const uint8_t *staged, uint64_t v,
+                                              bool filter_now, uint32_t *__restrict__ flags, uint64_t &l, uint64_t &h,
+                                              uint32_t (&w)[kWords], uint32_t &rem, uint64_t &result, bool &looked_up,
+                                              bool &passed) {
+    constexpr int kBits = (kWords + 1) / 2;  // u64 words of packed symbols during setup
+    const uint32_t k = src.k, depth = env.depth;
+    uint64_t bits[kBits];  // symbol of step t (t = 0 first) at bits [3t, 3t+3) of the little-endian words
+#pragma unroll
+    for (int j = 0; j < kBits; ++j) bits[j] = 0;
+    uint32_t bad = 0, acgt = 1, tidx = 0;
+    const uint8_t *mine = staged;
+    bool rc = false;
+    if (kReads) {  // window g of read r, forward or reverse-complemented
+        const uint64_t g = src.strands == 3u ? (v >> 1) : v;
+        rc = src.strands == 3u ? (v & 1u) != 0 : src.strands == 2u;
+        if (src.win_off == nullptr) {
+            mine = src.data + (g / src.windows) * src.read_len + (g % src.windows);
+        } else {  // last read whose first window is <= g (reads shorter than k own none)
+            uint64_t lo = 0, hi = src.n_reads;
+            while (hi - lo > 1) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (src.win_off[mid] <= g) lo = mid; else hi = mid;
+            }
+            mine = src.data + src.read_off[lo] + (g - src.win_off[lo]);
+        }
+    }
+#pragma unroll 4
+    for (uint32_t t = 0; t < k; ++t) {
+        uint32_t s;
+        if (!kReads) {
+            s = mine[k - 1u - t];
+        } else {
+            // the search consumes a k-mer from its last symbol: forward window -> byte k-1-t;
+            // reverse complement q'[j] = comp(window[k-1-j]) -> step t reads comp(window[t])
+            s = rc ? mine[t] : mine[k - 1u - t];
+            if (src.ascii) s = ascii_to_code(s);
+            if (rc) s = complement_code(s);
+        }
+        bad |= (s >= 6u) ? 1u : 0u;
+        const uint32_t pos = 3u * t, word = pos >> 6, off = pos & 63u;
+#pragma unroll
+        for (int j = 0; j < kBits; ++j) {
+            if (word == uint32_t(j)) bits[j] |= uint64_t(s & 7u) << off;
+            if (j > 0 && word == uint32_t(j - 1) && off > 61u) bits[j] |= uint64_t(s & 7u) >> (64u - off);
+        }
+        if (t < depth) {  // table index: A C G T -> 0..3, step t at bits [2t, 2t+2)
+            acgt &= acgt_bit(s);
+            tidx |= (acgt_code(s) & 3u) << (2u * t);
+        }
+    }
+    l = 0;
+    h = env.total;
+    rem = k;
+    if (bad) {
+        result = ~0ull;
+        atomicOr(flags, kFlagInvalidSymbol);
+        return false;
+    }
+    if (env.use_table && acgt) {
+        // L2-resident presence bit first: an absent suffix never touches the table line
+        bool maybe = true;
+        if (filter_now) {
+            const uint32_t fi = tidx & env.filter_mask;
+            maybe = ((env.filter[fi >> 5] >> (fi & 31u)) & 1u) != 0u;
+            looked_up = true;
+            passed = maybe;
+        }
+        uint4 e = make_uint4(0, 0, 0, 0);  // empty range: count 0
+        if (maybe) e = env.table[tidx];
+        l = (uint64_t(e.y) << 32) | e.x;
+        h = (uint64_t(e.w) << 32) | e.z;
+        rem = k - depth;
+        const uint32_t sh = 3u * depth;  // 3..48
+#pragma unroll
+        for (int j = 0; j < kBits; ++j)
+            bits[j] = (bits[j] >> sh) | (j + 1 < kBits ? bits[j + 1] << (64u - sh) : 0ull);
+    }
+    if (rem == 0u || l == h) {
+        result = h - l;
+        return false;
+    }
+#pragma unroll
+    for (int i = 0; i < kWords; ++i) w[i] = uint32_t(bits[i >> 1] >> ((i & 1) * 32));
+    return true;
+}
+
+// 256 CUs x 8 blocks of 256 threads fill the chip; smaller batches get just enough blocks
+inline uint32_t grid_for(uint64_t threads_wanted) {
+    const uint64_t blocks = (threads_wanted + 255) / 256;
+    return uint32_t(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
+}
+
+}  // namespace
+
+// lanes.hip: the one-query-per-lane search kernel (LDS-staged lines), 1 <= src.k <= 64; matrix
+// mode needs a 16-byte-aligned batch.
+hipError_t launch_lanes(const IndexView &ix, const QuerySource &src, bool reads, bool pair, uint32_t *flags,
+                        hipStream_t stream);
+
+}  // namespace msbwt

@@ -216,6 +216,17 @@ class RleBWT(BWT):
     def get_pair_index(self):
         return bool(_lib.lib().msbwt_rle_get_pair_index(self._h))
 
+    SEARCH_KERNELS = {"auto": 0, "groups": 1, "lanes": 2}
+
+    def set_search_kernel(self, mode):
+        """"auto" (default), "groups" (8 lanes per query) or "lanes" (one query per lane, LDS-staged lines)."""
+        rc = _lib.lib().msbwt_rle_set_search_kernel(self._h, self.SEARCH_KERNELS.get(mode, mode))
+        if rc:
+            _raise(rc, self._h)
+
+    def get_search_kernel(self):
+        return {v: k for k, v in self.SEARCH_KERNELS.items()}[int(_lib.lib().msbwt_rle_get_search_kernel(self._h))]
+
     def device_bytes(self):
         return int(_lib.lib().msbwt_rle_device_bytes(self._h))
 

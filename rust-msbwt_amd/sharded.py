@@ -10,15 +10,27 @@ torch / torch.distributed are plumbing here (device buffers, streams, the proces
 import numpy as np
 
 
+SHARD_ALIGN = 16  # queries
+
+
 def shard_bounds(n, world, rank):
-    """Contiguous, balanced slices: the first n % world ranks get one extra query."""
-    base, extra = divmod(n, world)
-    lo = rank * base + min(rank, extra)
-    return lo, lo + base + (1 if rank < extra else 0)
+    """Contiguous slices, balanced to within two 16-query units, every slice STARTING at a multiple of 16
+    queries: row `lo` of an (n, k) byte matrix then sits at a 16-byte-aligned address whatever k
+    is, which is what the tiled kernel's staged loads need (an unaligned batch silently takes the
+    slow generic kernel -- include/msbwt_hip.h, "alignment")."""
+    units = -(-n // SHARD_ALIGN)
+    base, extra = divmod(units, world)
+    lo_u = rank * base + min(rank, extra)
+    hi_u = lo_u + base + (1 if rank < extra else 0)
+    return min(n, lo_u * SHARD_ALIGN), min(n, hi_u * SHARD_ALIGN)
 
 
 def shard_capacity(n, world):
-    return -(-n // world) if world > 0 else n
+    """Largest shard (the per-rank length of the all_gather buffers)."""
+    if world <= 0:
+        return n
+    units = -(-n // SHARD_ALIGN)
+    return min(n, -(-units // world) * SHARD_ALIGN)
 
 
 class ShardedCounter:
@@ -57,7 +69,7 @@ class ShardedCounter:
         torch, dist = self.torch, self.dist
         n = kmers.shape[0]
         lo, hi = shard_bounds(n, self.world, self.rank)
-        mine = self._count_local(kmers[lo:hi].contiguous())
+        mine = self._count_local(kmers[lo:hi])  # a row slice: contiguous, and 16-byte aligned when `kmers` is
         if self.world == 1:
             return mine
         cap = shard_capacity(n, self.world)

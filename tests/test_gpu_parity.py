@@ -13,6 +13,15 @@ from rle_random import random_kmers, random_stream, raw_byte_stream, runs_to_byt
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["auto", "groups", "lanes"])
+def search_kernel(request, monkeypatch):
+    """Every test of this file runs three times: with the automatic choice of count_kmers kernel,
+    with the 8-lanes-per-query kernel forced and with the one-query-per-lane (LDS-staged) kernel
+    forced -- a handle reads MSBWT_SEARCH when it is created."""
+    monkeypatch.setenv("MSBWT_SEARCH", request.param)
+    return request.param
+
 CODES = {"$": 0, "A": 1, "C": 2, "G": 3, "N": 4, "T": 5}
 
 

@@ -1,0 +1,30 @@
+#!/bin/bash
+# rocprofv3 evidence for one bench.py configuration, in separate passes (MI355X_MICROARCH.md, HBM /
+# rocprofv3 sections): kernel-trace + stats, then one PMC pass per counter group.  The program goes
+# directly after `--` (no env/bash hop).  Writes everything under gpurun_out/prof_<tag>/<name>/ and
+# nothing else (only gpurun_out/ travels back from the GPU box); afterwards, in the repo:
+#   tools/profile_collect.sh <tag> <name>   -> profiles/<tag>/ + profiles/traffic.json, to be committed.
+#   usage: tools/profile_bench.sh <tag> <name> [bench.py arguments...]
+#   e.g.   tools/profile_bench.sh r02_v1 human
+#          tools/profile_bench.sh r02_v1 c3 --workload c3
+set -e -o pipefail
+TAG=$1; NAME=$2; shift 2
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG/$NAME
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+LEAN="--no-cpu-baseline --no-c5 --parity-sample 20000 --stats-sample 200000"
+
+echo "[profile] kernel-trace + stats" >&2
+rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o run -- python3 "$ROOT/bench.py" "$@" $LEAN --steps 10 --warmup 2 \
+    > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+
+for group in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS"; do
+    first=${group%% *}
+    echo "[profile] pmc $group" >&2
+    rocprofv3 --pmc $group --kernel-trace -d "$OUT/pmc_$first" -o run -- python3 "$ROOT/bench.py" "$@" $LEAN --no-oracle --steps 3 --warmup 1 \
+        > "$OUT/bench_pmc_$first.json" 2> "$OUT/pmc_$first.err"
+done
+find "$OUT" -name "*kernel_trace.csv" -size +8M -delete   # keep what travels back small
+echo "[profile] done: $OUT" >&2
