@@ -5,8 +5,9 @@
 // 0-3 handle bound l and lanes 4-7 bound h; a lane loads two 16-byte chunks of its bound's
 // 128-byte block (two coalesced global_load_dwordx4 per step), popcounts its symbols, and the
 // quad sums with two DPP steps plus one cross-quad exchange -- no LDS traffic, no barriers.
-// With pair blocks a step consumes two k-mer symbols.  Block layouts: plane_index.hpp,
-// rank_ops.hpp.
+// Block layout: plane_index.hpp.  This is the kernel for SHORT searches (few symbols left after
+// the suffix table: setup dominates and 32 waves per CU hide its latency); long searches go to
+// the one-query-per-lane kernel of lanes.hip, which also takes two symbols per step.
 //
 // count_kmers (k <= 64) works on tiles of 64 queries per wave, in two phases:
 //   1. lane-per-query setup: the tile's query bytes are staged through LDS with coalesced
@@ -66,11 +67,11 @@ struct WaveScratchT {
     uint64_t result[kTile];                        // 512 B
 };
 
-template <bool kReads, int kLanes, bool kPair, int kWords>
-__global__ __launch_bounds__(256, kWords == 6 ? 5 : (kLanes == 4 ? 6 : 8)) void k_count_kmers_tiled(
+template <bool kReads, int kWords>
+__global__ __launch_bounds__(256, kWords == 6 ? 5 : 8) void k_count_kmers_tiled(
     const uint4 *__restrict__ blocks, uint64_t total, const uint4 *__restrict__ table, uint32_t depth,
-    const uint32_t *__restrict__ filter, uint32_t filter_mask, const uint4 *__restrict__ pair_blocks, const uint64_t *__restrict__ pair_super, const QuerySource src,
-    uint32_t *__restrict__ flags) {
+    const uint32_t *__restrict__ filter, uint32_t filter_mask, const QuerySource src, uint32_t *__restrict__ flags) {
+    constexpr int kLanes = kGroup;
     using Scratch = WaveScratchT<kWords>;
     using WorkItem = WorkItemT<kWords>;
     constexpr int kPieces = Scratch::kMaxK / 16;  // 16-byte pieces of a tile per lane: 2 or 4
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256, kWords == 6 ? 5 : (kLanes == 4 ? 6 : 8)) void 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t sub = lane & (kLanes - 1);
     const uint32_t group_first_lane = lane & ~uint32_t(kLanes - 1);
-    constexpr uint64_t kGroupLeaders = kLanes == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;
+    constexpr uint64_t kGroupLeaders = 0x0101010101010101ull;
     Scratch &ws = scratch[threadIdx.x >> 6];
     const uint8_t *stage_bytes = reinterpret_cast<const uint8_t *>(ws.stage);
 
@@ -92,10 +93,10 @@ __global__ __launch_bounds__(256, kWords == 6 ? 5 : (kLanes == 4 ? 6 : 8)) void 
 
     const TableEnv env{table, depth, use_table, filter, filter_mask, total};
     // A tile is at most 64 x kMaxK bytes = kPieces pieces per lane, all loads in flight at once.
-    // In the lean k <= 32 variant (short searches, e.g. C2, where setup dominates) the loads of
-    // the NEXT tile are issued before the current tile is searched, hiding their latency; the
-    // other variants have no registers to spare for that and load at the top of the tile.
-    constexpr bool kPrefetch = !kPair && kWords == 3;
+    // For k <= 32 the loads of the NEXT tile are issued before the current tile is searched, hiding
+    // their latency; the k <= 64 variant has no registers to spare for that and loads at the top
+    // of the tile.
+    constexpr bool kPrefetch = kWords == 3;
     uint4 staged[kPieces];
 #pragma unroll
     for (int i = 0; i < kPieces; ++i) staged[i] = make_uint4(0, 0, 0, 0);
@@ -202,21 +203,11 @@ __global__ __launch_bounds__(256, kWords == 6 ? 5 : (kLanes == 4 ? 6 : 8)) void 
                 }
                 if (busy == 0ull) break;
                 if (have) {
-                    const uint32_t s1 = w[0] & 7u, s2 = (w[0] >> 3) & 7u;
-                    if (kPair && rem >= 2u && (acgt_bit(s1) & acgt_bit(s2)) != 0u) {
-                        // two symbols for one line fetch per bound
-                        const Range r = GroupOps<kLanes>::step2(pair_blocks, pair_super, acgt_code(s1), acgt_code(s2), l, h, sub);
-                        l = r.l;
-                        h = r.h;
-                        consume_symbols<kWords>(w, 6);
-                        rem -= 2u;
-                    } else {
-                        const Range r = GroupOps<kLanes>::step(blocks, s1, l, h, sub);
-                        l = r.l;
-                        h = r.h;
-                        consume_symbols<kWords>(w, 3);
-                        --rem;
-                    }
+                    const Range r = constrain_split(blocks, w[0] & 7u, l, h, sub);
+                    l = r.l;
+                    h = r.h;
+                    consume_symbols<kWords>(w, 3);
+                    --rem;
                     if (rem == 0u || l == h) {
                         if (sub == 0u) ws.result[slot] = h - l;
                         have = false;
@@ -298,56 +289,33 @@ __global__ __launch_bounds__(256) void k_constrain_ranges(const uint4 *__restric
     }
 }
 
-// The tiled kernel comes in 2 x 2 x 2 shapes; pick one and launch it.
-template <bool kReads>
-void launch_tiled(bool quad, bool pair, bool longk, dim3 grid, hipStream_t stream, const IndexView &ix,
-                  const QuerySource &src, uint32_t *flags);
-
-// Lanes per query in the tiled kernel: 8 (default) or 4 (MSBWT_GROUP_LANES=4)
-inline bool use_quad_groups() {
-    static const bool quad = [] {
-        const char *env = std::getenv("MSBWT_GROUP_LANES");
-        return env && std::atoi(env) == 4;
-    }();
-    return quad;
-}
-
 // Which search kernel (IndexView::search_kernel, msbwt_rle_set_search_kernel): the one-query-
 // per-lane kernel (lanes.hip) for long searches -- many symbols left after the table, throughput
 // set by random lines in flight -- and the 8-lane-group kernel above for short ones, where setup
 // (staging, table lookups) dominates and its 32 waves per CU hide that latency better.
-// Pair steps pay off when at least a few symbols remain after the table lookup; for shorter
-// tails the leaner single-step kernel is faster (C2: 21-mers behind a depth-13 table).
-inline bool use_pair_steps(const IndexView &ix, uint32_t k) {
+// Automatic choice: lanes.hip when the pair index exists and at least 10 symbols remain after the
+// table lookup (C3/C4/human-scale 31-mers); otherwise this file's kernel (C2: 21-mers behind a
+// depth-13 table mostly end in the table).
+inline bool long_search(const IndexView &ix, uint32_t k) {
     const uint32_t depth = (ix.table.entries && k >= uint32_t(ix.table.depth)) ? uint32_t(ix.table.depth) : 0u;
     return ix.pair_blocks != nullptr && k - depth >= 10u;
 }
 
 inline bool use_lanes_kernel(const IndexView &ix, uint32_t k) {
-    return ix.search_kernel == kSearchLanes || (ix.search_kernel == kSearchAuto && use_pair_steps(ix, k));
+    return ix.search_kernel == kSearchLanes || (ix.search_kernel == kSearchAuto && long_search(ix, k));
 }
 
 template <bool kReads>
-void launch_tiled(bool quad, bool pair, bool longk, dim3 grid, hipStream_t stream, const IndexView &ix,
-                  const QuerySource &src, uint32_t *flags) {
+void launch_tiled(bool longk, dim3 grid, hipStream_t stream, const IndexView &ix, const QuerySource &src, uint32_t *flags) {
     const uint4 *blocks = static_cast<const uint4 *>(ix.blocks);
     const uint4 *table = static_cast<const uint4 *>(ix.table.entries);
     const uint32_t depth = uint32_t(ix.table.depth);
     const uint32_t *filter = table ? ix.table.filter : nullptr;
     const uint32_t filter_mask = filter ? uint32_t((1ull << (2 * ix.table.filter_depth)) - 1ull) : 0u;
-    const uint4 *pair_blocks = static_cast<const uint4 *>(ix.pair_blocks);
-    const uint64_t *pair_super = ix.pair_super;
-    const uint64_t total = ix.total;
-#define MSBWT_LAUNCH(L, P, W) \
-    hipLaunchKernelGGL((k_count_kmers_tiled<kReads, L, P, W>), grid, dim3(256), 0, stream, blocks, total, table, depth, filter, filter_mask, pair_blocks, pair_super, src, flags)
-    if (longk) {  // 33 <= k <= 64: 8-lane groups
-        if (pair) MSBWT_LAUNCH(8, true, 6); else MSBWT_LAUNCH(8, false, 6);
-    } else if (quad) {
-        if (pair) MSBWT_LAUNCH(4, true, 3); else MSBWT_LAUNCH(4, false, 3);
-    } else {
-        if (pair) MSBWT_LAUNCH(8, true, 3); else MSBWT_LAUNCH(8, false, 3);
-    }
-#undef MSBWT_LAUNCH
+    if (longk)  // 33 <= k <= 64
+        hipLaunchKernelGGL((k_count_kmers_tiled<kReads, 6>), grid, dim3(256), 0, stream, blocks, ix.total, table, depth, filter, filter_mask, src, flags);
+    else
+        hipLaunchKernelGGL((k_count_kmers_tiled<kReads, 3>), grid, dim3(256), 0, stream, blocks, ix.total, table, depth, filter, filter_mask, src, flags);
 }
 
 }  // namespace
@@ -359,14 +327,13 @@ hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_
     const bool aligned = (reinterpret_cast<uintptr_t>(kmers) & 15u) == 0;
     if (k >= 1 && k <= uint32_t(kMaxTiledK) && aligned) {
         const uint64_t tiles = (n + kTile - 1) / kTile;
-        const bool quad = use_quad_groups();
         QuerySource src{};
         src.data = kmers;
         src.n = n;
         src.k = k;
         src.out_fwd = counts;
-        if (use_lanes_kernel(ix, k)) return launch_lanes(ix, src, false, use_pair_steps(ix, k), flags, stream);
-        launch_tiled<false>(quad, use_pair_steps(ix, k), k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, ix, src, flags);
+        if (use_lanes_kernel(ix, k)) return launch_lanes(ix, src, false, true, flags, stream);
+        launch_tiled<false>(k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, ix, src, flags);
     } else {
         hipLaunchKernelGGL(k_count_kmers_generic, dim3(grid_for(n * kGroup)), dim3(256), 0, stream, blocks,
                            ix.total, kmers, k, n, counts, flags);
@@ -379,7 +346,6 @@ hipError_t launch_count_read_kmers(const IndexView &ix, const uint8_t *reads, ui
                                    hipStream_t stream) {
     if (k < 1 || k > uint32_t(kMaxTiledK) || k > read_len || (!out_fwd && !out_rc)) return hipErrorInvalidValue;
     if (n_reads == 0) return hipSuccess;
-    const bool quad = use_quad_groups();
     QuerySource src{};
     src.data = reads;
     src.k = k;
@@ -390,9 +356,9 @@ hipError_t launch_count_read_kmers(const IndexView &ix, const uint8_t *reads, ui
     src.out_fwd = out_fwd;
     src.out_rc = out_rc;
     src.n = n_reads * src.windows * (src.strands == 3u ? 2u : 1u);
-    if (use_lanes_kernel(ix, k)) return launch_lanes(ix, src, true, use_pair_steps(ix, k), flags, stream);
+    if (use_lanes_kernel(ix, k)) return launch_lanes(ix, src, true, true, flags, stream);
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
-    launch_tiled<true>(quad, use_pair_steps(ix, k), k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, ix, src, flags);
+    launch_tiled<true>(k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, ix, src, flags);
     return hipGetLastError();
 }
 
@@ -402,7 +368,6 @@ hipError_t launch_count_ragged_read_kmers(const IndexView &ix, const uint8_t *re
                                           hipStream_t stream) {
     if (k < 1 || k > uint32_t(kMaxTiledK) || (!out_fwd && !out_rc)) return hipErrorInvalidValue;
     if (n_reads == 0 || n_windows == 0) return hipSuccess;
-    const bool quad = use_quad_groups();
     QuerySource src{};
     src.data = reads;
     src.k = k;
@@ -414,9 +379,9 @@ hipError_t launch_count_ragged_read_kmers(const IndexView &ix, const uint8_t *re
     src.win_off = win_off;
     src.n_reads = n_reads;
     src.n = n_windows * (src.strands == 3u ? 2u : 1u);
-    if (use_lanes_kernel(ix, k)) return launch_lanes(ix, src, true, use_pair_steps(ix, k), flags, stream);
+    if (use_lanes_kernel(ix, k)) return launch_lanes(ix, src, true, true, flags, stream);
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
-    launch_tiled<true>(quad, use_pair_steps(ix, k), k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, ix, src, flags);
+    launch_tiled<true>(k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, ix, src, flags);
     return hipGetLastError();
 }
 

@@ -16,13 +16,17 @@
 //      free, see line_base) and ranks both bounds itself: XOR / AND / popcount on the bit planes,
 //      no cross-lane reduction at all.
 //
-// Lanes whose query is finished take the next undecided query from a ring in LDS that phase 1
-// (stage the tile's bytes, validate, pack, suffix-table lookup -- the same code as the tiled
-// kernel, search_common.hpp) keeps topped up, so all 64 lanes stay busy whatever the mix of
-// early exits.  Counts go straight to the caller's buffer.  Block layouts: plane_index.hpp,
-// rank_ops.hpp.  One wave per workgroup, 22 KiB of LDS each: 7 waves per CU.
+// Lanes whose query is finished take the next undecided query from a ring in LDS that the setup
+// code (stage the tile's bytes, validate, pack, suffix-table lookup -- the pieces of
+// search_common.hpp) keeps topped up, so all 64 lanes stay busy whatever the mix of early exits.
+// Setup never waits for memory by itself: a tile's bytes are fetched an iteration early and its
+// table entries ride along with the next search step's lines.  Counts go straight to the caller's
+// buffer.  Block layouts: plane_index.hpp,
+// rank_ops.hpp.  One wave per workgroup, 15.5 KiB of LDS each: 10 waves per CU.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "kernels.hpp"
@@ -35,9 +39,10 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void global_void;
 
-constexpr int kRing = 128;       // undecided queries waiting for a lane (>= 64 left over + 64 new)
-constexpr int kRegions = 16;     // LDS-DMA regions of 8 lines: 64 first-bound lines + up to 64 second-bound lines
+constexpr int kRing = 64;        // undecided queries waiting for a lane: one tile's worth (the next tile waits in registers)
+constexpr int kRegions = 12;     // LDS-DMA regions of 8 lines: 64 first-bound lines + up to 32 second-bound lines
 constexpr int kLineSlots = kRegions * 8;
+constexpr uint32_t kMaxSecond = uint32_t(kLineSlots) - 64u;  // lanes beyond that with a second line sit the step out
 
 template <int kWords>
 struct LaneScratchT {
@@ -47,9 +52,9 @@ struct LaneScratchT {
     // read-back of "chunk j of my line" touches every bank exactly once per 16 lanes (lanes 16 m ..
     // 16 m + 15 own the lines of regions 2 m and 2 m + 1, whose bank phases differ by 128 bytes).
     // During phase 1 the same memory stages the tile's query bytes (2 or 4 KiB).
-    uint4 lines[(kRegions / 2) * 136];   // 17 KiB
-    uint64_t list[kLineSlots];        // this step's line addresses, 0 = none (1 KiB)
-    WorkItemT<kWords> ring[kRing];    // 4 or 6 KiB
+    uint4 lines[(kRegions / 2) * 136];   // 12.75 KiB
+    uint64_t list[kLineSlots];        // this step's line addresses (768 B)
+    WorkItemT<kWords> ring[kRing];    // 2 or 3 KiB
 };
 
 // uint4 index of the first of region i's 64 sixteen-byte pieces: pairs of regions take 136 pieces,
@@ -59,10 +64,8 @@ __host__ __device__ constexpr uint32_t region_base(uint32_t i) { return 136u * (
 // uint4 index of chunk 0 of the line in slot `s` (chunk j sits at line_base(s) + (j ^ (s & 7)))
 __device__ __forceinline__ uint32_t line_base(uint32_t s) { return region_base(s >> 3) + 8u * (s & 7u); }
 
-__device__ __forceinline__ uint32_t below(int r, int first) {  // mask of the bits [0, r - first) clamped to a word
-    const int n = r - first;
-    return n <= 0 ? 0u : (n >= 32 ? ~0u : ((1u << n) - 1u));
-}
+// (a ^ b) & c in one v_bitop3_b32 (truth-table index = 4 a + 2 b + c)
+__device__ __forceinline__ uint32_t xor_and(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x28); }
 
 // ---- rank of one bound from a staged plane-block line (single-symbol step) ----------------------
 struct PlaneLine {
@@ -76,25 +79,28 @@ __device__ __forceinline__ void read_plane_line(const uint4 *lines, uint32_t slo
 #pragma unroll
     for (uint32_t j = 0; j < 8; ++j) {
         const uint4 c = lines[base + (j ^ g)];
-        L.m[j] = (c.x ^ x0) & (c.y ^ x1) & (c.z ^ x2);
+        L.m[j] = xor_and(c.z, x2, xor_and(c.y, x1, c.x ^ x0));
         L.meta[j] = c.w;
     }
 }
 
 // start_index[s] + rank(s, pos) from the line of pos's block (plane_index.hpp layout)
 __device__ __forceinline__ uint64_t plane_line_bound(const PlaneLine &L, uint32_t s, uint64_t pos) {
-    const int r = int(uint32_t(pos) & 255u);
+    const uint32_t r = uint32_t(pos) & 255u, idx = r >> 6;
+    const uint64_t t = (1ull << (r & 63u)) - 1ull;  // the 64-position word that holds r keeps its low r % 64 bits
     uint32_t cnt = 0, lo = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        cnt += uint32_t(__popc(L.m[j] & below(r, 32 * j)));
-        if (j < 6) lo = (s == uint32_t(j)) ? L.meta[j] : lo;
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint64_t mask = j < idx ? ~0ull : (j == idx ? t : 0ull);
+        cnt += uint32_t(__popc(L.m[2 * j] & uint32_t(mask))) + uint32_t(__popc(L.m[2 * j + 1] & uint32_t(mask >> 32)));
     }
+#pragma unroll
+    for (uint32_t j = 0; j < 6; ++j) lo = (s == j) ? L.meta[j] : lo;
     const uint32_t hi = (((s >> 2) ? L.meta[7] : L.meta[6]) >> ((s & 3u) * 8u)) & 0xFFu;
     return ((uint64_t(hi) << 32) | lo) + cnt;
 }
 
-// ---- rank of one bound from a staged pair-block line (two-symbol step, rank_ops.hpp) -------------
+// ---- rank of one bound from a staged pair-block line (two-symbol step, rank_ops.hpp layout) -----
 struct PairLine {
     uint32_t m[4];   // per 32 positions: 1 where (S, S2) == (a, b)
     uint32_t field;  // the block's 24-bit header count of the pair
@@ -102,25 +108,31 @@ struct PairLine {
 
 __device__ __forceinline__ void read_pair_line(const uint4 *lines, uint32_t slot, uint32_t a2, uint32_t b2, PairLine &L) {
     const uint32_t base = line_base(slot), g = slot & 7u, p = a2 * 4u + b2;
-    const uint32_t pa = ((a2 & 1u) ? 0x0000FFFFu : 0u) | ((a2 & 2u) ? 0xFFFF0000u : 0u);
-    const uint32_t pb = ((b2 & 1u) ? 0x0000FFFFu : 0u) | ((b2 & 2u) ? 0xFFFF0000u : 0u);
-    L.field = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < 8; ++j) {
-        const uint4 c = lines[base + (j ^ g)];
-        uint32_t t = ~(c.x ^ pa) & ~(c.y ^ pb);  // 1 where a plane bit equals the wanted bit (both symbols)
-        t = t & (t >> 16) & c.z & 0xFFFFu;       // both planes of both symbols, and the position is valid
-        if (j & 1u) L.m[j >> 1] |= t << 16; else L.m[j >> 1] = t;
-        L.field = ((p >> 1) == j) ? pair_chunk_field(c, p) : L.field;
-    }
+    const uint4 a0 = lines[base + (0u ^ g)], a1 = lines[base + (1u ^ g)], b0 = lines[base + (2u ^ g)], b1 = lines[base + (3u ^ g)];
+    const uint4 v = lines[base + (uint32_t(kPairValidChunk) ^ g)];
+    // a plane word matches where it equals the wanted code bit: XOR with all-ones when that bit is 0
+    const uint32_t na0 = (a2 & 1u) - 1u, na1 = ((a2 >> 1) & 1u) - 1u, nb0 = (b2 & 1u) - 1u, nb1 = ((b2 >> 1) & 1u) - 1u;
+    L.m[0] = xor_and(b1.x, nb1, xor_and(b0.x, nb0, xor_and(a1.x, na1, xor_and(a0.x, na0, v.x))));
+    L.m[1] = xor_and(b1.y, nb1, xor_and(b0.y, nb0, xor_and(a1.y, na1, xor_and(a0.y, na0, v.y))));
+    L.m[2] = xor_and(b1.z, nb1, xor_and(b0.z, nb0, xor_and(a1.z, na1, xor_and(a0.z, na0, v.z))));
+    L.m[3] = xor_and(b1.w, nb1, xor_and(b0.w, nb0, xor_and(a1.w, na1, xor_and(a0.w, na0, v.w))));
+    // header: u16 low half in chunk 5/6, u8 high byte in chunk 7
+    const uint16_t *halves = reinterpret_cast<const uint16_t *>(lines + base + ((uint32_t(kPairLoChunk) + (p >> 3)) ^ g));
+    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(lines + base + (uint32_t(kPairHiChunk) ^ g));
+    L.field = uint32_t(halves[p & 7u]) | (uint32_t(bytes[p]) << 16);
+}
+
+// matches among the first r (0..127) positions of the block (branch-free: a 128-bit low mask)
+__device__ __forceinline__ uint32_t pair_line_count(const PairLine &L, uint32_t r) {
+    const uint64_t t = (1ull << (r & 63u)) - 1ull;
+    const bool upper = r >= 64u;
+    const uint64_t lo = upper ? ~0ull : t, hi = upper ? t : 0ull;
+    return uint32_t(__popc(L.m[0] & uint32_t(lo))) + uint32_t(__popc(L.m[1] & uint32_t(lo >> 32))) +
+           uint32_t(__popc(L.m[2] & uint32_t(hi))) + uint32_t(__popc(L.m[3] & uint32_t(hi >> 32)));
 }
 
 __device__ __forceinline__ uint64_t pair_line_bound(const PairLine &L, uint64_t super_base, uint64_t pos) {
-    const int r = int(uint32_t(pos) & 127u);
-    uint32_t cnt = L.field;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) cnt += uint32_t(__popc(L.m[w] & below(r, 32 * w)));
-    return super_base + cnt;
+    return super_base + L.field + pair_line_count(L, uint32_t(pos) & 127u);
 }
 
 template <bool kReads, bool kPair, int kWords>
@@ -142,55 +154,58 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
     const uint64_t ntiles = (n + kTile - 1) / kTile;
     const uint64_t wave_id = blockIdx.x, nwaves = gridDim.x;
     const bool use_table = table != nullptr && depth > 0 && k >= depth;
-    const TableEnv env{table, depth, use_table, filter, filter_mask, total};
-    // this lane's part in the line fetches: 16 bytes (chunk dma_chunk) of the line in list slot 8 i + dma_group
+    // this lane's part in the line fetches: 16 bytes (one chunk) of the line in list slot 8 i + dma_group
     const uint32_t dma_group = lane >> 3, dma_chunk_bytes = ((lane & 7u) ^ dma_group) * 16u;
 
-    uint64_t next_tile = wave_id;
-    uint32_t seq = 0;                    // tiles this wave has set up so far (slot = seq * 64 + lane of the tile)
+    uint64_t next_tile = wave_id;        // next tile to set up
+    uint32_t seq = 0;                    // tiles set up so far (slot = seq * 64 + lane of the tile)
     uint32_t ring_head = 0, ring_count = 0;  // wave-uniform
     uint32_t filter_pause = 0;           // as in the tiled kernel: the filter rests while nearly everything passes
 
+    // the lane's running query
     bool have = false;
     uint64_t l = 0, h = 0;
     uint32_t w[kWords], rem = 0, slot = 0;
 #pragma unroll
     for (int i = 0; i < kWords; ++i) w[i] = 0;
 
-    for (;;) {
-        // ---- phase 1: set up tiles until at least 64 undecided queries wait (or no tiles are left) ----
-        while (ring_count < 64u && next_tile < ntiles) {
-            const uint64_t tile = next_tile;
-            next_tile += nwaves;
+    // Setup runs one step AHEAD of the search and never waits for memory on its own: a tile's
+    // query bytes are fetched one iteration before they are packed, and the suffix-table entries
+    // a tile asks for stay in flight across the next search step (whose s_waitcnt covers them).
+    //   staged_next[]: bytes of tile `next_tile` (loads issued, not waited for)
+    //   prepared:      a tile has been packed and its table loads issued; per lane: prep_kind
+    //                  (0 nothing to do, 1 range comes from prep_entry, 2 range is [0, total)),
+    //                  prep_w / prep_rem / prep_slot
+    uint4 staged_next[kPieces];
+#pragma unroll
+    for (int i = 0; i < kPieces; ++i) staged_next[i] = make_uint4(0, 0, 0, 0);
+    auto fetch_tile_bytes = [&](uint64_t tile) {
+        if (!kReads && tile < ntiles) {
             const uint64_t q0 = tile * kTile;
-            const uint32_t in_tile = uint32_t(min(uint64_t(kTile), n - q0));
-            const bool filter_now = filter != nullptr && filter_pause == 0;
-            bool looked_up = false, passed = false;
-            if (!kReads) {  // the tile's bytes (contiguous, 16-byte aligned) go through LDS
-                uint4 staged[kPieces];
+            const uint32_t nbytes = uint32_t(min(uint64_t(kTile), n - q0)) * k;
 #pragma unroll
-                for (int i = 0; i < kPieces; ++i) staged[i] = load_piece(kmers + q0 * k, in_tile * k, lane + 64u * i);
+            for (int i = 0; i < kPieces; ++i) staged_next[i] = load_piece(kmers + q0 * k, nbytes, lane + 64u * i);
+        }
+    };
+    fetch_tile_bytes(next_tile);
+    bool prepared = false;  // wave-uniform
+    uint32_t prep_kind = 0, prep_rem = 0, prep_slot = 0, prep_w[kWords];
+    uint4 prep_entry = make_uint4(0, 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < kPieces; ++i) ws.lines[lane + 64u * i] = staged[i];
+    for (int i = 0; i < kWords; ++i) prep_w[i] = 0;
+
+    for (;;) {
+        // ---- A: the ring is empty: the prepared tile (its table entries arrived a step ago) moves in ----
+        if (prepared && ring_count == 0u) {
+            uint64_t pl = 0, ph = total;
+            if (prep_kind == 1u) {
+                pl = (uint64_t(prep_entry.y) << 32) | prep_entry.x;
+                ph = (uint64_t(prep_entry.w) << 32) | prep_entry.z;
             }
-            wave_lds_sync();
-            bool pending = false;
-            uint64_t pl = 0, ph = 0, result = 0;
-            uint32_t pw[kWords], prem = 0;
-#pragma unroll
-            for (int i = 0; i < kWords; ++i) pw[i] = 0;
-            if (lane < in_tile) {
-                pending = prepare_query<kReads, kWords>(src, env, stage_bytes + lane * k, q0 + lane, filter_now, flags, pl, ph,
-                                                        pw, prem, result, looked_up, passed);
-                if (!pending) store_count<kReads>(src, q0 + lane, result);
-            }
-            if (filter != nullptr) {
-                if (filter_now) {
-                    const uint32_t nlook = uint32_t(__popcll(__ballot(looked_up))), npass = uint32_t(__popcll(__ballot(passed)));
-                    if (nlook > 0 && npass * 10u >= nlook * 9u) filter_pause = 7;
-                } else {
-                    --filter_pause;
-                }
+            bool pending = prep_kind != 0u;
+            if (pending && (prep_rem == 0u || pl == ph)) {  // decided by the table (or an empty index)
+                store_count<kReads>(src, (wave_id + uint64_t(prep_slot >> 6) * nwaves) * kTile + (prep_slot & 63u), ph - pl);
+                pending = false;
             }
             const uint64_t pend_mask = __ballot(pending);
             if (pending) {
@@ -199,15 +214,15 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
                 it.l_lo = uint32_t(pl); it.l_hi = uint32_t(pl >> 32);
                 it.h_lo = uint32_t(ph); it.h_hi = uint32_t(ph >> 32);
 #pragma unroll
-                for (int i = 0; i < kWords; ++i) it.w[i] = pw[i];
-                it.rem_slot = prem | ((seq * 64u + lane) << 8);
+                for (int i = 0; i < kWords; ++i) it.w[i] = prep_w[i];
+                it.rem_slot = prep_rem | (prep_slot << 8);
                 ws.ring[(ring_head + ring_count + at) & (kRing - 1)] = it;
             }
             ring_count += uint32_t(__popcll(pend_mask));
-            ++seq;
-            wave_lds_sync();  // the ring entries are visible; the staged bytes may be overwritten
+            prepared = false;
+            wave_lds_sync();
         }
-        // ---- idle lanes take the waiting queries, in lane order ----
+        // ---- B: idle lanes take the waiting queries, in lane order ----
         uint64_t busy = __ballot(have);
         if (busy != ~0ull && ring_count > 0u) {
             const uint64_t idle = ~busy;
@@ -233,7 +248,6 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
             const uint32_t taken = min(ring_count, uint32_t(__popcll(idle)));
             ring_head = (ring_head + taken) & (kRing - 1);
             ring_count -= taken;
-            busy = __ballot(have);
         }
         // a range outside the index would turn into a wild line address: end such a query with
         // u64::MAX and a status flag instead (never seen on a well-formed index; cheap insurance)
@@ -251,9 +265,69 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
             have = false;
         }
         busy = __ballot(have);
-        if (busy == 0ull) break;  // nothing in flight, nothing waiting, no tiles left
 
-        // ---- one search step of every busy lane ----
+        // ---- C: nothing prepared: pack the next tile and ask the table for its ranges ----
+        if (!prepared && next_tile < ntiles) {
+            const uint64_t tile = next_tile;
+            next_tile += nwaves;
+            const uint64_t q0 = tile * kTile;
+            const uint32_t in_tile = uint32_t(min(uint64_t(kTile), n - q0));
+            const bool filter_now = filter != nullptr && filter_pause == 0;
+            bool looked_up = false, passed = false;
+            if (!kReads) {  // the tile's bytes go through LDS (the line area is free between two steps)
+#pragma unroll
+                for (int i = 0; i < kPieces; ++i) ws.lines[lane + 64u * i] = staged_next[i];
+            }
+            wave_lds_sync();
+            prep_kind = 0;
+            prep_slot = seq * 64u + lane;
+            if (lane < in_tile) {
+                PackedQuery<kWords> pq;
+                pack_query<kReads, kWords>(src, depth, stage_bytes + lane * k, q0 + lane, pq);
+                if (pq.bad) {  // the reference asserts (msbwt_core.rs:127)
+                    store_count<kReads>(src, q0 + lane, ~0ull);
+                    atomicOr(flags, kFlagInvalidSymbol);
+                } else if (use_table && pq.acgt) {
+                    bool maybe = true;
+                    if (filter_now) {  // L2-resident presence bit first: an absent suffix never touches the table line
+                        const uint32_t fi = pq.tidx & filter_mask;
+                        maybe = ((filter[fi >> 5] >> (fi & 31u)) & 1u) != 0u;
+                        looked_up = true;
+                        passed = maybe;
+                    }
+                    if (maybe) {
+                        prep_entry = table[pq.tidx];  // stays in flight: consumed in step A of the next iteration
+                        prep_kind = 1;
+                        prep_rem = k - depth;
+                        unpack_words<kWords>(pq, depth, prep_w);
+                    } else {
+                        store_count<kReads>(src, q0 + lane, 0ull);
+                    }
+                } else {
+                    prep_kind = 2;
+                    prep_rem = k;
+                    unpack_words<kWords>(pq, 0u, prep_w);
+                }
+            }
+            if (filter != nullptr) {
+                if (filter_now) {
+                    const uint32_t nlook = uint32_t(__popcll(__ballot(looked_up))), npass = uint32_t(__popcll(__ballot(passed)));
+                    if (nlook > 0 && npass * 10u >= nlook * 9u) filter_pause = 7;
+                } else {
+                    --filter_pause;
+                }
+            }
+            ++seq;
+            prepared = true;
+            wave_lds_sync();         // every lane has read its staged bytes: the line area may be overwritten
+            fetch_tile_bytes(next_tile);  // the following tile's bytes start their trip now
+        }
+        if (busy == 0ull) {
+            if (prepared) continue;  // nothing to search yet: go and take the prepared tile (waits for its table entries)
+            break;                   // nothing in flight, nothing waiting, no tiles left
+        }
+
+        // ---- D: one search step of every busy lane ----
         const uint32_t s1 = w[0] & 7u, s2 = (w[0] >> 3) & 7u;
         const bool pair = kPair && have && rem >= 2u && (acgt_bit(s1) & acgt_bit(s2)) != 0u;
         const uint32_t a2 = acgt_code(s1) & 3u, b2 = acgt_code(s2) & 3u;
@@ -262,32 +336,42 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
         const uint64_t bl = l >> shift, bh = h >> shift;
         const bool second = have && bh != bl;
         const uint64_t second_mask = __ballot(second);
-        const uint32_t nsecond = uint32_t(__popcll(second_mask));
         const uint32_t second_rank = __builtin_amdgcn_mbcnt_hi(uint32_t(second_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(second_mask), 0u));
+        const uint32_t nsecond = min(uint32_t(__popcll(second_mask)), kMaxSecond);
+        // room for 32 second lines per step: a lane beyond that sits this step out (its query simply
+        // takes the step in the next iteration)
+        const bool act = have && !(second && second_rank >= kMaxSecond);
         const uint32_t slot_l = lane, slot_h = second ? 64u + second_rank : lane;
-        ws.list[lane] = have ? base + bl * 128u : 0ull;
-        if (second) ws.list[slot_h] = base + bh * 128u;
+        // an idle slot names the index's first block (an L2 hit) instead of masking its eight DMA lanes
+        // off: one branch-free load instruction per region is cheaper than the exec-mask dance
+        const uint64_t dummy = reinterpret_cast<uint64_t>(blocks);
+        ws.list[lane] = act ? base + bl * 128u : dummy;
+        if (second && act) ws.list[slot_h] = base + bh * 128u;
+        if (lane < 8u && 64u + nsecond + lane < uint32_t(kLineSlots)) ws.list[64u + nsecond + lane] = dummy;  // the ragged end of the last second-bound region
         uint64_t super_l = 0, super_h = 0;  // pair steps: K[a][b] + occ2 at the superblock start (L2-resident table)
         if (pair) {
+            // one 8-byte load per lane is a separate L2 request each (64 per wave): fetch the second
+            // bound's base only in the rare case that it lies in another superblock
             const uint32_t p = a2 * 4u + b2;
-            super_l = pair_super[(l >> kPairSuperShift) * 16u + p];
-            super_h = pair_super[(h >> kPairSuperShift) * 16u + p];
+            const uint64_t sbl = l >> kPairSuperShift, sbh = h >> kPairSuperShift;
+            super_l = pair_super[sbl * 16u + p];
+            super_h = super_l;
+            if (sbh != sbl) super_h = pair_super[sbh * 16u + p];
         }
         wave_lds_sync();
+        {   // all line addresses first (one LDS round trip), then the LDS-DMA loads back to back
+            uint64_t addr[kRegions];
 #pragma unroll
-        for (int i = 0; i < kRegions; ++i) {
-            const bool wanted = i < 8 ? ((busy >> (8 * i)) & 0xFFull) != 0ull : nsecond > uint32_t(8 * (i - 8));  // wave-uniform
-            if (wanted) {
-                const uint32_t idx = 8u * i + dma_group;
-                uint64_t a = ws.list[idx];
-                if (i >= 8 && idx >= 64u + nsecond) a = 0;  // stale entry of an earlier step
-                if (a != 0ull)
-                    __builtin_amdgcn_global_load_lds((global_void *)(a + dma_chunk_bytes), (lds_void *)&ws.lines[region_base(i)], 16, 0, 0);
+            for (int i = 0; i < kRegions; ++i) addr[i] = ws.list[8u * i + dma_group] + dma_chunk_bytes;
+#pragma unroll
+            for (int i = 0; i < kRegions; ++i) {
+                const bool wanted = i < 8 ? ((busy >> (8 * i)) & 0xFFull) != 0ull : nsecond > uint32_t(8 * (i - 8));  // wave-uniform
+                if (wanted) __builtin_amdgcn_global_load_lds((global_void *)addr[i], (lds_void *)&ws.lines[region_base(i)], 16, 0, 0);
             }
         }
-        __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): every line has landed in LDS
+        __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): every line has landed in LDS (and the table entries of step C are here)
         wave_lds_sync();
-        if (have) {
+        if (act) {
             uint64_t nl, nh;
             if (pair) {
                 PairLine L;
@@ -309,35 +393,60 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
             l = nl;
             h = nh;
             if (rem == 0u || l == h) {
-                const uint64_t q = (wave_id + uint64_t(slot >> 6) * nwaves) * kTile + (slot & 63u);
-                store_count<kReads>(src, q, h - l);
+                store_count<kReads>(src, (wave_id + uint64_t(slot >> 6) * nwaves) * kTile + (slot & 63u), h - l);
                 have = false;
             }
         }
-        wave_lds_sync();  // the next step (or phase 1) overwrites the lines
+        wave_lds_sync();  // the next iteration overwrites the lines
     }
 }
 
 // The wave's 24-bit slot numbers allow 2^18 tiles per wave and launch
 constexpr uint64_t kMaxTilesPerWave = 1ull << 18;
 
-template <bool kReads>
-void launch_shape(bool pair, bool longk, dim3 grid, hipStream_t stream, const IndexView &ix, const QuerySource &src,
-                  uint32_t *flags) {
-    const uint4 *blocks = static_cast<const uint4 *>(ix.blocks);
+// The kernel is persistent and tiles are dealt out statically, so the grid must be exactly what
+// the device keeps resident: workgroups per CU (occupancy API: LDS- and VGPR-bound) x CUs.
+template <bool kReads, bool kPair, int kWords>
+uint32_t resident_waves() {
+    static const uint32_t cached = [] {
+        int device = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&device) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_count_kmers_lanes<kReads, kPair, kWords>, 64, 0) != hipSuccess ||
+            cus <= 0 || per_cu <= 0)
+            return 7u * 256u;
+        // Measured on MI355X (tools/sweep_waves.sh, human-scale index): throughput rises up to 8 waves
+        // per CU and collapses beyond (5: 3.76, 7: 4.20, 8: 4.31, 10: 3.04 x 10^9 q/s) -- past ~600
+        // lines in flight per CU the outstanding misses push the L2-resident tables out of L2.
+        per_cu = std::min(per_cu, 8);
+        if (const char *env = std::getenv("MSBWT_LANES_WAVES_PER_CU")) {  // experiments
+            const int want = std::atoi(env);
+            if (want > 0) per_cu = want;
+        }
+        if (std::getenv("MSBWT_VERBOSE")) std::fprintf(stderr, "[msbwt] lanes kernel <%d,%d,%d>: %d workgroups per CU x %d CUs\n", int(kReads), int(kPair), kWords, per_cu, cus);
+        return uint32_t(cus) * uint32_t(per_cu);
+    }();
+    return cached;
+}
+
+template <bool kReads, bool kPair, int kWords>
+hipError_t launch_variant(hipStream_t stream, const IndexView &ix, const QuerySource &src, uint32_t *flags) {
     const uint4 *table = static_cast<const uint4 *>(ix.table.entries);
-    const uint32_t depth = uint32_t(ix.table.depth);
     const uint32_t *filter = table ? ix.table.filter : nullptr;
     const uint32_t filter_mask = filter ? uint32_t((1ull << (2 * ix.table.filter_depth)) - 1ull) : 0u;
-    const uint4 *pair_blocks = static_cast<const uint4 *>(ix.pair_blocks);
-#define MSBWT_LAUNCH(P, W) \
-    hipLaunchKernelGGL((k_count_kmers_lanes<kReads, P, W>), grid, dim3(64), 0, stream, blocks, ix.total, table, depth, filter, filter_mask, pair_blocks, ix.pair_super, src, flags, ix.debug)
-    if (longk) {
-        if (pair) MSBWT_LAUNCH(true, 6); else MSBWT_LAUNCH(false, 6);
-    } else {
-        if (pair) MSBWT_LAUNCH(true, 3); else MSBWT_LAUNCH(false, 3);
-    }
-#undef MSBWT_LAUNCH
+    const uint64_t tiles = (src.n + kTile - 1) / kTile;
+    const uint64_t waves = std::min<uint64_t>(tiles, resident_waves<kReads, kPair, kWords>());
+    if ((tiles + waves - 1) / waves > kMaxTilesPerWave) return hipErrorInvalidValue;  // > 3e10 queries: split the batch
+    hipLaunchKernelGGL((k_count_kmers_lanes<kReads, kPair, kWords>), dim3(uint32_t(waves)), dim3(64), 0, stream,
+                       static_cast<const uint4 *>(ix.blocks), ix.total, table, uint32_t(ix.table.depth), filter, filter_mask,
+                       static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags, ix.debug);
+    return hipGetLastError();
+}
+
+template <bool kReads>
+hipError_t launch_shape(bool pair, bool longk, hipStream_t stream, const IndexView &ix, const QuerySource &src, uint32_t *flags) {
+    if (longk) return pair ? launch_variant<kReads, true, 6>(stream, ix, src, flags) : launch_variant<kReads, false, 6>(stream, ix, src, flags);
+    return pair ? launch_variant<kReads, true, 3>(stream, ix, src, flags) : launch_variant<kReads, false, 3>(stream, ix, src, flags);
 }
 
 }  // namespace
@@ -348,13 +457,8 @@ hipError_t launch_lanes(const IndexView &ix, const QuerySource &src, bool reads,
     if (!reads && (reinterpret_cast<uintptr_t>(src.data) & 15u) != 0) return hipErrorInvalidValue;
     if (src.n == 0) return hipSuccess;
     pair = pair && ix.pair_blocks != nullptr;
-    const uint64_t tiles = (src.n + kTile - 1) / kTile;
-    // 7 one-wave workgroups per CU (LDS-bound) on 256 CUs; fewer for small batches
-    const uint64_t waves = tiles < 7 * 256 ? tiles : 7 * 256;
-    if ((tiles + waves - 1) / waves > kMaxTilesPerWave) return hipErrorInvalidValue;  // > 3e10 queries: split the batch
-    if (reads) launch_shape<true>(pair, src.k > uint32_t(kMaxShortK), dim3(uint32_t(waves)), stream, ix, src, flags);
-    else launch_shape<false>(pair, src.k > uint32_t(kMaxShortK), dim3(uint32_t(waves)), stream, ix, src, flags);
-    return hipGetLastError();
+    const bool longk = src.k > uint32_t(kMaxShortK);
+    return reads ? launch_shape<true>(pair, longk, stream, ix, src, flags) : launch_shape<false>(pair, longk, stream, ix, src, flags);
 }
 
 }  // namespace msbwt

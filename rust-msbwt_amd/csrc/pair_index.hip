@@ -4,7 +4,8 @@
 //   k_pair_paint      per plane block: for each ACGT symbol a the positions holding a map, in
 //                     order, to the consecutive rows A[a], A[a]+1, ... (A[a] = the block's
 //                     header value), so S2[i] = S[LF(i)] is read from a contiguous row range;
-//                     every lane owns two pair chunks outright (plain stores, no atomics)
+//                     every lane owns one word of each of the five planes of its pair block
+//                     outright (plain stores, no atomics)
 //   k_pair_tile_sums  16 pair counts per tile of 1024 pair blocks
 //   k_pair_scan       exclusive prefix over tiles
 //   k_pair_headers    24-bit per-block header fields, relative to the 2^24-position superblock
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void k_pair_paint(const uint4 *__restrict__ bl
         const uint4 c = blocks[b * 8 + sub];
         // header words of the whole block: low words from chunks 1,2,3,5, high bytes from chunks 6,7
         const uint32_t hi03 = __shfl(c.w, int(group_base + 6)), hi45 = __shfl(c.w, int(group_base + 7));
-        uint32_t xa[2] = {0, 0}, yb[2] = {0, 0}, valid[2] = {0, 0};
+        uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0, valid = 0;  // my 32 positions' bits of the five planes
         uint64_t cached_chunk = ~0ull;
         uint4 tc = make_uint4(0, 0, 0, 0);
 #pragma unroll
@@ -79,29 +80,39 @@ __global__ __launch_bounds__(256) void k_pair_paint(const uint4 *__restrict__ bl
                 const uint32_t bit = uint32_t(target) & 31u;
                 const uint32_t s2 = ((tc.x >> bit) & 1u) | (((tc.y >> bit) & 1u) << 1) | (((tc.z >> bit) & 1u) << 2);
                 if (is_acgt(s2)) {
-                    const uint32_t b2 = acgt_code(s2), half = q >> 4, at = q & 15u;
-                    const uint32_t xa_bits = ((a2 & 1u) << at) | (((a2 >> 1) & 1u) << (16u + at));
-                    const uint32_t yb_bits = ((b2 & 1u) << at) | (((b2 >> 1) & 1u) << (16u + at));
-                    if (half) { xa[1] |= xa_bits; yb[1] |= yb_bits; valid[1] |= 1u << at; }
-                    else      { xa[0] |= xa_bits; yb[0] |= yb_bits; valid[0] |= 1u << at; }
+                    const uint32_t b2 = acgt_code(s2);
+                    a0 |= (a2 & 1u) << q;
+                    a1 |= (a2 >> 1) << q;
+                    b0 |= (b2 & 1u) << q;
+                    b1 |= (b2 >> 1) << q;
+                    valid |= 1u << q;
                 }
                 ++target;
             }
         }
-        // my 32 positions are pair chunks 2*(sub&3), +1 of pair block 2b + (sub>>2)
-        uint4 *out = pair_blocks + (2 * b + (sub >> 2)) * 8 + 2 * (sub & 3u);
-        out[0] = make_uint4(xa[0], yb[0], valid[0], 0u);
-        out[1] = make_uint4(xa[1], yb[1], valid[1], 0u);
+        // my 32 positions are word (sub & 3) of every plane of pair block 2b + (sub >> 2)
+        uint32_t *out = reinterpret_cast<uint32_t *>(pair_blocks + (2 * b + (sub >> 2)) * 8) + (sub & 3u);
+        out[0] = a0;
+        out[4] = a1;
+        out[8] = b0;
+        out[12] = b1;
+        out[16] = valid;
     }
 }
 
 // the 16 pair counts of one pair block, added into acc[]
 __device__ __forceinline__ void add_block_pair_counts(const uint4 *__restrict__ blk, uint32_t acc[16]) {
+    const uint4 a0 = blk[0], a1 = blk[1], b0 = blk[2], b1 = blk[3], v = blk[kPairValidChunk];
+    const uint32_t A0[4] = {a0.x, a0.y, a0.z, a0.w}, A1[4] = {a1.x, a1.y, a1.z, a1.w};
+    const uint32_t B0[4] = {b0.x, b0.y, b0.z, b0.w}, B1[4] = {b1.x, b1.y, b1.z, b1.w};
+    const uint32_t V[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const uint4 c = blk[j];
+    for (int w = 0; w < 4; ++w) {
+        uint32_t ia[4], ib[4];  // positions whose first / second symbol is A C G T
+        ia[0] = ~A0[w] & ~A1[w] & V[w]; ia[1] = A0[w] & ~A1[w] & V[w]; ia[2] = ~A0[w] & A1[w] & V[w]; ia[3] = A0[w] & A1[w] & V[w];
+        ib[0] = ~B0[w] & ~B1[w]; ib[1] = B0[w] & ~B1[w]; ib[2] = ~B0[w] & B1[w]; ib[3] = B0[w] & B1[w];
 #pragma unroll
-        for (uint32_t p = 0; p < 16; ++p) acc[p] += pair_chunk_count(c, p >> 2, p & 3u, 16);
+        for (uint32_t p = 0; p < 16; ++p) acc[p] += uint32_t(__popc(ia[p >> 2] & ib[p & 3u]));
     }
 }
 
@@ -197,14 +208,14 @@ __global__ __launch_bounds__(kThreads) void k_pair_headers(uint4 *__restrict__ p
             uint4 *blk = pair_blocks + pb * 8;
             uint32_t add[16] = {0};
             add_block_pair_counts(blk, add);
+            uint32_t lo[8], hi[4] = {0, 0, 0, 0};  // 16 x u16 low halves, 16 x u8 high bytes
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t f0 = rel[2 * j] & 0xFFFFFFu, f1 = rel[2 * j + 1] & 0xFFFFFFu;
-                uint4 c = blk[j];
-                c.z = (c.z & 0xFFFFu) | ((f0 & 0xFFFFu) << 16);
-                c.w = (f0 >> 16) | (f1 << 8);
-                blk[j] = c;
-            }
+            for (int j = 0; j < 8; ++j) lo[j] = (rel[2 * j] & 0xFFFFu) | ((rel[2 * j + 1] & 0xFFFFu) << 16);
+#pragma unroll
+            for (int p = 0; p < 16; ++p) hi[p >> 2] |= ((rel[p] >> 16) & 0xFFu) << (8 * (p & 3));
+            blk[kPairLoChunk] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            blk[kPairLoChunk + 1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+            blk[kPairHiChunk] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
 #pragma unroll
             for (int p = 0; p < 16; ++p) rel[p] += add[p];
         }

@@ -108,21 +108,30 @@ __device__ __forceinline__ void store_count(const QuerySource &src, uint64_t v, 
     }
 }
 
-// One lane = one query: validate (symbols >= 6 -> result u64::MAX + status flag, the reference
-// asserts, msbwt_core.rs:127), pack 3 bits/symbol in search order, look the last `depth` symbols
-// up in the suffix table (behind the presence filter when filter_now).  Returns true when a
-// search is still needed (l, h, w, rem filled), false when `result` already is the count.
-// Matrix mode: `staged` = this lane's k bytes in LDS; reads mode: v = global query index.
-template <bool kReads, int kWords>
-__device__ __forceinline__ bool prepare_query(const QuerySource &src, const TableEnv &env, const uint8_t *staged, uint64_t v,
-                                              bool filter_now, uint32_t *__restrict__ flags, uint64_t &l, uint64_t &h,
-                                              uint32_t (&w)[kWords], uint32_t &rem, uint64_t &result, bool &looked_up,
-                                              bool &passed) {
-    constexpr int kBits = (kWords + 1) / 2;  // u64 words of packed symbols during setup
-    const uint32_t k = src.k, depth = env.depth;
+// ---- one lane = one query: setup in three pieces -----------------------------------------------
+// pack_query:   read the k symbols (matrix mode: this lane's staged bytes in LDS; reads mode: the
+//               window of global query v), note symbols >= 6 (the reference asserts,
+//               msbwt_core.rs:127), pack 3 bits/symbol in search order (last symbol first) and form
+//               the suffix-table index of the first `depth` steps.
+// table lookup: env.table[tidx] behind the presence filter -- issued by the caller, so that the
+//               lanes kernel can leave the load in flight across a search step.
+// unpack_words: drop the table's symbols, hand the rest over as kWords dwords.
+template <int kWords>
+struct PackedQuery {
+    static constexpr int kBits = (kWords + 1) / 2;
     uint64_t bits[kBits];  // symbol of step t (t = 0 first) at bits [3t, 3t+3) of the little-endian words
+    uint32_t tidx;         // table index of steps 0..depth-1 (A C G T -> 0..3, step t at bits [2t, 2t+2))
+    bool bad;              // a symbol code >= 6
+    bool acgt;             // steps 0..depth-1 are all ACGT: the table applies
+};
+
+template <bool kReads, int kWords>
+__device__ __forceinline__ void pack_query(const QuerySource &src, uint32_t depth, const uint8_t *staged, uint64_t v,
+                                           PackedQuery<kWords> &pq) {
+    constexpr int kBits = PackedQuery<kWords>::kBits;
+    const uint32_t k = src.k;
 #pragma unroll
-    for (int j = 0; j < kBits; ++j) bits[j] = 0;
+    for (int j = 0; j < kBits; ++j) pq.bits[j] = 0;
     uint32_t bad = 0, acgt = 1, tidx = 0;
     const uint8_t *mine = staged;
     bool rc = false;
@@ -156,47 +165,71 @@ __device__ __forceinline__ bool prepare_query(const QuerySource &src, const Tabl
         const uint32_t pos = 3u * t, word = pos >> 6, off = pos & 63u;
 #pragma unroll
         for (int j = 0; j < kBits; ++j) {
-            if (word == uint32_t(j)) bits[j] |= uint64_t(s & 7u) << off;
-            if (j > 0 && word == uint32_t(j - 1) && off > 61u) bits[j] |= uint64_t(s & 7u) >> (64u - off);
+            if (word == uint32_t(j)) pq.bits[j] |= uint64_t(s & 7u) << off;
+            if (j > 0 && word == uint32_t(j - 1) && off > 61u) pq.bits[j] |= uint64_t(s & 7u) >> (64u - off);
         }
-        if (t < depth) {  // table index: A C G T -> 0..3, step t at bits [2t, 2t+2)
+        if (t < depth) {
             acgt &= acgt_bit(s);
             tidx |= (acgt_code(s) & 3u) << (2u * t);
         }
     }
+    pq.tidx = tidx;
+    pq.bad = bad != 0u;
+    pq.acgt = acgt != 0u;
+}
+
+// the remaining symbols after `skip` steps (0 or the table depth), as kWords dwords
+template <int kWords>
+__device__ __forceinline__ void unpack_words(const PackedQuery<kWords> &pq, uint32_t skip, uint32_t (&w)[kWords]) {
+    constexpr int kBits = PackedQuery<kWords>::kBits;
+    uint64_t bits[kBits];
+    const uint32_t sh = 3u * skip;  // 0, or 3..48
+#pragma unroll
+    for (int j = 0; j < kBits; ++j)
+        bits[j] = sh == 0u ? pq.bits[j] : ((pq.bits[j] >> sh) | (j + 1 < kBits ? pq.bits[j + 1] << (64u - sh) : 0ull));
+#pragma unroll
+    for (int i = 0; i < kWords; ++i) w[i] = uint32_t(bits[i >> 1] >> ((i & 1) * 32));
+}
+
+// The whole setup of one query, table lookup included (the 8-lane-group kernel).  Returns true
+// when a search is still needed (l, h, w, rem filled), false when `result` already is the count.
+template <bool kReads, int kWords>
+__device__ __forceinline__ bool prepare_query(const QuerySource &src, const TableEnv &env, const uint8_t *staged, uint64_t v,
+                                              bool filter_now, uint32_t *__restrict__ flags, uint64_t &l, uint64_t &h,
+                                              uint32_t (&w)[kWords], uint32_t &rem, uint64_t &result, bool &looked_up,
+                                              bool &passed) {
+    PackedQuery<kWords> pq;
+    pack_query<kReads, kWords>(src, env.depth, staged, v, pq);
     l = 0;
     h = env.total;
-    rem = k;
-    if (bad) {
+    rem = src.k;
+    if (pq.bad) {
         result = ~0ull;
         atomicOr(flags, kFlagInvalidSymbol);
         return false;
     }
-    if (env.use_table && acgt) {
+    uint32_t skip = 0;
+    if (env.use_table && pq.acgt) {
         // L2-resident presence bit first: an absent suffix never touches the table line
         bool maybe = true;
         if (filter_now) {
-            const uint32_t fi = tidx & env.filter_mask;
+            const uint32_t fi = pq.tidx & env.filter_mask;
             maybe = ((env.filter[fi >> 5] >> (fi & 31u)) & 1u) != 0u;
             looked_up = true;
             passed = maybe;
         }
         uint4 e = make_uint4(0, 0, 0, 0);  // empty range: count 0
-        if (maybe) e = env.table[tidx];
+        if (maybe) e = env.table[pq.tidx];
         l = (uint64_t(e.y) << 32) | e.x;
         h = (uint64_t(e.w) << 32) | e.z;
-        rem = k - depth;
-        const uint32_t sh = 3u * depth;  // 3..48
-#pragma unroll
-        for (int j = 0; j < kBits; ++j)
-            bits[j] = (bits[j] >> sh) | (j + 1 < kBits ? bits[j + 1] << (64u - sh) : 0ull);
+        skip = env.depth;
+        rem = src.k - env.depth;
     }
     if (rem == 0u || l == h) {
         result = h - l;
         return false;
     }
-#pragma unroll
-    for (int i = 0; i < kWords; ++i) w[i] = uint32_t(bits[i >> 1] >> ((i & 1) * 32));
+    unpack_words<kWords>(pq, skip, w);
     return true;
 }
 

@@ -1,0 +1,150 @@
+"""GPU parity at the sizes of the BASELINE.json configs (not only on toy genomes): the HIP path
+through the C ABI against the CPU oracle on large samples, plus whole-batch equality of the two
+search kernels.  Needs an MI355X and a few minutes (the C4 index alone takes about a minute of
+host time to build)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import rust_msbwt_amd as msbwt
+from rust_msbwt_amd import RleBWT
+from oracle import oracle as orc
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+NCPU = min(os.cpu_count() or 1, 16)
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch, torch.device("cuda", 0)
+
+
+def _count_matrix(torch, dev, bwt, d_q):
+    n, k = d_q.shape
+    out = torch.empty(n, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    bwt.count_kmers_device(d_q.data_ptr(), k, n, out.data_ptr(), stream)
+    bwt.device_status(stream)
+    return out
+
+
+def _revcomp(codes):
+    comp = np.array([0, 5, 3, 2, 4, 1], dtype=np.uint8)  # string_util.rs:12
+    return np.ascontiguousarray(comp[codes[:, ::-1]])
+
+
+def test_c3_full_all_read_kmers_fused_both_strands():
+    """BASELINE configs[2] at full size: ALL 31-mers of ALL 1 547 217 reads (1.857e8 windows), forward
+    and reverse-complemented, prepared in-kernel; 1e6 sampled windows per strand against the oracle."""
+    import synth
+    torch, dev = _torch()
+    npy, reads = synth.workload_index("c3")
+    k = 31
+    nread, rlen = reads.shape
+    wins = rlen - k + 1
+    bwt = RleBWT(device=0)
+    bwt.load_numpy_file(npy)
+    ref = orc.OracleRleBWT()
+    ref.load_numpy_file(npy)
+    assert bwt.get_total_size() == ref.get_total_size() == nread * (rlen + 1)
+    d_reads = torch.from_numpy(reads).to(dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    outs = {}
+    for mode in ("lanes", "groups"):
+        bwt.set_search_kernel(mode)
+        fwd = torch.empty(nread * wins, dtype=torch.int64, device=dev)
+        rc = torch.empty(nread * wins, dtype=torch.int64, device=dev)
+        bwt.count_read_kmers_device(d_reads.data_ptr(), rlen, nread, k, False, fwd.data_ptr(), rc.data_ptr(), stream)
+        bwt.device_status(stream)
+        outs[mode] = (fwd, rc)
+    # the two search kernels agree on every one of the 3.7e8 counts
+    assert torch.equal(outs["lanes"][0], outs["groups"][0]) and torch.equal(outs["lanes"][1], outs["groups"][1])
+    fwd, rc = outs["lanes"]
+    assert int(fwd.min()) >= 1  # every window occurs at least in its own read
+    rng = np.random.default_rng(31)
+    ids = np.sort(rng.choice(nread * wins, size=1_000_000, replace=False))
+    windows = np.ascontiguousarray(reads[(ids // wins)[:, None], (ids % wins)[:, None] + np.arange(k)[None, :]])
+    d_ids = torch.from_numpy(ids).to(dev)
+    exp_f = ref.count_kmers(windows, nthreads=NCPU)
+    exp_r = ref.count_kmers(_revcomp(windows), nthreads=NCPU)
+    assert np.array_equal(fwd[d_ids].cpu().numpy().astype(np.uint64), exp_f)
+    assert np.array_equal(rc[d_ids].cpu().numpy().astype(np.uint64), exp_r)
+    # the explicit n x k matrix path gives the same counts for the sampled windows
+    got_m = _count_matrix(torch, dev, bwt, torch.from_numpy(windows).to(dev))
+    assert np.array_equal(got_m.cpu().numpy().astype(np.uint64), exp_f)
+
+
+def test_c4_real_bwt_random_and_read_derived_31mers():
+    """BASELINE configs[3]'s index and batch at full size on one GPU: the MSBWT of 12 888 833 reads
+    (1.95e9 symbols, built here in the reference's ordering), 1e8 random 31-mers (1e6 sampled against
+    the oracle, whole batch lanes == groups) and 2e7 read-derived 31-mers."""
+    import synth
+    torch, dev = _torch()
+    npy, reads = synth.workload_index("c4")
+    k = 31
+    bwt = RleBWT(device=0)
+    bwt.load_numpy_file(npy)
+    ref = orc.OracleRleBWT()
+    ref.load_numpy_file(npy)
+    total = ref.get_total_size()
+    assert bwt.get_total_size() == total == reads.shape[0] * (reads.shape[1] + 1)
+    assert [bwt.get_symbol_count(s) for s in range(6)] == [ref.get_symbol_count(s) for s in range(6)]
+    rng = np.random.default_rng(41)
+    for name, q in (("random", synth.random_kmers(100_000_000, k, synth.CONFIGS["c4"]["qseed"])),
+                    ("reads", synth.read_kmers(reads, k, limit=20_000_000, seed=7))):
+        d_q = torch.from_numpy(q).to(dev)
+        bwt.set_search_kernel("lanes")
+        a = _count_matrix(torch, dev, bwt, d_q)
+        bwt.set_search_kernel("groups")
+        b = _count_matrix(torch, dev, bwt, d_q)
+        assert torch.equal(a, b), name
+        ids = np.sort(rng.choice(len(q), size=1_000_000, replace=False))
+        exp = ref.count_kmers(q[ids], nthreads=NCPU)
+        assert np.array_equal(a[torch.from_numpy(ids).to(dev)].cpu().numpy().astype(np.uint64), exp), name
+        if name == "reads":
+            assert int(a.min()) >= 1
+        del d_q, a, b
+
+
+def test_stream_beyond_2_pow_33_symbols_hbm_regime():
+    """A 9e9-symbol synthetic RLE stream (total > 2^33: positions and counts need more than 32 bits, the
+    index is far larger than the Infinity Cache): present (LF-walk) and absent 31-mers and batched
+    constrain_range at l, h > 2^32, all against the oracle on the same stream."""
+    import synth
+    sys.path.insert(0, ROOT)
+    import bench
+    torch, dev = _torch()
+    rle, total = synth.rle_stream(9_000_000_000, 6.0, 123)
+    assert total > 2**33
+    bwt = RleBWT(device=0)
+    bwt.load_vector(rle)
+    ref = orc.OracleRleBWT()
+    ref.load_vector(rle)
+    assert bwt.get_total_size() == total == ref.get_total_size()
+    k = 31
+    present = bench.walk_kmers(torch, np, bwt, dev, total, 2_000_000, k, 99)
+    absent = bench.device_random_kmers(torch, dev, 2_000_000, k, 98)
+    d_q = torch.cat([present, absent])
+    q = d_q.cpu().numpy()
+    exp = ref.count_kmers(q, nthreads=NCPU)
+    for mode in ("lanes", "groups"):
+        bwt.set_search_kernel(mode)
+        got = _count_matrix(torch, dev, bwt, d_q).cpu().numpy().astype(np.uint64)
+        assert np.array_equal(got, exp), mode
+    assert exp[:2_000_000].min() >= 1 and (exp[2_000_000:] == 0).mean() > 0.9
+    # batched constrain_range with both bounds beyond 2^32
+    rng = np.random.default_rng(17)
+    n = 1_000_000
+    a = rng.integers(2**32, total + 1, size=n, dtype=np.uint64)
+    b = a + rng.integers(0, 5000, size=n).astype(np.uint64) * rng.integers(0, 2, size=n).astype(np.uint64)
+    b = np.minimum(b, np.uint64(total))
+    syms = rng.integers(0, 6, size=n).astype(np.uint8)
+    gl, gh = bwt.constrain_ranges(syms, a, b)
+    ol, oh = ref.constrain_ranges(syms, a, b)
+    assert np.array_equal(gl, ol) and np.array_equal(gh, oh)
+    assert int(gl.max()) > 2**32

@@ -17,14 +17,22 @@ cd /tmp
 LEAN="--no-cpu-baseline --no-c5 --parity-sample 20000 --stats-sample 200000"
 
 echo "[profile] kernel-trace + stats" >&2
-rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o run -- python3 "$ROOT/bench.py" "$@" $LEAN --steps 10 --warmup 2 \
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 "$ROOT/bench.py" "$@" $LEAN --steps 10 --warmup 2 \
     > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 
 for group in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS"; do
     first=${group%% *}
     echo "[profile] pmc $group" >&2
-    rocprofv3 --pmc $group --kernel-trace -d "$OUT/pmc_$first" -o run -- python3 "$ROOT/bench.py" "$@" $LEAN --no-oracle --steps 3 --warmup 1 \
+    rocprofv3 --pmc $group --kernel-include-regex "k_count_kmers" --kernel-trace --output-format csv -d "$OUT/pmc_$first" -o run -- python3 "$ROOT/bench.py" "$@" $LEAN --no-oracle --steps 3 --warmup 1 \
         > "$OUT/bench_pmc_$first.json" 2> "$OUT/pmc_$first.err"
 done
-find "$OUT" -name "*kernel_trace.csv" -size +8M -delete   # keep what travels back small
+# only gpurun_out/ travels back (64 MiB at most): keep the aggregated stats, the counter rows of the
+# query kernels, the bench lines and the logs; everything else (per-dispatch traces of the workload
+# generator's thousands of launches, databases) stays behind
+for f in $(find "$OUT" -name "*counter_collection.csv"); do
+    (head -1 "$f"; grep "k_count_kmers" "$f" || true) > "$f.tmp" && mv "$f.tmp" "$f"
+done
+find "$OUT" -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" ! -name "*.json" ! -name "*.err" -size +64k -print -delete | sed 's/^/[profile] dropped /' >&2
+find "$OUT" -type f -size +2M -print -delete | sed 's/^/[profile] dropped (too big) /' >&2
+du -sh "$OUT" >&2
 echo "[profile] done: $OUT" >&2
