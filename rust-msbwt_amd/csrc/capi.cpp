@@ -12,6 +12,7 @@
 
 #include "../../include/msbwt_hip.h"
 #include "device_build.hpp"
+#include "host_pipeline.hpp"
 #include "kernels.hpp"
 #include "npy_io.hpp"
 #include "pair_index.hpp"
@@ -45,6 +46,7 @@ struct msbwt_rle {
     hipStream_t stream = nullptr;  // used by the host-pointer entry points
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
+    HostPipeline pipe;             // pinned, triple-buffered path of the host-pointer batch entry points
     bool timing = false;
     std::vector<hipEvent_t> events;  // start/stop pairs not yet read back
     double timed_ms = 0.0;
@@ -427,6 +429,7 @@ void msbwt_rle_free(msbwt_rle *h) {
         DeviceScope scope(h->device);
         release_index(h);
         for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+        h->pipe.release();
         if (h->d_stage) (void)hipFree(h->d_stage);
         if (h->d_flags) (void)hipFree(h->d_flags);
         if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -525,27 +528,25 @@ int msbwt_rle_count_read_kmers(const msbwt_rle *ch, const uint8_t *reads, size_t
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
     const size_t windows = read_len - k + 1;
-    // bounded staging: batches of reads whose windows number at most ~4 Mi
-    const size_t batch = std::max<size_t>(1, std::min<size_t>(n_reads, (size_t(1) << 22) / windows + 1));
-    uint32_t all_flags = 0;
-    for (size_t done = 0; done < n_reads; done += batch) {
-        const size_t m = std::min(batch, n_reads - done);
-        const size_t read_bytes = (m * read_len + 15) / 16 * 16, cnt_bytes = m * windows * sizeof(uint64_t);
-        int rc = ensure_stage(h, read_bytes + 2 * cnt_bytes);
-        if (rc) return rc;
-        uint8_t *d_r = static_cast<uint8_t *>(h->d_stage);
-        uint64_t *d_f = reinterpret_cast<uint64_t *>(d_r + read_bytes), *d_c = d_f + m * windows;
-        HIP_TRY(h, hipMemcpyAsync(d_r, reads + done * read_len, m * read_len, hipMemcpyHostToDevice, h->stream));
-        rc = launch_read_kmers_locked(h, d_r, read_len, m, k, ascii, out_fwd ? d_f : nullptr, out_rc ? d_c : nullptr, h->stream, kHostFlags);
-        if (rc) return rc;
-        if (out_fwd) HIP_TRY(h, hipMemcpyAsync(out_fwd + done * windows, d_f, cnt_bytes, hipMemcpyDeviceToHost, h->stream));
-        if (out_rc) HIP_TRY(h, hipMemcpyAsync(out_rc + done * windows, d_c, cnt_bytes, hipMemcpyDeviceToHost, h->stream));
-        uint32_t flags = 0;
-        rc = read_flags(h, h->stream, kHostFlags, &flags);
-        if (rc) return rc;
-        all_flags |= flags;
-    }
-    return flags_to_code(h, all_flags);
+    // pipelined: chunks of reads holding ~2 Mi windows travel host -> pinned -> HBM -> pinned -> host
+    const size_t chunk = std::max<size_t>(1, (size_t(1) << 21) / windows);
+    std::vector<HostArray> ins(1), outs;
+    ins[0].in = reads;
+    ins[0].item_bytes = read_len;
+    if (out_fwd) { HostArray a; a.out = out_fwd; a.item_bytes = windows * sizeof(uint64_t); outs.push_back(a); }
+    if (out_rc) { HostArray a; a.out = out_rc; a.item_bytes = windows * sizeof(uint64_t); outs.push_back(a); }
+    int launch_rc = MSBWT_OK;
+    const hipError_t e = h->pipe.run(n_reads, chunk, ins, outs, h->stream,
+                                     [&](size_t, size_t m, void *const *d_in, void *const *d_out, hipStream_t stream) -> hipError_t {
+                                         void *d_f = out_fwd ? d_out[0] : nullptr, *d_c = out_rc ? d_out[out_fwd ? 1 : 0] : nullptr;
+                                         launch_rc = launch_read_kmers_locked(h, d_in[0], read_len, m, k, ascii, d_f, d_c, stream, kHostFlags);
+                                         return launch_rc ? hipErrorUnknown : hipSuccess;
+                                     });
+    if (launch_rc) return launch_rc;
+    if (e != hipSuccess) return hip_fail(h, e, "count_read_kmers pipeline");
+    uint32_t flags = 0;
+    const int rc = read_flags(h, h->stream, kHostFlags, &flags);
+    return rc ? rc : flags_to_code(h, flags);
 }
 
 int msbwt_rle_count_ragged_read_kmers(const msbwt_rle *ch, const uint8_t *reads, const uint64_t *read_offsets,
@@ -630,26 +631,25 @@ int msbwt_rle_count_kmers(const msbwt_rle *ch, const uint8_t *kmers, size_t k, s
     if (n && (!out_counts || (!kmers && k))) return fail(h, MSBWT_ERR_INVALID_ARG, "null pointer");
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
-    // bounded staging: chunks of up to 4 Mi queries travel host -> HBM -> host
-    const size_t chunk = std::min<size_t>(n, size_t(1) << 22);
-    const size_t kmer_bytes = (chunk * k + 15) / 16 * 16;
-    int rc = ensure_stage(h, kmer_bytes + chunk * sizeof(uint64_t) + 16);
-    if (rc) return rc;
-    uint8_t *d_k = static_cast<uint8_t *>(h->d_stage);
-    uint64_t *d_c = reinterpret_cast<uint64_t *>(d_k + kmer_bytes);
-    uint32_t all_flags = 0;
-    for (size_t done = 0; done < n; done += chunk) {
-        const size_t m = std::min(chunk, n - done);
-        if (k) HIP_TRY(h, hipMemcpyAsync(d_k, kmers + done * k, m * k, hipMemcpyHostToDevice, h->stream));
-        rc = launch_count(h, d_k, k, m, d_c, h->stream, kHostFlags);
-        if (rc) return rc;
-        HIP_TRY(h, hipMemcpyAsync(out_counts + done, d_c, m * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
-        uint32_t flags = 0;
-        rc = read_flags(h, h->stream, kHostFlags, &flags);
-        if (rc) return rc;
-        all_flags |= flags;
-    }
-    return flags_to_code(h, all_flags);
+    // pipelined: chunks of 2 Mi queries travel host -> pinned -> HBM -> pinned -> host, copies and
+    // kernels overlapping on three streams (host_pipeline.hpp)
+    std::vector<HostArray> ins(1), outs(1);
+    ins[0].in = kmers;
+    ins[0].item_bytes = k;
+    outs[0].out = out_counts;
+    outs[0].item_bytes = sizeof(uint64_t);
+    int launch_rc = MSBWT_OK;
+    const hipError_t e = h->pipe.run(n, size_t(1) << 21, ins, outs, h->stream,
+                                     [&](size_t, size_t m, void *const *d_in, void *const *d_out, hipStream_t stream) -> hipError_t {
+                                         launch_rc = launch_count(h, static_cast<const uint8_t *>(d_in[0]), k, m,
+                                                                  static_cast<uint64_t *>(d_out[0]), stream, kHostFlags);
+                                         return launch_rc ? hipErrorUnknown : hipSuccess;
+                                     });
+    if (launch_rc) return launch_rc;
+    if (e != hipSuccess) return hip_fail(h, e, "count_kmers pipeline");
+    uint32_t flags = 0;
+    const int rc = read_flags(h, h->stream, kHostFlags, &flags);
+    return rc ? rc : flags_to_code(h, flags);
 }
 
 int msbwt_rle_constrain_ranges(const msbwt_rle *ch, const uint8_t *syms, const uint64_t *l, const uint64_t *hh,
@@ -661,28 +661,23 @@ int msbwt_rle_constrain_ranges(const msbwt_rle *ch, const uint8_t *syms, const u
     if (n && (!syms || !l || !hh || !out_l || !out_h)) return fail(h, MSBWT_ERR_INVALID_ARG, "null pointer");
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
-    const size_t chunk = std::min<size_t>(n, size_t(1) << 22);
-    const size_t sym_bytes = (chunk + 15) / 16 * 16;
-    int rc = ensure_stage(h, sym_bytes + 4 * chunk * sizeof(uint64_t));
-    if (rc) return rc;
-    uint8_t *d_s = static_cast<uint8_t *>(h->d_stage);
-    uint64_t *d_l = reinterpret_cast<uint64_t *>(d_s + sym_bytes);
-    uint64_t *d_h = d_l + chunk, *d_ol = d_h + chunk, *d_oh = d_ol + chunk;
-    uint32_t all_flags = 0;
-    for (size_t done = 0; done < n; done += chunk) {
-        const size_t m = std::min(chunk, n - done);
-        HIP_TRY(h, hipMemcpyAsync(d_s, syms + done, m, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(d_l, l + done, m * 8, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(d_h, hh + done, m * 8, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, launch_constrain_ranges(view_of(h), d_s, d_l, d_h, m, d_ol, d_oh, h->d_flags, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(out_l + done, d_ol, m * 8, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(out_h + done, d_oh, m * 8, hipMemcpyDeviceToHost, h->stream));
-        uint32_t flags = 0;
-        rc = read_flags(h, h->stream, kHostFlags, &flags);
-        if (rc) return rc;
-        all_flags |= flags;
-    }
-    return flags_to_code(h, all_flags);
+    std::vector<HostArray> ins(3), outs(2);
+    ins[0].in = syms; ins[0].item_bytes = 1;
+    ins[1].in = l; ins[1].item_bytes = sizeof(uint64_t);
+    ins[2].in = hh; ins[2].item_bytes = sizeof(uint64_t);
+    outs[0].out = out_l; outs[0].item_bytes = sizeof(uint64_t);
+    outs[1].out = out_h; outs[1].item_bytes = sizeof(uint64_t);
+    const hipError_t e = h->pipe.run(n, size_t(1) << 21, ins, outs, h->stream,
+                                     [&](size_t, size_t m, void *const *d_in, void *const *d_out, hipStream_t stream) -> hipError_t {
+                                         return launch_constrain_ranges(view_of(h), static_cast<const uint8_t *>(d_in[0]),
+                                                                        static_cast<const uint64_t *>(d_in[1]), static_cast<const uint64_t *>(d_in[2]), m,
+                                                                        static_cast<uint64_t *>(d_out[0]), static_cast<uint64_t *>(d_out[1]),
+                                                                        h->d_flags + kHostFlags, stream);
+                                     });
+    if (e != hipSuccess) return hip_fail(h, e, "constrain_ranges pipeline");
+    uint32_t flags = 0;
+    const int rc = read_flags(h, h->stream, kHostFlags, &flags);
+    return rc ? rc : flags_to_code(h, flags);
 }
 
 int msbwt_rle_constrain_range(const msbwt_rle *h, uint8_t sym, uint64_t l, uint64_t hh, uint64_t *out_l,

@@ -22,7 +22,7 @@
 // Setup never waits for memory by itself: a tile's bytes are fetched an iteration early and its
 // table entries ride along with the next search step's lines.  Counts go straight to the caller's
 // buffer.  Block layouts: plane_index.hpp,
-// rank_ops.hpp.  One wave per workgroup, 15.5 KiB of LDS each: 10 waves per CU.
+// rank_ops.hpp.  One wave per workgroup, 17.75 KiB of LDS each; 8 waves per CU (launch_variant).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -40,7 +40,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void global_void;
 
 constexpr int kRing = 64;        // undecided queries waiting for a lane: one tile's worth (the next tile waits in registers)
-constexpr int kRegions = 12;     // LDS-DMA regions of 8 lines: 64 first-bound lines + up to 32 second-bound lines
+constexpr int kRegions = 14;     // LDS-DMA regions of 8 lines: 64 first-bound lines + up to 48 second-bound lines
 constexpr int kLineSlots = kRegions * 8;
 constexpr uint32_t kMaxSecond = uint32_t(kLineSlots) - 64u;  // lanes beyond that with a second line sit the step out
 
@@ -52,8 +52,8 @@ struct LaneScratchT {
     // read-back of "chunk j of my line" touches every bank exactly once per 16 lanes (lanes 16 m ..
     // 16 m + 15 own the lines of regions 2 m and 2 m + 1, whose bank phases differ by 128 bytes).
     // During phase 1 the same memory stages the tile's query bytes (2 or 4 KiB).
-    uint4 lines[(kRegions / 2) * 136];   // 12.75 KiB
-    uint64_t list[kLineSlots];        // this step's line addresses (768 B)
+    uint4 lines[(kRegions / 2) * 136];   // 14.9 KiB
+    uint64_t list[kLineSlots];        // this step's line addresses (896 B)
     WorkItemT<kWords> ring[kRing];    // 2 or 3 KiB
 };
 
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
         const uint64_t second_mask = __ballot(second);
         const uint32_t second_rank = __builtin_amdgcn_mbcnt_hi(uint32_t(second_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(second_mask), 0u));
         const uint32_t nsecond = min(uint32_t(__popcll(second_mask)), kMaxSecond);
-        // room for 32 second lines per step: a lane beyond that sits this step out (its query simply
+        // room for 48 second lines per step: a lane beyond that sits this step out (its query simply
         // takes the step in the next iteration)
         const bool act = have && !(second && second_rank >= kMaxSecond);
         const uint32_t slot_l = lane, slot_h = second ? 64u + second_rank : lane;
@@ -415,9 +415,9 @@ uint32_t resident_waves() {
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_count_kmers_lanes<kReads, kPair, kWords>, 64, 0) != hipSuccess ||
             cus <= 0 || per_cu <= 0)
             return 7u * 256u;
-        // Measured on MI355X (tools/sweep_waves.sh, human-scale index): throughput rises up to 8 waves
-        // per CU and collapses beyond (5: 3.76, 7: 4.20, 8: 4.31, 10: 3.04 x 10^9 q/s) -- past ~600
-        // lines in flight per CU the outstanding misses push the L2-resident tables out of L2.
+        // Measured on MI355X (tools/sweep_waves.sh): throughput rises up to 8 waves per CU -- two per
+        // SIMD -- and falls beyond, in the HBM regime (human-scale index: 5: 3.76, 7: 4.20, 8: 4.31,
+        // 9: 3.80, 10: 3.04 x 10^9 q/s) and on a cache-resident index alike (C3: 8: 4.32, 10: 3.13).
         per_cu = std::min(per_cu, 8);
         if (const char *env = std::getenv("MSBWT_LANES_WAVES_PER_CU")) {  // experiments
             const int want = std::atoi(env);

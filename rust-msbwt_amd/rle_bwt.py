@@ -89,13 +89,16 @@ class RleBWT(BWT):
         return int(out.value)
 
     # ---- batch forms -----------------------------------------------------------------
-    def count_kmers(self, kmers):
-        """kmers: (n, k) uint8 symbol codes -> uint64[n]."""
+    def count_kmers(self, kmers, out=None):
+        """kmers: (n, k) uint8 symbol codes -> uint64[n] (`out`: optional preallocated result array)."""
         a = np.ascontiguousarray(kmers, dtype=np.uint8)
         if a.ndim != 2:
             raise ValueError("kmers must be (n, k)")
         n, k = a.shape
-        out = np.empty(n, dtype=np.uint64)
+        if out is None:
+            out = np.empty(n, dtype=np.uint64)
+        elif out.dtype != np.uint64 or out.shape != (n,) or not out.flags.c_contiguous:
+            raise ValueError("out must be a contiguous uint64 array of length n")
         rc = _lib.lib().msbwt_rle_count_kmers(self._h, a.ctypes.data_as(C.c_void_p), k, n,
                                               out.ctypes.data_as(C.c_void_p))
         if rc:
@@ -117,7 +120,7 @@ class RleBWT(BWT):
             _raise(rc, self._h)
         return ol, oh
 
-    def count_read_kmers(self, reads, k, ascii=None, forward=True, revcomp=False):
+    def count_read_kmers(self, reads, k, ascii=None, forward=True, revcomp=False, out_fwd=None, out_rc=None):
         """Counts every k-mer window of every read, fused on the GPU (no n x k query matrix).
 
         reads: (n_reads, read_len) uint8 -- symbol codes, or ASCII bytes (`ascii=True`; a list of
@@ -132,8 +135,11 @@ class RleBWT(BWT):
             raise ValueError("reads must be (n_reads, read_len)")
         n, length = a.shape
         w = length - k + 1
-        fwd = np.empty((n, max(w, 0)), dtype=np.uint64) if forward else None
-        rc = np.empty((n, max(w, 0)), dtype=np.uint64) if revcomp else None
+        fwd = (out_fwd if out_fwd is not None else np.empty((n, max(w, 0)), dtype=np.uint64)) if forward else None
+        rc = (out_rc if out_rc is not None else np.empty((n, max(w, 0)), dtype=np.uint64)) if revcomp else None
+        for o in (fwd, rc):
+            if o is not None and (o.dtype != np.uint64 or o.shape != (n, max(w, 0)) or not o.flags.c_contiguous):
+                raise ValueError("output arrays must be contiguous uint64 of shape (n_reads, read_len - k + 1)")
         code = _lib.lib().msbwt_rle_count_read_kmers(
             self._h, a.ctypes.data_as(C.c_void_p), length, n, k, 1 if ascii else 0,
             fwd.ctypes.data_as(C.c_void_p) if fwd is not None else None,

@@ -1,15 +1,32 @@
+"""Throughput of the HOST-pointer batch entry points (PCIe copies included): msbwt_rle_count_kmers and
+msbwt_rle_count_read_kmers through the pinned three-stage pipeline (csrc/host_pipeline.hpp).
+The reported `value` of bench.py never includes PCIe; these are the numbers DESIGN.md section 5 quotes."""
 import sys, time, numpy as np
 sys.path.insert(0, '.')
 import rust_msbwt_amd as m
 import synth
+from oracle import oracle as orc
 npy, rd = synth.workload_index('c2')
 b = m.RleBWT(); b.load_numpy_file(npy)
-q = synth.random_kmers(10_000_000, 21, 3)
+ref = orc.OracleRleBWT(); ref.load_numpy_file(npy)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
+q = synth.random_kmers(n, 21, 3)
+out = np.zeros(n, dtype=np.uint64)  # touched: no first-touch page faults inside the timed region
 b.count_kmers(q[:1000])
-for _ in range(3):
-    t = time.time(); c = b.count_kmers(q); dt = time.time() - t
-    print("host API count_kmers: %.3e q/s (%.1f ms, %.2f GB/s in+out)" % (len(q) / dt, dt * 1e3, (q.nbytes + c.nbytes) / dt / 1e9))
-reads = rd[:200000]
-for _ in range(2):
-    t = time.time(); f, r = b.count_read_kmers(reads, 31, ascii=False, revcomp=True); dt = time.time() - t
-    print("host API count_read_kmers both strands: %.3e windows/s (%.1f ms)" % (2 * f.size / dt, dt * 1e3))
+for _ in range(4):
+    t = time.time(); c = b.count_kmers(q, out=out); dt = time.time() - t
+    print("host API count_kmers: %.3e 21-mers/s (%.1f ms, %.2f GB/s in+out)" % (len(q) / dt, dt * 1e3, (q.nbytes + c.nbytes) / dt / 1e9), flush=True)
+sel = np.random.default_rng(1).choice(n, size=200_000, replace=False)
+assert np.array_equal(out[sel], ref.count_kmers(q[sel], nthreads=8)), "host path differs from the oracle"
+reads = rd
+of = np.zeros((reads.shape[0], reads.shape[1] - 30), dtype=np.uint64)
+oc = np.zeros_like(of)
+for _ in range(4):
+    t = time.time(); f, r = b.count_read_kmers(reads, 31, ascii=False, revcomp=True, out_fwd=of, out_rc=oc); dt = time.time() - t
+    print("host API count_read_kmers both strands: %.3e windows/s (%.1f ms, %d reads)" % (2 * f.size / dt, dt * 1e3, len(reads)), flush=True)
+k = 31
+ids = np.random.default_rng(2).choice(f.size, size=100_000, replace=False)
+w = reads.shape[1] - k + 1
+win = np.ascontiguousarray(reads[(ids // w)[:, None], (ids % w)[:, None] + np.arange(k)[None, :]])
+assert np.array_equal(f.reshape(-1)[ids], ref.count_kmers(win, nthreads=8)), "fused host path differs from the oracle"
+print("parity ok")
