@@ -84,7 +84,10 @@ int msbwt_rle_constrain_ranges(const msbwt_rle *bwt, const uint8_t *syms, const 
                                const uint64_t *h, size_t n, uint64_t *out_l, uint64_t *out_h);
 /* Same, with DEVICE pointers on the handle's device; asynchronous on `hip_stream` (a
  * hipStream_t, NULL = default stream).  Invalid input is reported by
- * msbwt_rle_device_status(), which synchronises the stream. */
+ * msbwt_rle_device_status(), which synchronises the stream (the device entry points keep their
+ * own status word: a host-pointer call on another thread never sees or clears it).
+ * Alignment: d_kmers should be 16-byte aligned -- then 1 <= k <= 64 runs the fast kernels; an
+ * unaligned batch is still counted correctly, by the slower generic kernel. */
 int msbwt_rle_count_kmers_device(const msbwt_rle *bwt, const void *d_kmers, size_t k, size_t n,
                                  void *d_out_counts, void *hip_stream);
 int msbwt_rle_constrain_ranges_device(const msbwt_rle *bwt, const void *d_syms, const void *d_l,
@@ -112,6 +115,32 @@ int msbwt_rle_count_read_kmers_device(const msbwt_rle *bwt, const void *d_reads,
 int msbwt_rle_count_ragged_read_kmers(const msbwt_rle *bwt, const uint8_t *reads, const uint64_t *read_offsets,
                                       size_t n_reads, size_t k, int ascii, uint64_t *out_fwd, uint64_t *out_rc,
                                       uint64_t *out_windows);
+
+/* ---- several GPUs of one node (no reference counterpart: the crate is single-threaded) ----
+ * count_kmer calls are independent and read-only (`&self`, src/msbwt_core.rs:125), so the path
+ * shards over queries: every device holds a replica of the index, a batch is cut into contiguous
+ * shards that start at multiples of 16 queries, and the counts of all shards end up in ONE buffer.
+ *
+ * msbwt_rle_replicate: a new, independent handle on `device` holding a copy of src's loaded index --
+ * blocks, suffix table, presence filter and pair index travel GPU -> GPU (hipMemcpyPeerAsync: over
+ * xGMI when peer access is available) instead of being uploaded and rebuilt per device.  NULL on
+ * error (msbwt_rle_last_error(src) says why).  `device` may equal src's own (tests). */
+msbwt_rle *msbwt_rle_replicate(const msbwt_rle *src, int device);
+/* Host batch over `n_replicas` handles (normally one per GPU; replicas[0] may be the original):
+ * one host thread and one pinned pipeline per replica, each shard's counts are copied straight
+ * into out_counts -- no collective is needed.  Same arguments and results as
+ * msbwt_rle_count_kmers / msbwt_rle_count_read_kmers on a single handle. */
+int msbwt_rle_count_kmers_multi(const msbwt_rle *const *replicas, size_t n_replicas, const uint8_t *kmers,
+                                size_t k, size_t n, uint64_t *out_counts);
+int msbwt_rle_count_read_kmers_multi(const msbwt_rle *const *replicas, size_t n_replicas, const uint8_t *reads,
+                                     size_t read_len, size_t n_reads, size_t k, int ascii, uint64_t *out_fwd,
+                                     uint64_t *out_rc);
+/* Device batch: d_kmers and d_out_counts live on replicas[0]'s device.  Shard r is copied to
+ * replica r's device, counted there and its counts are copied back into d_out_counts, all by peer
+ * copies on that replica's stream (the gather over xGMI).  Synchronous: d_kmers must be complete
+ * before the call, d_out_counts is complete when it returns. */
+int msbwt_rle_count_kmers_multi_device(const msbwt_rle *const *replicas, size_t n_replicas, const void *d_kmers,
+                                       size_t k, size_t n, void *d_out_counts);
 
 /* ---- tuning / introspection (no reference counterpart) ---- */
 /* Depth of the precomputed suffix table (the reference's stubbed kmer_cache,

@@ -33,6 +33,10 @@ SIGNATURES = {
     "msbwt_rle_count_read_kmers": (_int, [_vp, _vp, _sz, _sz, _sz, _int, _vp, _vp]),
     "msbwt_rle_count_ragged_read_kmers": (_int, [_vp, _vp, _vp, _sz, _sz, _int, _vp, _vp, _pu64]),
     "msbwt_rle_count_read_kmers_device": (_int, [_vp, _vp, _sz, _sz, _sz, _int, _vp, _vp, _vp]),
+    "msbwt_rle_replicate": (_vp, [_vp, _int]),
+    "msbwt_rle_count_kmers_multi": (_int, [_vp, _sz, _vp, _sz, _sz, _vp]),
+    "msbwt_rle_count_read_kmers_multi": (_int, [_vp, _sz, _vp, _sz, _sz, _sz, _int, _vp, _vp]),
+    "msbwt_rle_count_kmers_multi_device": (_int, [_vp, _sz, _vp, _sz, _sz, _vp]),
     "msbwt_rle_set_table_depth": (_int, [_vp, _int]),
     "msbwt_rle_get_table_depth": (_int, [_vp]),
     "msbwt_rle_set_presence_filter": (_int, [_vp, _int]),

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/msbwt_hip.h"
@@ -114,6 +115,7 @@ void release_index(msbwt_rle *h) {
     h->pair_bytes = 0;
     h->nblocks = 0;
     h->table_depth = 0;
+    h->totals = Totals{};  // an unloaded handle reports 0 symbols, not the previous BWT's
     h->loaded = false;
 }
 
@@ -325,6 +327,8 @@ int build_on_device(msbwt_rle *h, const uint8_t *rle, size_t n, Totals *t_out) {
 }
 
 // Common tail of both load entry points: build the plane blocks in HBM, then the table.
+// The previous index is released FIRST (two human-scale indexes do not fit one GPU): a failed load
+// leaves the handle unloaded -- total size and symbol counts 0, queries MSBWT_ERR_NOT_LOADED.
 int install(msbwt_rle *h, const uint8_t *rle, size_t n) {
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
@@ -379,18 +383,23 @@ int flags_to_code(msbwt_rle *h, uint32_t flags) {
 // it with HIP events on that same stream (read back by msbwt_rle_kernel_time_ms).
 template <class Launch>
 int timed_launch(msbwt_rle *h, hipStream_t stream, Launch &&launch) {
+    if (!h->timing) {
+        HIP_TRY(h, launch());
+        return MSBWT_OK;
+    }
     hipEvent_t start = nullptr, stop = nullptr;
-    if (h->timing) {
-        HIP_TRY(h, hipEventCreate(&start));
-        HIP_TRY(h, hipEventCreate(&stop));
-        HIP_TRY(h, hipEventRecord(start, stream));
+    hipError_t e = hipEventCreate(&start);
+    if (e == hipSuccess) e = hipEventCreate(&stop);
+    if (e == hipSuccess) e = hipEventRecord(start, stream);
+    if (e == hipSuccess) e = launch();
+    if (e == hipSuccess) e = hipEventRecord(stop, stream);
+    if (e != hipSuccess) {  // nothing is left behind on the error path
+        if (start) (void)hipEventDestroy(start);
+        if (stop) (void)hipEventDestroy(stop);
+        return hip_fail(h, e, "count kernel launch");
     }
-    HIP_TRY(h, launch());
-    if (h->timing) {
-        HIP_TRY(h, hipEventRecord(stop, stream));
-        h->events.push_back(start);
-        h->events.push_back(stop);
-    }
+    h->events.push_back(start);
+    h->events.push_back(stop);
     return MSBWT_OK;
 }
 
@@ -689,6 +698,175 @@ int msbwt_rle_constrain_range(const msbwt_rle *h, uint8_t sym, uint64_t l, uint6
 int msbwt_rle_count_kmer(const msbwt_rle *h, const uint8_t *kmer, size_t k, uint64_t *out_count) {
     if (!out_count) return MSBWT_ERR_INVALID_ARG;
     return msbwt_rle_count_kmers(h, kmer, k, 1, out_count);
+}
+
+// ---- several devices of one node: replicas of one index, batches sharded over them --------------
+msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
+    msbwt_rle *src = const_cast<msbwt_rle *>(csrc);
+    if (!src) return nullptr;
+    std::lock_guard<std::mutex> lock(src->mu);
+    if (!src->loaded) {
+        fail(src, MSBWT_ERR_NOT_LOADED, "no BWT loaded");
+        return nullptr;
+    }
+    msbwt_rle *h = msbwt_rle_new_on_device(src->bin_power, device);
+    if (!h) return nullptr;
+    h->wanted_table_depth = src->wanted_table_depth;
+    h->wanted_pair = src->wanted_pair;
+    h->wanted_filter = src->wanted_filter;
+    h->search_kernel = src->search_kernel;
+    auto give_up = [&](hipError_t e, const char *what) -> msbwt_rle * {
+        hip_fail(src, e, what);
+        msbwt_rle_free(h);
+        return nullptr;
+    };
+    DeviceScope scope(h->device);
+    if (!scope.ok()) {
+        fail(src, MSBWT_ERR_HIP, scope.why());
+        msbwt_rle_free(h);
+        return nullptr;
+    }
+    if (ensure_runtime(h) != MSBWT_OK) return give_up(hipErrorUnknown, "replicate: runtime setup");
+    if (h->device != src->device) {  // direct GPU -> GPU copies (xGMI) when the pair allows it; staged by the runtime otherwise
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, h->device, src->device) == hipSuccess && can) {
+            const hipError_t pe = hipDeviceEnablePeerAccess(src->device, 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+        }
+    }
+    const PairIndexSizes psz = pair_index_sizes(src->nblocks);
+    struct Piece { void *const *from; void **to; size_t bytes; };
+    const Piece pieces[] = {
+        {&src->d_blocks, &h->d_blocks, size_t(src->nblocks) * kBlockBytes},
+        {&src->d_table, &h->d_table, src->d_table ? (size_t(16) << (2 * src->table_depth)) : 0},
+        {reinterpret_cast<void *const *>(&src->d_filter), reinterpret_cast<void **>(&h->d_filter), src->d_filter ? (size_t(1) << (2 * src->filter_depth)) / 8 : 0},
+        {&src->d_pair_blocks, &h->d_pair_blocks, src->d_pair_blocks ? psz.pair_block_bytes : 0},
+        {&src->d_pair_super, &h->d_pair_super, src->d_pair_super ? psz.super_bytes : 0},
+    };
+    for (const Piece &p : pieces) {
+        if (!p.bytes || !*p.from) continue;
+        hipError_t e = hipMalloc(p.to, p.bytes);
+        if (e == hipSuccess) e = hipMemcpyPeerAsync(*p.to, h->device, *p.from, src->device, p.bytes, h->stream);
+        if (e != hipSuccess) return give_up(e, "replicate: copy index to the other device");
+    }
+    const hipError_t e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return give_up(e, "replicate: copy index to the other device");
+    h->totals = src->totals;
+    h->nblocks = src->nblocks;
+    h->table_depth = src->table_depth;
+    h->filter_depth = src->filter_depth;
+    h->pair_bytes = src->pair_bytes;
+    h->loaded = true;
+    return h;
+}
+
+}  // extern "C"
+
+namespace {
+
+// contiguous shards starting at multiples of 16 items (16-byte aligned rows for any k; sharded.py has the same rule)
+void shard_of(size_t n, size_t world, size_t rank, size_t *lo, size_t *hi) {
+    const size_t units = (n + 15) / 16, base = units / world, extra = units % world;
+    const size_t lo_u = rank * base + std::min(rank, extra), hi_u = lo_u + base + (rank < extra ? 1 : 0);
+    *lo = std::min(n, lo_u * 16);
+    *hi = std::min(n, hi_u * 16);
+}
+
+// runs work(r) for every replica on its own host thread; returns the first non-zero code
+template <class Work>
+int on_every_replica(size_t n_replicas, Work &&work) {
+    std::vector<int> rc(n_replicas, MSBWT_OK);
+    std::vector<std::thread> threads;
+    for (size_t r = 1; r < n_replicas; ++r) threads.emplace_back([&, r] { rc[r] = work(r); });
+    rc[0] = work(0);
+    for (auto &t : threads) t.join();
+    for (int c : rc)
+        if (c) return c;
+    return MSBWT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msbwt_rle_count_kmers_multi(const msbwt_rle *const *replicas, size_t n_replicas, const uint8_t *kmers, size_t k, size_t n,
+                                uint64_t *out_counts) {
+    if (!replicas || n_replicas == 0) return MSBWT_ERR_INVALID_ARG;
+    for (size_t r = 0; r < n_replicas; ++r)
+        if (!replicas[r]) return MSBWT_ERR_INVALID_ARG;
+    if (n && (!out_counts || (!kmers && k))) return MSBWT_ERR_INVALID_ARG;
+    // one host thread and one pinned pipeline per replica; every shard's counts land directly in the
+    // caller's buffer -- the "gather" is the D2H copies themselves
+    return on_every_replica(n_replicas, [&](size_t r) {
+        size_t lo, hi;
+        shard_of(n, n_replicas, r, &lo, &hi);
+        return hi > lo ? msbwt_rle_count_kmers(replicas[r], kmers + lo * k, k, hi - lo, out_counts + lo) : MSBWT_OK;
+    });
+}
+
+int msbwt_rle_count_read_kmers_multi(const msbwt_rle *const *replicas, size_t n_replicas, const uint8_t *reads, size_t read_len,
+                                     size_t n_reads, size_t k, int ascii, uint64_t *out_fwd, uint64_t *out_rc) {
+    if (!replicas || n_replicas == 0 || k < 1 || k > read_len) return MSBWT_ERR_INVALID_ARG;
+    for (size_t r = 0; r < n_replicas; ++r)
+        if (!replicas[r]) return MSBWT_ERR_INVALID_ARG;
+    const size_t windows = read_len - k + 1;
+    return on_every_replica(n_replicas, [&](size_t r) {
+        size_t lo, hi;
+        shard_of(n_reads, n_replicas, r, &lo, &hi);
+        if (hi <= lo) return int(MSBWT_OK);
+        return msbwt_rle_count_read_kmers(replicas[r], reads + lo * read_len, read_len, hi - lo, k, ascii,
+                                          out_fwd ? out_fwd + lo * windows : nullptr, out_rc ? out_rc + lo * windows : nullptr);
+    });
+}
+
+int msbwt_rle_count_kmers_multi_device(const msbwt_rle *const *replicas, size_t n_replicas, const void *d_kmers, size_t k, size_t n,
+                                       void *d_out_counts) {
+    if (!replicas || n_replicas == 0) return MSBWT_ERR_INVALID_ARG;
+    for (size_t r = 0; r < n_replicas; ++r)
+        if (!replicas[r]) return MSBWT_ERR_INVALID_ARG;
+    if (n && (!d_out_counts || (!d_kmers && k))) return MSBWT_ERR_INVALID_ARG;
+    const int home = replicas[0]->device;
+    const uint8_t *src = static_cast<const uint8_t *>(d_kmers);
+    uint64_t *dst = static_cast<uint64_t *>(d_out_counts);
+    // enqueue every shard on its replica's stream: shard in by peer copy, kernel, counts back by peer copy
+    for (size_t r = 0; r < n_replicas; ++r) {
+        msbwt_rle *h = const_cast<msbwt_rle *>(replicas[r]);
+        size_t lo, hi;
+        shard_of(n, n_replicas, r, &lo, &hi);
+        if (hi <= lo) continue;
+        std::lock_guard<std::mutex> lock(h->mu);
+        if (!h->loaded) return fail(h, MSBWT_ERR_NOT_LOADED, "no BWT loaded");
+        DeviceScope scope(h->device);
+        if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+        const size_t m = hi - lo;
+        if (h->device == home) {
+            const int rc = launch_count(h, src + lo * k, k, m, dst + lo, h->stream, kHostFlags);
+            if (rc) return rc;
+        } else {
+            const size_t kmer_bytes = (m * k + 255) / 256 * 256;
+            int rc = ensure_stage(h, kmer_bytes + m * sizeof(uint64_t));
+            if (rc) return rc;
+            uint8_t *d_k = static_cast<uint8_t *>(h->d_stage);
+            uint64_t *d_c = reinterpret_cast<uint64_t *>(d_k + kmer_bytes);
+            if (k) HIP_TRY(h, hipMemcpyPeerAsync(d_k, h->device, src + lo * k, home, m * k, h->stream));
+            rc = launch_count(h, d_k, k, m, d_c, h->stream, kHostFlags);
+            if (rc) return rc;
+            HIP_TRY(h, hipMemcpyPeerAsync(dst + lo, home, d_c, h->device, m * sizeof(uint64_t), h->stream));
+        }
+    }
+    // the counts are complete when every replica's stream has drained
+    int first = MSBWT_OK;
+    for (size_t r = 0; r < n_replicas; ++r) {
+        msbwt_rle *h = const_cast<msbwt_rle *>(replicas[r]);
+        std::lock_guard<std::mutex> lock(h->mu);
+        if (!h->stream) continue;
+        DeviceScope scope(h->device);
+        uint32_t flags = 0;
+        int rc = scope.ok() ? read_flags(h, h->stream, kHostFlags, &flags) : fail(h, MSBWT_ERR_HIP, scope.why());
+        if (!rc) rc = flags_to_code(h, flags);
+        if (rc && !first) first = rc;
+    }
+    return first;
 }
 
 int msbwt_rle_set_table_depth(msbwt_rle *h, int depth) {

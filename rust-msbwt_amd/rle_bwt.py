@@ -194,6 +194,17 @@ class RleBWT(BWT):
         if rc:
             _raise(rc, self._h)
 
+    # ---- several GPUs of one node ---------------------------------------------------------
+    def replicate(self, device):
+        """A new RleBWT on `device` holding a GPU -> GPU copy of this index (no rebuild, no upload)."""
+        h = _lib.lib().msbwt_rle_replicate(self._h, device)
+        if not h:
+            _raise(_lib.ERR_HIP, self._h)
+        other = object.__new__(RleBWT)
+        other._h = h
+        other.bin_power = self.bin_power
+        return other
+
     # ---- tuning / introspection --------------------------------------------------------
     def set_table_depth(self, depth):
         rc = _lib.lib().msbwt_rle_set_table_depth(self._h, depth)
@@ -249,3 +260,45 @@ class RleBWT(BWT):
 
     def device_ordinal(self):
         return int(_lib.lib().msbwt_rle_device_ordinal(self._h))
+
+
+def _handles(replicas):
+    arr = (C.c_void_p * len(replicas))(*[r._h for r in replicas])
+    return arr
+
+
+def count_kmers_multi(replicas, kmers, out=None):
+    """msbwt_rle_count_kmers_multi: a host batch sharded over the replicas (one per GPU)."""
+    a = np.ascontiguousarray(kmers, dtype=np.uint8)
+    if a.ndim != 2:
+        raise ValueError("kmers must be (n, k)")
+    n, k = a.shape
+    if out is None:
+        out = np.empty(n, dtype=np.uint64)
+    rc = _lib.lib().msbwt_rle_count_kmers_multi(_handles(replicas), len(replicas), a.ctypes.data_as(C.c_void_p), k, n,
+                                                out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise MsbwtError(rc, "; ".join(_lib.lib().msbwt_rle_last_error(r._h).decode(errors="replace") for r in replicas))
+    return out
+
+
+def count_read_kmers_multi(replicas, reads, k, ascii=False, forward=True, revcomp=False):
+    """msbwt_rle_count_read_kmers_multi: reads sharded over the replicas, every k-mer window counted."""
+    a = np.ascontiguousarray(reads, dtype=np.uint8)
+    n, length = a.shape
+    w = length - k + 1
+    fwd = np.empty((n, w), dtype=np.uint64) if forward else None
+    rc_arr = np.empty((n, w), dtype=np.uint64) if revcomp else None
+    rc = _lib.lib().msbwt_rle_count_read_kmers_multi(
+        _handles(replicas), len(replicas), a.ctypes.data_as(C.c_void_p), length, n, k, 1 if ascii else 0,
+        fwd.ctypes.data_as(C.c_void_p) if fwd is not None else None, rc_arr.ctypes.data_as(C.c_void_p) if rc_arr is not None else None)
+    if rc:
+        raise MsbwtError(rc, "; ".join(_lib.lib().msbwt_rle_last_error(r._h).decode(errors="replace") for r in replicas))
+    return fwd, rc_arr
+
+
+def count_kmers_multi_device(replicas, d_kmers, k, n, d_out):
+    """msbwt_rle_count_kmers_multi_device: device pointers on replicas[0]'s device; synchronous."""
+    rc = _lib.lib().msbwt_rle_count_kmers_multi_device(_handles(replicas), len(replicas), d_kmers, k, n, d_out)
+    if rc:
+        raise MsbwtError(rc, "; ".join(_lib.lib().msbwt_rle_last_error(r._h).decode(errors="replace") for r in replicas))

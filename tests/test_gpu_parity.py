@@ -242,6 +242,35 @@ def test_reload_replaces_index():
     b.load_vector(msbwt.bwt_converter.convert_to_vec("TG$$CAGCCG"))
     assert b.get_total_size() == 10
     assert b.count_kmer(stoi("CG")) == 2
+    # a failed load leaves the handle unloaded and reporting nothing of the previous BWT
+    with pytest.raises(msbwt.MsbwtError) as err:
+        b.load_vector(np.array([9, 10, 15], dtype=np.uint8))  # 15 & 7 = 7: not a symbol code
+    assert err.value.code == msbwt._lib.ERR_INVALID_SYMBOL
+    assert b.get_total_size() == 0 and b.get_symbol_count(1) == 0
+    with pytest.raises(msbwt.MsbwtError) as err:
+        b.count_kmer(stoi("CG"))
+    assert err.value.code == msbwt._lib.ERR_NOT_LOADED
+
+
+def test_device_and_host_entry_points_keep_separate_status_words():
+    """An invalid symbol in a *_device batch must be reported by device_status, not swallowed (or
+    blamed on them) by host-pointer calls in between."""
+    import torch
+    reads, rle = _real_bwt(5, 100, 60)
+    b = gpu_bwt(rle)
+    dev = torch.device("cuda", 0)
+    bad = torch.full((130, 21), 7, dtype=torch.uint8, device=dev)
+    out = torch.zeros(130, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    b.count_kmers_device(bad.data_ptr(), 21, 130, out.data_ptr(), stream)
+    torch.cuda.synchronize(dev)
+    good = np.array([orc.convert_stoi(reads[0][:21])], dtype=np.uint8)
+    assert b.count_kmers(good)[0] >= 1           # a host call: fine, and does not clear the device word
+    with pytest.raises(msbwt.MsbwtError) as err:
+        b.device_status(stream)
+    assert err.value.code == msbwt._lib.ERR_INVALID_SYMBOL
+    b.device_status(stream)                      # cleared by the call that reported it
+    assert int(out[0].item()) == -1              # u64::MAX
 
 
 @pytest.mark.parametrize("depth", [0, 1, 2, 5, 9])
@@ -568,3 +597,42 @@ def test_presence_filter_never_changes_results(filt):
     dense = gpu_bwt(random_stream(5, 200000, "short", alphabet=(1, 2, 3, 5)))
     dense.set_table_depth(6)
     assert dense.get_presence_filter() == 0
+
+
+def test_replicas_and_sharded_batches_match_a_single_handle():
+    """The C ABI's multi-device entry points, rehearsed on this box's one GPU (devices = {0, 0, 0}):
+    replicas are GPU -> GPU copies of the loaded index, a batch is sharded over them, and the counts
+    must equal a single handle's (and the oracle's) bit for bit -- host and device forms."""
+    import torch
+    from rust_msbwt_amd import rle_bwt
+    reads, rle = _real_bwt(77, 300, 80)
+    reads = [r for r in reads if "N" not in r]
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    replicas = [b, b.replicate(0), b.replicate(0)]
+    assert all(r.get_total_size() == b.get_total_size() and r.get_table_depth() == b.get_table_depth()
+               and r.get_pair_index() == b.get_pair_index() for r in replicas)
+    rng = np.random.default_rng(5)
+    for k in (4, 21, 31, 40):
+        present = np.array([orc.convert_stoi(r[i:i + k]) for r in reads for i in (0, 11, 23) if i + k <= len(r)], dtype=np.uint8)
+        absent = np.array([1, 2, 3, 5], dtype=np.uint8)[rng.integers(0, 4, size=(1003, k))]
+        q = np.concatenate([present, absent])
+        exp = o.count_kmers(q)
+        assert np.array_equal(rle_bwt.count_kmers_multi(replicas, q), exp)
+        assert np.array_equal(rle_bwt.count_kmers_multi(replicas[:2], q[:5]), exp[:5])  # fewer queries than one shard unit
+        dev = torch.device("cuda", 0)
+        d_q = torch.from_numpy(q).to(dev)
+        d_out = torch.zeros(len(q), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(dev)
+        rle_bwt.count_kmers_multi_device(replicas, d_q.data_ptr(), k, len(q), d_out.data_ptr())
+        assert np.array_equal(d_out.cpu().numpy().astype(np.uint64), exp)
+    codes = np.array([orc.convert_stoi(r) for r in reads], dtype=np.uint8)
+    f1, r1 = b.count_read_kmers(codes, 25, ascii=False, revcomp=True)
+    f3, r3 = rle_bwt.count_read_kmers_multi(replicas, codes, 25, ascii=False, revcomp=True)
+    assert np.array_equal(f1, f3) and np.array_equal(r1, r3)
+    # an invalid symbol in one shard is reported by the whole call
+    bad = np.concatenate([q[:100], np.full((1, q.shape[1]), 7, dtype=np.uint8), q[100:]])
+    with pytest.raises(msbwt.MsbwtError) as err:
+        rle_bwt.count_kmers_multi(replicas, bad)
+    assert err.value.code == msbwt._lib.ERR_INVALID_SYMBOL
