@@ -427,6 +427,21 @@ def main():
     if weak is not None:
         result["weak_scaling"] = weak
 
+    # the rows the oracle will check travel to the host now; then the batch leaves HBM (the extra line
+    # below needs 39 GB next to a 200 GB index)
+    queries = got = None
+    if rank == 0 and not args.no_oracle:
+        rng = np.random.default_rng(5)
+        want = min(nq, max(args.parity_sample, args.stats_sample or nq, 0 if args.no_cpu_baseline else args.cpu_sample))
+        sample_ids = np.sort(rng.choice(nq, size=want, replace=False)) if want < nq else np.arange(nq)
+        if fused:
+            queries = np.ascontiguousarray(reads[(sample_ids // wins)[:, None], (sample_ids % wins)[:, None] + np.arange(k)[None, :]])
+        else:
+            queries = d_q[torch.from_numpy(sample_ids).to(dev)].cpu().numpy()
+        got = d_counts[torch.from_numpy(sample_ids).to(dev)].cpu().numpy().astype(np.uint64)
+    del d_counts, d_out, d_all, d_q
+    torch.cuda.empty_cache()
+
     # ---- BASELINE configs[4] in its literal shape on this GPU: 1e9 random 31-mers generated in HBM ----
     c5 = None
     if human and world == 1 and not args.no_c5 and args.scale == 1.0:
@@ -467,14 +482,6 @@ def main():
         else:
             ref.load_numpy_file(npy)
         log("oracle loaded in %.1fs" % (time.time() - t0))
-        rng = np.random.default_rng(5)
-        want = min(nq, max(args.parity_sample, args.stats_sample or nq, 0 if args.no_cpu_baseline else args.cpu_sample))
-        sample_ids = np.sort(rng.choice(nq, size=want, replace=False)) if want < nq else np.arange(nq)
-        if fused:
-            queries = np.ascontiguousarray(reads[(sample_ids // wins)[:, None], (sample_ids % wins)[:, None] + np.arange(k)[None, :]])
-        else:
-            queries = d_q[torch.from_numpy(sample_ids).to(dev)].cpu().numpy()
-        got = d_counts[torch.from_numpy(sample_ids).to(dev)].cpu().numpy().astype(np.uint64)
         ns = min(len(queries), args.parity_sample)
         sel = np.linspace(0, len(queries) - 1, ns).astype(np.int64)
         ncpu = min(os.cpu_count() or 1, 16)

@@ -151,6 +151,17 @@ int msbwt_rle_count_kmers_multi_device(const msbwt_rle *const *replicas, size_t 
  * immediately if an index is loaded.  Results never change. */
 int msbwt_rle_set_table_depth(msbwt_rle *bwt, int depth);
 int msbwt_rle_get_table_depth(const msbwt_rle *bwt);
+/* Packed suffix table: beside a pair index the finished table can be extended by TWO more levels
+ * and stored as 128-byte lines of 30 entries (16-bit deltas; 4.27 bytes per entry instead of 16),
+ * e.g. depth 17 in 73 GB for a 30x human BWT.  One line fetch per query as before, one search step
+ * fewer -- and it is the widest-range step, the one that usually needs two lines.  mode 1 = on
+ * (whenever a pair index exists), 0 = off, -1 = automatic (default: when the table depth itself is
+ * automatic, 4^(depth+2) <= total symbols and the lines fit in half of the free HBM;
+ * MSBWT_TABLE_PACKED=0/1 overrides).
+ * msbwt_rle_get_table_depth reports the effective depth (flat depth + 2).  Lines whose deltas do not
+ * fit 16 bits are marked and their queries search from scratch.  Results never change. */
+int msbwt_rle_set_table_packed(msbwt_rle *bwt, int mode);
+int msbwt_rle_get_table_packed(const msbwt_rle *bwt);
 /* Presence filter: one bit per ACGT suffix of length min(12, table depth), set when some table
  * entry with that suffix is a non-empty range; at most 2 MiB, so it lives in L2 and decides
  * absent k-mers (random queries, small genomes) without fetching the table line.  Built on the

@@ -39,6 +39,8 @@ SIGNATURES = {
     "msbwt_rle_count_kmers_multi_device": (_int, [_vp, _sz, _vp, _sz, _sz, _vp]),
     "msbwt_rle_set_table_depth": (_int, [_vp, _int]),
     "msbwt_rle_get_table_depth": (_int, [_vp]),
+    "msbwt_rle_set_table_packed": (_int, [_vp, _int]),
+    "msbwt_rle_get_table_packed": (_int, [_vp]),
     "msbwt_rle_set_presence_filter": (_int, [_vp, _int]),
     "msbwt_rle_get_presence_filter": (_int, [_vp]),
     "msbwt_rle_set_search_kernel": (_int, [_vp, _int]),

@@ -34,7 +34,10 @@ struct msbwt_rle {
     uint64_t pair_bytes = 0;
     int wanted_pair = -1;           // -1 = on when it fits comfortably, 0 = off, 1 = on
     void *d_table = nullptr;
-    int table_depth = 0;         // depth of the table currently in HBM
+    int table_depth = 0;         // symbols a table entry stands for (of the table currently in HBM)
+    bool table_packed = false;   // packed lines (two levels deeper than the flat table it was made from)
+    size_t table_bytes = 0;
+    int wanted_table_packed = -1; // -1 = pack when the data warrants it and it fits, 0 = never, 1 = whenever a pair index exists
     uint32_t *d_filter = nullptr;   // presence bits over the low 2*filter_depth index bits of the table
     int filter_depth = 0;
     int wanted_filter = -1;         // -1 = keep it when it can reject something, 0 = off
@@ -115,6 +118,8 @@ void release_index(msbwt_rle *h) {
     h->pair_bytes = 0;
     h->nblocks = 0;
     h->table_depth = 0;
+    h->table_packed = false;
+    h->table_bytes = 0;
     h->totals = Totals{};  // an unloaded handle reports 0 symbols, not the previous BWT's
     h->loaded = false;
 }
@@ -126,6 +131,7 @@ IndexView view_of(const msbwt_rle *h) {
     v.total = h->totals.total;
     v.table.entries = h->d_table;
     v.table.depth = h->d_table ? h->table_depth : 0;
+    v.table.packed = h->d_table && h->table_packed;
     v.table.filter = h->d_table ? h->d_filter : nullptr;
     v.table.filter_depth = h->filter_depth;
     v.pair_blocks = h->d_pair_blocks;
@@ -206,6 +212,8 @@ int rebuild_table(msbwt_rle *h) {
     if (h->d_table) (void)hipFree(h->d_table);
     h->d_table = nullptr;
     h->table_depth = 0;
+    h->table_packed = false;
+    h->table_bytes = 0;
     int depth = h->wanted_table_depth < 0 ? auto_table_depth(h->totals.total, h->nblocks * kBlockBytes) : h->wanted_table_depth;
     if (depth <= 0) return MSBWT_OK;
     const size_t bytes = (size_t(1) << (2 * depth)) * 16;
@@ -221,7 +229,38 @@ int rebuild_table(msbwt_rle *h) {
     }
     h->d_table = tab;
     h->table_depth = depth;
-    return rebuild_filter(h);
+    h->table_bytes = bytes;
+    int rc = rebuild_filter(h);  // from the flat table, before it may be packed away
+    if (rc) return rc;
+    // Packed form, two levels deeper (kernels.hpp, launch_pack_table): every level removes a line fetch
+    // per query, and the first step after a shallow table is the expensive one (wide ranges straddle
+    // blocks).  Needs the pair index; automatic when the data warrants the depth (4^(depth+2) <= T) and
+    // the packed lines take at most half of the HBM that is free once the flat table is gone.
+    if (!h->d_pair_blocks || h->wanted_table_packed == 0 || depth + 2 > 18) return MSBWT_OK;
+    const uint64_t pbytes = packed_table_bytes(depth + 2);
+    if (h->wanted_table_packed < 0) {
+        size_t free_b = 0, total_b = 0;
+        if (h->wanted_table_depth >= 0 ||  // an explicit depth is taken literally
+            (uint64_t(1) << (2 * (depth + 2))) > h->totals.total || hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
+            2 * pbytes > uint64_t(free_b) + bytes)
+            return MSBWT_OK;
+    }
+    void *packed = nullptr;
+    e = hipMalloc(&packed, pbytes);
+    if (e == hipSuccess) e = launch_pack_table(view_of(h), depth, h->d_table, packed, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+        if (packed) (void)hipFree(packed);
+        (void)hipGetLastError();
+        if (h->wanted_table_packed < 0) return MSBWT_OK;  // optional structure: keep the flat table
+        return hip_fail(h, e, "pack suffix table");
+    }
+    (void)hipFree(h->d_table);
+    h->d_table = packed;
+    h->table_depth = depth + 2;
+    h->table_packed = true;
+    h->table_bytes = pbytes;
+    return MSBWT_OK;
 }
 
 // Pair index (two symbols per step, rank_ops.hpp): 1 byte/symbol on top of the plane blocks,
@@ -345,8 +384,8 @@ int install(msbwt_rle *h, const uint8_t *rle, size_t n) {
     h->totals = t;
     h->nblocks = plane_block_count(t.total);
     h->loaded = true;
-    rc = rebuild_table(h);
-    if (!rc) rc = rebuild_pair_index(h);
+    rc = rebuild_pair_index(h);  // first: the table may be packed with its help
+    if (!rc) rc = rebuild_table(h);
     if (rc) {
         release_index(h);
         return rc;
@@ -423,6 +462,7 @@ msbwt_rle *msbwt_rle_new_on_device(uint8_t bin_power, int device) {
     if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;
     h->device = device;
     if (const char *env = std::getenv("MSBWT_TABLE_DEPTH")) h->wanted_table_depth = std::atoi(env);
+    if (const char *env = std::getenv("MSBWT_TABLE_PACKED")) h->wanted_table_packed = std::atoi(env) ? 1 : 0;
     if (const char *env = std::getenv("MSBWT_PAIR_INDEX")) h->wanted_pair = std::atoi(env) ? 1 : 0;
     if (const char *env = std::getenv("MSBWT_FILTER")) h->wanted_filter = std::atoi(env) ? -1 : 0;
     if (const char *env = std::getenv("MSBWT_SEARCH"))
@@ -712,6 +752,7 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
     msbwt_rle *h = msbwt_rle_new_on_device(src->bin_power, device);
     if (!h) return nullptr;
     h->wanted_table_depth = src->wanted_table_depth;
+    h->wanted_table_packed = src->wanted_table_packed;
     h->wanted_pair = src->wanted_pair;
     h->wanted_filter = src->wanted_filter;
     h->search_kernel = src->search_kernel;
@@ -738,7 +779,7 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
     struct Piece { void *const *from; void **to; size_t bytes; };
     const Piece pieces[] = {
         {&src->d_blocks, &h->d_blocks, size_t(src->nblocks) * kBlockBytes},
-        {&src->d_table, &h->d_table, src->d_table ? (size_t(16) << (2 * src->table_depth)) : 0},
+        {&src->d_table, &h->d_table, src->d_table ? src->table_bytes : 0},
         {reinterpret_cast<void *const *>(&src->d_filter), reinterpret_cast<void **>(&h->d_filter), src->d_filter ? (size_t(1) << (2 * src->filter_depth)) / 8 : 0},
         {&src->d_pair_blocks, &h->d_pair_blocks, src->d_pair_blocks ? psz.pair_block_bytes : 0},
         {&src->d_pair_super, &h->d_pair_super, src->d_pair_super ? psz.super_bytes : 0},
@@ -754,6 +795,8 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
     h->totals = src->totals;
     h->nblocks = src->nblocks;
     h->table_depth = src->table_depth;
+    h->table_packed = src->table_packed;
+    h->table_bytes = src->table_bytes;
     h->filter_depth = src->filter_depth;
     h->pair_bytes = src->pair_bytes;
     h->loaded = true;
@@ -888,7 +931,8 @@ int msbwt_rle_set_pair_index(msbwt_rle *h, int mode) {
     if (!h->loaded) return MSBWT_OK;
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
-    return rebuild_pair_index(h);
+    const int rc = rebuild_pair_index(h);
+    return rc ? rc : rebuild_table(h);  // the table's packed form exists only beside a pair index
 }
 
 int msbwt_rle_get_pair_index(const msbwt_rle *h) { return (h && h->d_pair_blocks) ? 1 : 0; }
@@ -900,8 +944,20 @@ int msbwt_rle_set_presence_filter(msbwt_rle *h, int mode) {
     if (!h->loaded) return MSBWT_OK;
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
-    return rebuild_filter(h);
+    return rebuild_table(h);  // the filter is made from the flat table, which a packed table no longer holds
 }
+
+int msbwt_rle_set_table_packed(msbwt_rle *h, int mode) {
+    if (!h || mode < -1 || mode > 1) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->wanted_table_packed = mode;
+    if (!h->loaded) return MSBWT_OK;
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    return rebuild_table(h);
+}
+
+int msbwt_rle_get_table_packed(const msbwt_rle *h) { return (h && h->d_table && h->table_packed) ? 1 : 0; }
 
 int msbwt_rle_get_presence_filter(const msbwt_rle *h) { return (h && h->d_filter) ? h->filter_depth : 0; }
 
@@ -916,7 +972,7 @@ int msbwt_rle_get_search_kernel(const msbwt_rle *h) { return h ? h->search_kerne
 
 uint64_t msbwt_rle_device_bytes(const msbwt_rle *h) {
     if (!h || !h->loaded) return 0;
-    return h->nblocks * kBlockBytes + (h->d_table ? (uint64_t(16) << (2 * h->table_depth)) : 0) + h->pair_bytes +
+    return h->nblocks * kBlockBytes + (h->d_table ? uint64_t(h->table_bytes) : 0) + h->pair_bytes +
            (h->d_filter ? (uint64_t(1) << (2 * h->filter_depth)) / 8 : 0);
 }
 

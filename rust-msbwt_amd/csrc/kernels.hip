@@ -70,7 +70,8 @@ struct WaveScratchT {
 template <bool kReads, int kWords>
 __global__ __launch_bounds__(256, kWords == 6 ? 5 : 8) void k_count_kmers_tiled(
     const uint4 *__restrict__ blocks, uint64_t total, const uint4 *__restrict__ table, uint32_t depth,
-    const uint32_t *__restrict__ filter, uint32_t filter_mask, const QuerySource src, uint32_t *__restrict__ flags) {
+    uint32_t table_packed, const uint32_t *__restrict__ filter, uint32_t filter_mask, const QuerySource src,
+    uint32_t *__restrict__ flags) {
     constexpr int kLanes = kGroup;
     using Scratch = WaveScratchT<kWords>;
     using WorkItem = WorkItemT<kWords>;
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256, kWords == 6 ? 5 : 8) void k_count_kmers_tiled(
     const uint64_t nwaves = uint64_t(gridDim.x) * kWavesPerBlock;
     const bool use_table = table != nullptr && depth > 0 && k >= depth;
 
-    const TableEnv env{table, depth, use_table, filter, filter_mask, total};
+    const TableEnv env{table, depth, use_table, table_packed != 0u, filter, filter_mask, total};
     // A tile is at most 64 x kMaxK bytes = kPieces pieces per lane, all loads in flight at once.
     // For k <= 32 the loads of the NEXT tile are issued before the current tile is searched, hiding
     // their latency; the k <= 64 variant has no registers to spare for that and loads at the top
@@ -259,6 +260,70 @@ __global__ __launch_bounds__(256) void k_table_filter(const uint4 *__restrict__ 
     }
 }
 
+// ---- packed table: two more levels in the HBM of one -------------------------------------------
+// occ2(a, b, pos) + K[a][b] by ONE thread straight from global memory (pair block layout: rank_ops.hpp)
+__device__ __forceinline__ uint64_t pair_bound_thread(const uint4 *__restrict__ pair_blocks, const uint64_t *__restrict__ pair_super,
+                                                      uint32_t a2, uint32_t b2, uint64_t pos) {
+    const uint4 *blk = pair_blocks + (pos >> kPairShift) * 8;
+    const uint4 a0 = blk[0], a1 = blk[1], b0 = blk[2], b1 = blk[3], v = blk[kPairValidChunk];
+    const uint32_t na0 = (a2 & 1u) - 1u, na1 = ((a2 >> 1) & 1u) - 1u, nb0 = (b2 & 1u) - 1u, nb1 = ((b2 >> 1) & 1u) - 1u;
+    const uint32_t m0 = (a0.x ^ na0) & (a1.x ^ na1) & (b0.x ^ nb0) & (b1.x ^ nb1) & v.x;
+    const uint32_t m1 = (a0.y ^ na0) & (a1.y ^ na1) & (b0.y ^ nb0) & (b1.y ^ nb1) & v.y;
+    const uint32_t m2 = (a0.z ^ na0) & (a1.z ^ na1) & (b0.z ^ nb0) & (b1.z ^ nb1) & v.z;
+    const uint32_t m3 = (a0.w ^ na0) & (a1.w ^ na1) & (b0.w ^ nb0) & (b1.w ^ nb1) & v.w;
+    const uint32_t r = uint32_t(pos) & 127u, p = a2 * 4u + b2;
+    const uint64_t t = (1ull << (r & 63u)) - 1ull;
+    const bool upper = r >= 64u;
+    const uint64_t lo = upper ? ~0ull : t, hi = upper ? t : 0ull;
+    const uint32_t cnt = uint32_t(__popc(m0 & uint32_t(lo))) + uint32_t(__popc(m1 & uint32_t(lo >> 32))) +
+                         uint32_t(__popc(m2 & uint32_t(hi))) + uint32_t(__popc(m3 & uint32_t(hi >> 32)));
+    const uint32_t field = uint32_t(reinterpret_cast<const uint16_t *>(blk + kPairLoChunk)[p]) |
+                           (uint32_t(reinterpret_cast<const uint8_t *>(blk + kPairHiChunk)[p]) << 16);
+    return pair_super[(pos >> kPairSuperShift) * 16u + p] + field + cnt;
+}
+
+// One half-wave (32 lanes) writes one packed line: lane i < 30 extends flat entry
+// (t mod 4^flat_depth) by the two symbols in t's top four bits, t = 30 line + i.
+__global__ __launch_bounds__(256) void k_table_pack(const uint4 *__restrict__ flat, uint32_t flat_depth,
+                                                    const uint4 *__restrict__ pair_blocks, const uint64_t *__restrict__ pair_super,
+                                                    uint32_t *__restrict__ packed, uint64_t nlines) {
+    const uint32_t lane = threadIdx.x & 63u, i = lane & 31u, team_first = lane & 32u;
+    const uint64_t entries = 1ull << (2u * (flat_depth + 2u)), parent_mask = (1ull << (2u * flat_depth)) - 1ull;
+    const uint64_t nteams = (uint64_t(gridDim.x) * blockDim.x) / 32;
+    for (uint64_t line = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) / 32; line < nlines; line += nteams) {
+        const uint64_t t = line * kPackedPerLine + i;
+        const bool valid = i < kPackedPerLine && t < entries;
+        uint64_t l = 0, h = 0;
+        if (valid) {
+            const uint4 e = flat[t & parent_mask];
+            l = (uint64_t(e.y) << 32) | e.x;
+            h = (uint64_t(e.w) << 32) | e.z;
+            if (l != h) {
+                const uint32_t a2 = uint32_t(t >> (2u * flat_depth)) & 3u, b2 = uint32_t(t >> (2u * flat_depth + 2u)) & 3u;
+                l = pair_bound_thread(pair_blocks, pair_super, a2, b2, l);
+                h = pair_bound_thread(pair_blocks, pair_super, a2, b2, h);
+            }
+        }
+        const bool nonempty = valid && l != h;
+        // base = the first non-empty range's l (ranges of consecutive indices are consecutive, so l is monotone)
+        const uint64_t ne = __ballot(nonempty);
+        const uint32_t mine32 = uint32_t(ne >> team_first);
+        const int first = mine32 ? __ffs(int(mine32)) - 1 : 0;
+        const uint64_t base = (uint64_t(uint32_t(__shfl(int(uint32_t(l >> 32)), int(team_first) + first))) << 32) |
+                              uint32_t(__shfl(int(uint32_t(l)), int(team_first) + first));
+        const uint64_t dl = nonempty ? l - base : 0ull, w = nonempty ? h - l : 0ull;
+        const bool wide = dl > 0xFFFFull || w > 0xFFFFull;
+        const bool escape = (uint32_t(__ballot(wide) >> team_first)) != 0u;
+        uint32_t *out = packed + line * 32;
+        if (i < kPackedPerLine) out[2u + i] = uint32_t(dl & 0xFFFFu) | (uint32_t(w & 0xFFFFu) << 16);
+        if (i == 30u) {
+            const uint64_t b = (mine32 ? base : 0ull) | (escape ? kPackedEscape : 0ull);
+            out[0] = uint32_t(b);
+            out[1] = uint32_t(b >> 32);
+        }
+    }
+}
+
 __global__ void k_table_root(uint4 *table, uint64_t total) {
     if (threadIdx.x == 0 && blockIdx.x == 0) table[0] = make_uint4(0u, 0u, uint32_t(total), uint32_t(total >> 32));
 }
@@ -312,10 +377,11 @@ void launch_tiled(bool longk, dim3 grid, hipStream_t stream, const IndexView &ix
     const uint32_t depth = uint32_t(ix.table.depth);
     const uint32_t *filter = table ? ix.table.filter : nullptr;
     const uint32_t filter_mask = filter ? uint32_t((1ull << (2 * ix.table.filter_depth)) - 1ull) : 0u;
+    const uint32_t packed = ix.table.packed ? 1u : 0u;
     if (longk)  // 33 <= k <= 64
-        hipLaunchKernelGGL((k_count_kmers_tiled<kReads, 6>), grid, dim3(256), 0, stream, blocks, ix.total, table, depth, filter, filter_mask, src, flags);
+        hipLaunchKernelGGL((k_count_kmers_tiled<kReads, 6>), grid, dim3(256), 0, stream, blocks, ix.total, table, depth, packed, filter, filter_mask, src, flags);
     else
-        hipLaunchKernelGGL((k_count_kmers_tiled<kReads, 3>), grid, dim3(256), 0, stream, blocks, ix.total, table, depth, filter, filter_mask, src, flags);
+        hipLaunchKernelGGL((k_count_kmers_tiled<kReads, 3>), grid, dim3(256), 0, stream, blocks, ix.total, table, depth, packed, filter, filter_mask, src, flags);
 }
 
 }  // namespace
@@ -403,6 +469,16 @@ hipError_t launch_build_table(const IndexView &ix, int depth, void *entries, hip
         hipLaunchKernelGGL(k_table_level, dim3(grid_for(parents * kGroup)), dim3(256), 0, stream,
                            static_cast<const uint4 *>(ix.blocks), table, uint32_t(level));
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_table(const IndexView &ix, int flat_depth, const void *flat_entries, void *packed_entries,
+                             hipStream_t stream) {
+    if (flat_depth < 1 || flat_depth > 16 || !ix.pair_blocks || !ix.pair_super) return hipErrorInvalidValue;
+    const uint64_t nlines = packed_table_bytes(flat_depth + 2) / 128;
+    hipLaunchKernelGGL(k_table_pack, dim3(grid_for(nlines * 32)), dim3(256), 0, stream, static_cast<const uint4 *>(flat_entries),
+                       uint32_t(flat_depth), static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super,
+                       static_cast<uint32_t *>(packed_entries), nlines);
     return hipGetLastError();
 }
 

@@ -13,8 +13,10 @@ constexpr uint32_t kFlagInternal = 4u;  // a device-side consistency check faile
 
 // One entry of the suffix table: the range after the last `depth` symbols of a k-mer.
 struct TableView {
-    const void *entries;  // uint4-aligned {l, h} pairs, 4^depth of them, or nullptr
+    const void *entries;  // 4^depth entries, or nullptr: flat = {l, h} u64 pairs (16 B each);
+                          // packed = 128-byte lines of 30 entries (search_common.hpp, kPackedPerLine)
     int depth;            // 0 = no table
+    bool packed = false;
     // presence filter: bit i = "some table entry whose low 2*filter_depth index bits equal i is
     // non-empty"; small enough (<= 2 MiB) to live in L2, it decides absent k-mers without the
     // random table line.  nullptr = none.
@@ -63,6 +65,12 @@ hipError_t launch_constrain_ranges(const IndexView &ix, const uint8_t *syms, con
 // Fills the suffix table of `depth` symbols (entries: 4^depth x {l,h}) by backward search
 // on the device.
 hipError_t launch_build_table(const IndexView &ix, int depth, void *entries, hipStream_t stream);
+// Packs a finished FLAT table of `flat_depth` levels into a PACKED table two levels deeper
+// (`packed_entries`: ceil(4^(flat_depth+2) / 30) lines of 128 bytes): every entry is extended by
+// one two-symbol step of the pair index (required).  Returns the packed size through the helper.
+hipError_t launch_pack_table(const IndexView &ix, int flat_depth, const void *flat_entries, void *packed_entries,
+                             hipStream_t stream);
+inline uint64_t packed_table_bytes(int depth) { return ((uint64_t(1) << (2 * depth)) + 29) / 30 * 128; }
 // filter (zero-filled, 4^filter_depth bits) from a finished table of `depth` levels
 hipError_t launch_build_filter(const void *entries, int depth, int filter_depth, uint32_t *filter, hipStream_t stream);
 

@@ -137,7 +137,7 @@ __device__ __forceinline__ uint64_t pair_line_bound(const PairLine &L, uint64_t 
 
 template <bool kReads, bool kPair, int kWords>
 __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restrict__ blocks, uint64_t total,
-                                                          const uint4 *__restrict__ table, uint32_t depth,
+                                                          const uint4 *__restrict__ table, uint32_t depth, uint32_t table_packed,
                                                           const uint32_t *__restrict__ filter, uint32_t filter_mask,
                                                           const uint4 *__restrict__ pair_blocks,
                                                           const uint64_t *__restrict__ pair_super, const QuerySource src,
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
     const uint64_t ntiles = (n + kTile - 1) / kTile;
     const uint64_t wave_id = blockIdx.x, nwaves = gridDim.x;
     const bool use_table = table != nullptr && depth > 0 && k >= depth;
+    const TableEnv env{table, depth, use_table, table_packed != 0u, filter, filter_mask, total};
     // this lane's part in the line fetches: 16 bytes (one chunk) of the line in list slot 8 i + dma_group
     const uint32_t dma_group = lane >> 3, dma_chunk_bytes = ((lane & 7u) ^ dma_group) * 16u;
 
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
     //   staged_next[]: bytes of tile `next_tile` (loads issued, not waited for)
     //   prepared:      a tile has been packed and its table loads issued; per lane: prep_kind
     //                  (0 nothing to do, 1 range comes from prep_entry, 2 range is [0, total)),
-    //                  prep_w / prep_rem / prep_slot
+    //                  prep_q (the packed symbols) / prep_slot
     uint4 staged_next[kPieces];
 #pragma unroll
     for (int i = 0; i < kPieces; ++i) staged_next[i] = make_uint4(0, 0, 0, 0);
@@ -189,19 +190,22 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
     };
     fetch_tile_bytes(next_tile);
     bool prepared = false;  // wave-uniform
-    uint32_t prep_kind = 0, prep_rem = 0, prep_slot = 0, prep_w[kWords];
-    uint4 prep_entry = make_uint4(0, 0, 0, 0);
+    uint32_t prep_kind = 0, prep_slot = 0;
+    PackedQuery<kWords> prep_q;
 #pragma unroll
-    for (int i = 0; i < kWords; ++i) prep_w[i] = 0;
+    for (int i = 0; i < PackedQuery<kWords>::kBits; ++i) prep_q.bits[i] = 0;
+    uint4 prep_entry = make_uint4(0, 0, 0, 0);
 
     for (;;) {
         // ---- A: the ring is empty: the prepared tile (its table entries arrived a step ago) moves in ----
         if (prepared && ring_count == 0u) {
             uint64_t pl = 0, ph = total;
-            if (prep_kind == 1u) {
-                pl = (uint64_t(prep_entry.y) << 32) | prep_entry.x;
-                ph = (uint64_t(prep_entry.w) << 32) | prep_entry.z;
-            }
+            uint32_t skip = 0;
+            if (prep_kind == 1u && table_decode(env, prep_entry, pl, ph)) skip = depth;
+            else { pl = 0; ph = total; }  // no table for this query (non-ACGT suffix, or an escape line)
+            const uint32_t prep_rem = k - skip;
+            uint32_t prep_w[kWords];
+            unpack_words<kWords>(prep_q, skip, prep_w);
             bool pending = prep_kind != 0u;
             if (pending && (prep_rem == 0u || pl == ph)) {  // decided by the table (or an empty index)
                 store_count<kReads>(src, (wave_id + uint64_t(prep_slot >> 6) * nwaves) * kTile + (prep_slot & 63u), ph - pl);
@@ -290,23 +294,21 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
                 } else if (use_table && pq.acgt) {
                     bool maybe = true;
                     if (filter_now) {  // L2-resident presence bit first: an absent suffix never touches the table line
-                        const uint32_t fi = pq.tidx & filter_mask;
+                        const uint32_t fi = uint32_t(pq.tidx) & filter_mask;
                         maybe = ((filter[fi >> 5] >> (fi & 31u)) & 1u) != 0u;
                         looked_up = true;
                         passed = maybe;
                     }
                     if (maybe) {
-                        prep_entry = table[pq.tidx];  // stays in flight: consumed in step A of the next iteration
+                        prep_entry = table_fetch(env, pq.tidx);  // stays in flight: consumed in step A of a later iteration
                         prep_kind = 1;
-                        prep_rem = k - depth;
-                        unpack_words<kWords>(pq, depth, prep_w);
+                        prep_q = pq;
                     } else {
                         store_count<kReads>(src, q0 + lane, 0ull);
                     }
                 } else {
                     prep_kind = 2;
-                    prep_rem = k;
-                    unpack_words<kWords>(pq, 0u, prep_w);
+                    prep_q = pq;
                 }
             }
             if (filter != nullptr) {
@@ -438,7 +440,7 @@ hipError_t launch_variant(hipStream_t stream, const IndexView &ix, const QuerySo
     const uint64_t waves = std::min<uint64_t>(tiles, resident_waves<kReads, kPair, kWords>());
     if ((tiles + waves - 1) / waves > kMaxTilesPerWave) return hipErrorInvalidValue;  // > 3e10 queries: split the batch
     hipLaunchKernelGGL((k_count_kmers_lanes<kReads, kPair, kWords>), dim3(uint32_t(waves)), dim3(64), 0, stream,
-                       static_cast<const uint4 *>(ix.blocks), ix.total, table, uint32_t(ix.table.depth), filter, filter_mask,
+                       static_cast<const uint4 *>(ix.blocks), ix.total, table, uint32_t(ix.table.depth), ix.table.packed ? 1u : 0u, filter, filter_mask,
                        static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags, ix.debug);
     return hipGetLastError();
 }

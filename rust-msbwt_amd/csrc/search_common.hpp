@@ -58,12 +58,44 @@ struct alignas(16) WorkItemT {  // one undecided query: 32 bytes (kWords 3) or 4
 // the suffix table and its presence filter as the setup code sees them
 struct TableEnv {
     const uint4 *table;
-    uint32_t depth;
+    uint32_t depth;        // symbols a table entry stands for
     bool use_table;        // table present and k >= depth
+    bool packed;           // entry format: false = flat {l, h} (16 B), true = packed lines (kernels.hpp)
     const uint32_t *filter;
     uint32_t filter_mask;
     uint64_t total;
 };
+
+// Packed suffix table (TableView::packed): a 128-byte line = u64 base | 30 x u32 { l - base : 16, h - l : 16 }
+// for 30 consecutive table indices (consecutive indices are consecutive ranges, so the deltas are
+// small); bit 63 of base = ESCAPE (some entry of the line does not fit 16 bits: its queries search
+// from scratch).  4.27 bytes per entry instead of 16: two more table levels in the same HBM.
+constexpr uint32_t kPackedPerLine = 30;
+constexpr uint64_t kPackedEscape = 1ull << 63;
+
+// The raw bits of one table entry, as loaded (the loads may stay in flight):
+//   flat:   {l_lo, l_hi, h_lo, h_hi};   packed: {base_lo, base_hi, entry, 0}
+__device__ __forceinline__ uint4 table_fetch(const TableEnv &env, uint64_t tidx) {
+    if (!env.packed) return env.table[tidx];
+    const uint64_t line = tidx / kPackedPerLine;
+    const uint32_t slot = uint32_t(tidx - line * kPackedPerLine);
+    const uint2 base = *reinterpret_cast<const uint2 *>(env.table + line * 8);
+    const uint32_t e = reinterpret_cast<const uint32_t *>(env.table + line * 8)[2u + slot];
+    return make_uint4(base.x, base.y, e, 0u);
+}
+
+// -> range; returns false when the entry cannot be used (escape line): search from [0, total)
+__device__ __forceinline__ bool table_decode(const TableEnv &env, const uint4 raw, uint64_t &l, uint64_t &h) {
+    if (!env.packed) {
+        l = (uint64_t(raw.y) << 32) | raw.x;
+        h = (uint64_t(raw.w) << 32) | raw.z;
+        return true;
+    }
+    const uint64_t base = (uint64_t(raw.y) << 32) | raw.x;
+    l = (base & ~kPackedEscape) + (raw.z & 0xFFFFu);
+    h = l + (raw.z >> 16);
+    return (base & kPackedEscape) == 0ull;
+}
 
 __device__ __forceinline__ uint32_t ascii_to_code(uint32_t c) {
     if (c == 0x24u) return 0u;  // '$'
@@ -120,7 +152,7 @@ template <int kWords>
 struct PackedQuery {
     static constexpr int kBits = (kWords + 1) / 2;
     uint64_t bits[kBits];  // symbol of step t (t = 0 first) at bits [3t, 3t+3) of the little-endian words
-    uint32_t tidx;         // table index of steps 0..depth-1 (A C G T -> 0..3, step t at bits [2t, 2t+2))
+    uint64_t tidx;         // table index of steps 0..depth-1 (A C G T -> 0..3, step t at bits [2t, 2t+2))
     bool bad;              // a symbol code >= 6
     bool acgt;             // steps 0..depth-1 are all ACGT: the table applies
 };
@@ -132,7 +164,8 @@ __device__ __forceinline__ void pack_query(const QuerySource &src, uint32_t dept
     const uint32_t k = src.k;
 #pragma unroll
     for (int j = 0; j < kBits; ++j) pq.bits[j] = 0;
-    uint32_t bad = 0, acgt = 1, tidx = 0;
+    uint32_t bad = 0, acgt = 1;
+    uint64_t tidx = 0;
     const uint8_t *mine = staged;
     bool rc = false;
     if (kReads) {  // window g of read r, forward or reverse-complemented
@@ -170,7 +203,7 @@ __device__ __forceinline__ void pack_query(const QuerySource &src, uint32_t dept
         }
         if (t < depth) {
             acgt &= acgt_bit(s);
-            tidx |= (acgt_code(s) & 3u) << (2u * t);
+            tidx |= uint64_t(acgt_code(s) & 3u) << (2u * t);
         }
     }
     pq.tidx = tidx;
@@ -213,17 +246,22 @@ __device__ __forceinline__ bool prepare_query(const QuerySource &src, const Tabl
         // L2-resident presence bit first: an absent suffix never touches the table line
         bool maybe = true;
         if (filter_now) {
-            const uint32_t fi = pq.tidx & env.filter_mask;
+            const uint32_t fi = uint32_t(pq.tidx) & env.filter_mask;
             maybe = ((env.filter[fi >> 5] >> (fi & 31u)) & 1u) != 0u;
             looked_up = true;
             passed = maybe;
         }
-        uint4 e = make_uint4(0, 0, 0, 0);  // empty range: count 0
-        if (maybe) e = env.table[pq.tidx];
-        l = (uint64_t(e.y) << 32) | e.x;
-        h = (uint64_t(e.w) << 32) | e.z;
-        skip = env.depth;
-        rem = src.k - env.depth;
+        if (!maybe) {
+            l = h = 0;  // empty range: count 0
+            skip = env.depth;
+            rem = src.k - env.depth;
+        } else if (table_decode(env, table_fetch(env, pq.tidx), l, h)) {
+            skip = env.depth;
+            rem = src.k - env.depth;
+        } else {  // escape line of a packed table: this query searches from scratch
+            l = 0;
+            h = env.total;
+        }
     }
     if (rem == 0u || l == h) {
         result = h - l;

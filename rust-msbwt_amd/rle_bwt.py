@@ -214,6 +214,15 @@ class RleBWT(BWT):
     def get_table_depth(self):
         return int(_lib.lib().msbwt_rle_get_table_depth(self._h))
 
+    def set_table_packed(self, mode):
+        """1 = packed table two levels deeper whenever a pair index exists, 0 = flat table only, -1 = automatic."""
+        rc = _lib.lib().msbwt_rle_set_table_packed(self._h, mode)
+        if rc:
+            _raise(rc, self._h)
+
+    def get_table_packed(self):
+        return bool(_lib.lib().msbwt_rle_get_table_packed(self._h))
+
     def set_presence_filter(self, mode):
         """0 = no presence filter, anything else = automatic (kept when it can reject something)."""
         rc = _lib.lib().msbwt_rle_set_presence_filter(self._h, mode)

@@ -493,6 +493,57 @@ def test_pair_index_on_random_streams_and_superblock_borders():
         assert np.array_equal(b.count_kmers(qs), o.count_kmers(qs))
 
 
+@pytest.mark.parametrize("flat_depth", [1, 3, 6])
+def test_packed_table_never_changes_results(flat_depth):
+    """The packed suffix table (two levels deeper than the flat one, 30 entries per 128-byte line,
+    16-bit deltas) on a true BWT: present and absent k-mers around the effective depth."""
+    reads, rle = _real_bwt(12 + flat_depth, 220, 75)
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    b.set_pair_index(1)
+    b.set_table_depth(flat_depth)
+    b.set_table_packed(1)
+    assert b.get_table_packed() and b.get_table_depth() == flat_depth + 2
+    rng = np.random.default_rng(flat_depth)
+    for k in (flat_depth + 1, flat_depth + 2, flat_depth + 3, 21, 31, 40):
+        qs = []
+        for r in reads:
+            if len(r) >= k:
+                p = int(rng.integers(0, len(r) - k + 1))
+                qs.append(orc.convert_stoi(r[p:p + k]))
+        qs = np.concatenate([np.array(qs, dtype=np.uint8), random_kmers(k, 500, k), random_kmers(k + 1, 100, k, alphabet=(0, 1, 2, 3, 4, 5))])
+        exp = o.count_kmers(qs)
+        assert np.array_equal(b.count_kmers(qs), exp), k
+    b.set_table_packed(0)
+    assert not b.get_table_packed() and b.get_table_depth() == flat_depth
+    assert np.array_equal(b.count_kmers(qs), exp)
+    b.set_table_packed(1)
+    b.set_pair_index(0)          # no pair index: the table falls back to its flat form
+    assert not b.get_table_packed() and b.get_table_depth() == flat_depth
+    assert np.array_equal(b.count_kmers(qs), exp)
+
+
+def test_packed_table_escape_lines_on_long_run_streams():
+    """Arbitrary symbol streams with runs of up to 10^5: ranges far wider than 16 bits, so most packed
+    lines are ESCAPE lines and their queries must search from scratch -- same counts."""
+    for seed, kind in ((51, "long"), (52, "mixed"), (53, "short")):
+        rle = random_stream(seed, 30_000, kind)
+        o = orc.OracleRleBWT()
+        o.load_vector(rle)
+        b = gpu_bwt(rle)
+        b.set_pair_index(1)
+        b.set_table_depth(3)
+        b.set_table_packed(1)
+        assert b.get_table_packed() and b.get_table_depth() == 5
+        for k in (5, 6, 9, 14):
+            qs = random_kmers(k + seed, 3000, k)
+            assert np.array_equal(b.count_kmers(qs), o.count_kmers(qs)), (kind, k)
+        rep = b.replicate(0)     # a replica carries the packed table along
+        assert rep.get_table_packed() and rep.get_table_depth() == 5
+        assert np.array_equal(rep.count_kmers(qs), o.count_kmers(qs))
+
+
 def test_too_large_index_is_rejected():
     """A 9-digit run encodes 32^8 = 2^40 symbols: beyond the 40-bit block counters."""
     rle = np.array([1] * 8 + [1 | (1 << 3)], dtype=np.uint8)      # A-run of exactly 2^40
