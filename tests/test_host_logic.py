@@ -4,6 +4,7 @@ load-path layout builder produces blocks that decode back to the BWT.  No GPU co
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -137,3 +138,21 @@ def test_bad_input_is_rejected():
     bad = np.array([9, 14], dtype=np.uint8)  # symbol code 6
     total = C.c_uint64()
     assert _lib.lib().msbwt_build_plane_blocks(bad.ctypes.data_as(C.c_void_p), 2, None, 0, C.byref(total)) == _lib.SIZE_MAX
+
+
+def test_default_bench_has_a_fresh_pmc_traffic_entry():
+    """bench.py's roofline.frac is HBM-counter traffic / kernel time; the traffic comes from a committed
+    rocprofv3 --pmc summary that is only valid for the kernel sources it was taken with.  The entry for
+    the DEFAULT bench configuration must carry the stamp of the sources in the tree -- re-run
+    tools/profile_bench.sh + tools/profile_collect.sh after touching a query kernel."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    stamp = bench.kernel_stamp()
+    entries = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["entries"]
+    fresh = [e for e in entries if e["workload"] == "human" and e["k"] == 31 and e.get("kernel_stamp") == stamp]
+    assert fresh, "no profiles/traffic.json entry for the default bench matches kernel stamp %s" % stamp
+    e = fresh[-1]
+    assert e["bwt_symbols"] == int(bench.HUMAN_SYMBOLS) and e["query_kind"] == "walk"
+    assert os.path.exists(os.path.join(ROOT, e["source"]))
+    assert 0 < e["traffic_bytes_per_query"] < 31 * 2 * 184  # far below the reference algorithm's worst case
