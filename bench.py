@@ -383,12 +383,15 @@ def main():
 
     weak = None
     if strong and not args.no_weak:
-        w_out, w_all, w_elapsed, _, _, w_narrow = measure(0, nq, nq)
-        assert torch.equal(w_all[rank * nq:(rank + 1) * nq], w_out)
-        assert torch.equal(w_out, d_counts), "sharded counts differ from one GPU's counts of the whole batch"
-        weak = {"value": nq * world * args.steps / w_elapsed, "unit": "queries/s", "ms_per_step": w_elapsed / args.steps * 1e3,
-                "queries_per_gpu": nq, "payload": "int16" if w_narrow else "int64",
-                "note": "every rank runs the WHOLE batch and all N x n counts are all_gathered each step"}
+        # every rank the same (whole or 1e8-query) batch, all N x n counts gathered each step; bounded so that
+        # the N x n gathered vectors fit next to a 200 GB index at N = 8
+        nw = min(nq, 100_000_000)
+        w_out, w_all, w_elapsed, _, _, w_narrow = measure(0, nw, nw)
+        assert torch.equal(w_all[rank * nw:(rank + 1) * nw], w_out)
+        assert torch.equal(w_out, d_counts[:nw]), "sharded counts differ from one GPU's counts of the same queries"
+        weak = {"value": nw * world * args.steps / w_elapsed, "unit": "queries/s", "ms_per_step": w_elapsed / args.steps * 1e3,
+                "queries_per_gpu": nw, "payload": "int16" if w_narrow else "int64",
+                "note": "every rank runs the same %d queries and all N x n counts are all_gathered each step" % nw}
         del w_out, w_all
 
     kind_text = {"walk": "present (LF-walk)", "random": "random", "reads": "read-derived"}[kind]
