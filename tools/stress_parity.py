@@ -51,8 +51,11 @@ def main():
             b.set_table_depth(depth)
             b.set_pair_index(int(rng.integers(0, 2)))
             b.set_presence_filter(int(rng.integers(0, 2)))
+            b.set_table_packed(int(rng.integers(-1, 2)))           # packed table when a pair index exists
+            b.set_search_kernel(str(rng.choice(["auto", "groups", "lanes", "lanes"])))
             k = int(rng.integers(1, 72))
-            n = int(rng.integers(1, 700))
+            # mostly small batches, sometimes many tiles per wave (ring refill, setup running ahead)
+            n = int(rng.integers(1, 700)) if rng.random() < 0.8 else int(rng.integers(5000, 60000))
             qs = [random_kmers(int(rng.integers(0, 1 << 30)), n, k),
                   random_kmers(int(rng.integers(0, 1 << 30)), n // 3 + 1, k, alphabet=(0, 1, 2, 3, 4, 5))]
             if reads is not None and reads.shape[1] >= k:
