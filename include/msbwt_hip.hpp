@@ -129,10 +129,32 @@ class RleBWT final : public BWT {
     }
 
     void set_table_depth(int depth) { check(msbwt_rle_set_table_depth(raw_, depth)); }
+    void set_table_packed(int mode) { check(msbwt_rle_set_table_packed(raw_, mode)); }
     void set_pair_index(int mode) { check(msbwt_rle_set_pair_index(raw_, mode)); }
+    void set_search_kernel(int mode) { check(msbwt_rle_set_search_kernel(raw_, mode)); }
     msbwt_rle *raw() const { return raw_; }
 
+    /// A copy of the loaded index on another GPU of the node (GPU -> GPU, no rebuild).
+    RleBWT replicate(int device) const {
+        msbwt_rle *other = msbwt_rle_replicate(raw_, device);
+        if (!other) throw Panic(MSBWT_ERR_HIP, msbwt_rle_last_error(raw_));
+        return RleBWT(other);
+    }
+    /// One batch sharded over several replicas (one per GPU); counts in query order.
+    static std::vector<std::uint64_t> count_kmers_multi(const std::vector<const RleBWT *> &replicas,
+                                                        const std::vector<std::uint8_t> &kmers, std::size_t k) {
+        if (replicas.empty()) throw std::invalid_argument("no replicas");
+        const std::size_t n = k ? kmers.size() / k : 0;
+        std::vector<const msbwt_rle *> raws;
+        for (const RleBWT *r : replicas) raws.push_back(r->raw_);
+        std::vector<std::uint64_t> out(n);
+        const int code = msbwt_rle_count_kmers_multi(raws.data(), raws.size(), kmers.data(), k, n, out.data());
+        if (code != MSBWT_OK) throw Panic(code, "count_kmers_multi failed");
+        return out;
+    }
+
   private:
+    explicit RleBWT(msbwt_rle *adopted) : raw_(adopted) {}
     void check(int code) const {
         if (code == MSBWT_OK) return;
         const std::string msg = msbwt_rle_last_error(raw_);

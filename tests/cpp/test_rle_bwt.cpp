@@ -116,6 +116,11 @@ static void error_behaviour(const std::string &dir) {
     const std::vector<uint8_t> flat = {1, 2, 3, 2, 2, 0, 5, 1, 2};  // ACG CC$ TAC
     const std::vector<uint64_t> counts = three.count_kmers(flat, 3);
     CHECK(counts.size() == 3 && counts[0] == 4 && counts[2] == 2);
+    // replicas (here on the same device) and a batch sharded over them
+    const RleBWT copy = three.replicate(-1);
+    CHECK(copy.get_total_size() == three.get_total_size() && copy.count_kmer(convert_stoi("ACG")) == 4);
+    const std::vector<uint64_t> sharded = RleBWT::count_kmers_multi({&three, &copy}, flat, 3);
+    CHECK(sharded == counts);
     const auto both = three.count_read_kmers("CCGTACGTAGGTACAGTA", 9, 3);
     CHECK(both.first.size() == 14 && both.first[2] == three.count_kmer(convert_stoi("GTA")));
     CHECK(both.second[0] == three.count_kmer(reverse_complement_i(convert_stoi("CCG"))));
