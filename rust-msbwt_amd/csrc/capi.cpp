@@ -43,6 +43,7 @@ struct msbwt_rle {
     int wanted_filter = -1;         // -1 = keep it when it can reject something, 0 = off
     int wanted_table_depth = -1; // -1 = pick from the index size
     int search_kernel = kSearchAuto;
+    unsigned launch_seq = 0;
     // device status block (128 bytes): word 0 = flags of the host-pointer entry points (handle
     // stream), word 1 = flags of the *_device entry points (caller streams; read and cleared only by
     // msbwt_rle_device_status), bytes 64.. = 8 x u64 record of a failed device consistency check
@@ -62,7 +63,9 @@ struct msbwt_rle {
 namespace {
 
 constexpr int kMaxTableDepth = 16;  // 4^16 x 16 B = 64 GiB
-constexpr size_t kStatusBytes = 128;
+constexpr size_t kStatusBytes = 1024;  // flags + debug record (first 128 bytes), then 64 u64 tile-ticket counters
+constexpr size_t kCounterOffset = 512;
+constexpr unsigned kCounters = 64;
 constexpr int kHostFlags = 0, kDeviceFlags = 1;  // words of the status block
 
 const char *kVersion = "rust-msbwt_amd 0.1.0 (gfx950 plane-block index)";
@@ -124,7 +127,7 @@ void release_index(msbwt_rle *h) {
     h->loaded = false;
 }
 
-IndexView view_of(const msbwt_rle *h) {
+IndexView view_of(msbwt_rle *h) {
     IndexView v;
     v.blocks = h->d_blocks;
     v.nblocks = h->nblocks;
@@ -138,6 +141,9 @@ IndexView view_of(const msbwt_rle *h) {
     v.pair_super = static_cast<const uint64_t *>(h->d_pair_super);
     v.search_kernel = h->search_kernel;
     v.debug = h->d_flags ? reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(h->d_flags) + 64) : nullptr;
+    // one ticket counter per launch, round robin over 64: launches on one stream are ordered anyway, and 64
+    // launches of one handle in flight on different streams at once is beyond any sensible use
+    if (h->d_flags) v.tile_counter = reinterpret_cast<char *>(h->d_flags) + kCounterOffset + 8 * (h->launch_seq++ % kCounters);
     return v;
 }
 

@@ -36,6 +36,7 @@ struct IndexView {
     const uint64_t *pair_super = nullptr;
     int search_kernel = kSearchAuto;
     uint64_t *debug = nullptr;  // 8 words: [0] != 0 once a consistency check has recorded its values in [1..]
+    void *tile_counter = nullptr;  // u64 ticket counter of the lanes kernel's dynamic tile scheduling (zeroed per launch)
 };
 
 // counts[q] = count_kmer(kmers[q*k .. q*k+k)) for q < n.  Sets kFlagInvalidSymbol in *flags

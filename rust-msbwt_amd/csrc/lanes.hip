@@ -141,7 +141,8 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
                                                           const uint32_t *__restrict__ filter, uint32_t filter_mask,
                                                           const uint4 *__restrict__ pair_blocks,
                                                           const uint64_t *__restrict__ pair_super, const QuerySource src,
-                                                          uint32_t *__restrict__ flags, uint64_t *__restrict__ debug) {
+                                                          uint32_t *__restrict__ flags, uint64_t *__restrict__ debug,
+                                                          unsigned long long *__restrict__ tile_counter, uint32_t grain) {
     using Scratch = LaneScratchT<kWords>;
     using WorkItem = WorkItemT<kWords>;
     constexpr int kPieces = Scratch::kMaxK / 16;  // 16-byte pieces of a tile per lane: 2 or 4
@@ -152,21 +153,40 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
     const uint32_t lane = threadIdx.x;
     const uint8_t *stage_bytes = reinterpret_cast<const uint8_t *>(ws.lines);
     const uint64_t ntiles = (n + kTile - 1) / kTile;
-    const uint64_t wave_id = blockIdx.x, nwaves = gridDim.x;
     const bool use_table = table != nullptr && depth > 0 && k >= depth;
     const TableEnv env{table, depth, use_table, table_packed != 0u, filter, filter_mask, total};
     // this lane's part in the line fetches: 16 bytes (one chunk) of the line in list slot 8 i + dma_group
     const uint32_t dma_group = lane >> 3, dma_chunk_bytes = ((lane & 7u) ^ dma_group) * 16u;
 
-    uint64_t next_tile = wave_id;        // next tile to set up
-    uint32_t seq = 0;                    // tiles set up so far (slot = seq * 64 + lane of the tile)
+    // Tiles are dealt out dynamically, `grain` consecutive tiles per atomic ticket (one address takes
+    // only ~10^8 atomics/s: a ticket per tile would cap a human-scale launch), one ticket ahead so
+    // that neither the ticket nor a tile's bytes are ever waited for.  Waves that run slower -- a SIMD
+    // shared with a third wave, a CU shared with an RCCL kernel -- simply take fewer tiles.
+    auto take_ticket = [&]() -> uint64_t {
+        unsigned long long t = 0;
+        if (lane == 0) t = atomicAdd(tile_counter, 1ull);
+        return ((uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(t >> 32))))) << 32) |
+                uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(t))))) * grain;
+    };
+    uint64_t batch = take_ticket(), batch_after = take_ticket();
+    uint32_t in_batch = 0;
+    uint64_t next_tile = batch;          // next tile to set up (its bytes are being fetched)
+    auto advance_tile = [&]() {
+        if (++in_batch == grain) {
+            batch = batch_after;
+            in_batch = 0;
+            batch_after = take_ticket();
+        }
+        next_tile = batch + in_batch;
+    };
     uint32_t ring_head = 0, ring_count = 0;  // wave-uniform
     uint32_t filter_pause = 0;           // as in the tiled kernel: the filter rests while nearly everything passes
 
     // the lane's running query
     bool have = false;
     uint64_t l = 0, h = 0;
-    uint32_t w[kWords], rem = 0, slot = 0;
+    uint32_t w[kWords], rem = 0;
+    uint64_t qid = 0;  // global index of the lane's query
 #pragma unroll
     for (int i = 0; i < kWords; ++i) w[i] = 0;
 
@@ -176,7 +196,7 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
     //   staged_next[]: bytes of tile `next_tile` (loads issued, not waited for)
     //   prepared:      a tile has been packed and its table loads issued; per lane: prep_kind
     //                  (0 nothing to do, 1 range comes from prep_entry, 2 range is [0, total)),
-    //                  prep_q (the packed symbols) / prep_slot
+    //                  prep_q (the packed symbols); prep_tile (wave-uniform) is the tile they belong to
     uint4 staged_next[kPieces];
 #pragma unroll
     for (int i = 0; i < kPieces; ++i) staged_next[i] = make_uint4(0, 0, 0, 0);
@@ -190,7 +210,8 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
     };
     fetch_tile_bytes(next_tile);
     bool prepared = false;  // wave-uniform
-    uint32_t prep_kind = 0, prep_slot = 0;
+    uint32_t prep_kind = 0;
+    uint64_t prep_tile = 0;
     PackedQuery<kWords> prep_q;
 #pragma unroll
     for (int i = 0; i < PackedQuery<kWords>::kBits; ++i) prep_q.bits[i] = 0;
@@ -208,18 +229,19 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
             unpack_words<kWords>(prep_q, skip, prep_w);
             bool pending = prep_kind != 0u;
             if (pending && (prep_rem == 0u || pl == ph)) {  // decided by the table (or an empty index)
-                store_count<kReads>(src, (wave_id + uint64_t(prep_slot >> 6) * nwaves) * kTile + (prep_slot & 63u), ph - pl);
+                store_count<kReads>(src, prep_tile * kTile + lane, ph - pl);
                 pending = false;
             }
             const uint64_t pend_mask = __ballot(pending);
             if (pending) {
                 const uint32_t at = __builtin_amdgcn_mbcnt_hi(uint32_t(pend_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(pend_mask), 0u));
                 WorkItem it;
-                it.l_lo = uint32_t(pl); it.l_hi = uint32_t(pl >> 32);
-                it.h_lo = uint32_t(ph); it.h_hi = uint32_t(ph >> 32);
+                // l, h < 2^40: the hi words have 24 spare bits each -- they carry the 32-bit tile index
+                it.l_lo = uint32_t(pl); it.l_hi = uint32_t(pl >> 32) | (uint32_t(prep_tile) << 8);
+                it.h_lo = uint32_t(ph); it.h_hi = uint32_t(ph >> 32) | ((uint32_t(prep_tile) >> 24) << 8);
 #pragma unroll
                 for (int i = 0; i < kWords; ++i) it.w[i] = prep_w[i];
-                it.rem_slot = prep_rem | (prep_slot << 8);
+                it.rem_slot = prep_rem | (lane << 8);
                 ws.ring[(ring_head + ring_count + at) & (kRing - 1)] = it;
             }
             ring_count += uint32_t(__popcll(pend_mask));
@@ -234,8 +256,9 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
             if (!have && my < ring_count) {
                 const uint4 *it = reinterpret_cast<const uint4 *>(&ws.ring[(ring_head + my) & (kRing - 1)]);
                 const uint4 a = it[0], b = it[1];
-                l = (uint64_t(a.y) << 32) | a.x;
-                h = (uint64_t(a.w) << 32) | a.z;
+                l = (uint64_t(a.y & 0xFFu) << 32) | a.x;
+                h = (uint64_t(a.w & 0xFFu) << 32) | a.z;
+                const uint32_t item_tile = (a.y >> 8) | ((a.w >> 8) << 24);
                 uint32_t rem_slot;
                 if constexpr (kWords == 3) {
                     w[0] = b.x; w[1] = b.y; w[2] = b.z;
@@ -246,7 +269,7 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
                     rem_slot = c.z;
                 }
                 rem = rem_slot & 0xFFu;
-                slot = rem_slot >> 8;
+                qid = uint64_t(item_tile) * kTile + (rem_slot >> 8);
                 have = true;
             }
             const uint32_t taken = min(ring_count, uint32_t(__popcll(idle)));
@@ -261,11 +284,11 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
             if (debug != nullptr && atomicCAS(reinterpret_cast<unsigned long long *>(debug), 0ull, 1ull) == 0ull) {
                 debug[1] = l;
                 debug[2] = h;
-                debug[3] = (uint64_t(rem) << 32) | slot;
+                debug[3] = (uint64_t(rem) << 56) | qid;
                 debug[4] = (uint64_t(w[1]) << 32) | w[0];
                 debug[5] = (uint64_t(blockIdx.x) << 32) | lane;
             }
-            store_count<kReads>(src, (wave_id + uint64_t(slot >> 6) * nwaves) * kTile + (slot & 63u), ~0ull);
+            store_count<kReads>(src, qid, ~0ull);
             have = false;
         }
         busy = __ballot(have);
@@ -273,7 +296,7 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
         // ---- C: nothing prepared: pack the next tile and ask the table for its ranges ----
         if (!prepared && next_tile < ntiles) {
             const uint64_t tile = next_tile;
-            next_tile += nwaves;
+            advance_tile();
             const uint64_t q0 = tile * kTile;
             const uint32_t in_tile = uint32_t(min(uint64_t(kTile), n - q0));
             const bool filter_now = filter != nullptr && filter_pause == 0;
@@ -284,7 +307,7 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
             }
             wave_lds_sync();
             prep_kind = 0;
-            prep_slot = seq * 64u + lane;
+            prep_tile = tile;
             if (lane < in_tile) {
                 PackedQuery<kWords> pq;
                 pack_query<kReads, kWords>(src, depth, stage_bytes + lane * k, q0 + lane, pq);
@@ -319,7 +342,6 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
                     --filter_pause;
                 }
             }
-            ++seq;
             prepared = true;
             wave_lds_sync();         // every lane has read its staged bytes: the line area may be overwritten
             fetch_tile_bytes(next_tile);  // the following tile's bytes start their trip now
@@ -395,7 +417,7 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
             l = nl;
             h = nh;
             if (rem == 0u || l == h) {
-                store_count<kReads>(src, (wave_id + uint64_t(slot >> 6) * nwaves) * kTile + (slot & 63u), h - l);
+                store_count<kReads>(src, qid, h - l);
                 have = false;
             }
         }
@@ -403,11 +425,11 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
     }
 }
 
-// The wave's 24-bit slot numbers allow 2^18 tiles per wave and launch
-constexpr uint64_t kMaxTilesPerWave = 1ull << 18;
+// A work item carries its tile index in 32 bits: at most 2^32 tiles (2^38 queries) per launch
+constexpr uint64_t kMaxTiles = 1ull << 32;
 
-// The kernel is persistent and tiles are dealt out statically, so the grid must be exactly what
-// the device keeps resident: workgroups per CU (occupancy API: LDS- and VGPR-bound) x CUs.
+// The kernel is persistent: the grid is what the device keeps resident -- workgroups per CU
+// (occupancy API: LDS- and VGPR-bound, capped below) x CUs; tiles are dealt out by atomic tickets.
 template <bool kReads, bool kPair, int kWords>
 uint32_t resident_waves() {
     static const uint32_t cached = [] {
@@ -417,9 +439,10 @@ uint32_t resident_waves() {
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_count_kmers_lanes<kReads, kPair, kWords>, 64, 0) != hipSuccess ||
             cus <= 0 || per_cu <= 0)
             return 7u * 256u;
-        // Measured on MI355X (tools/sweep_waves.sh): throughput rises up to 8 waves per CU -- two per
-        // SIMD -- and falls beyond, in the HBM regime (human-scale index: 5: 3.76, 7: 4.20, 8: 4.31,
-        // 9: 3.80, 10: 3.04 x 10^9 q/s) and on a cache-resident index alike (C3: 8: 4.32, 10: 3.13).
+        // Measured on MI355X (tools/sweep_waves.sh, human-scale index): throughput rises up to 8 waves
+        // per CU -- two per SIMD -- and is flat beyond (8, 9, 10, 12: 5.15 x 10^9 q/s each): the memory
+        // system's random-line rate is reached.  (With static tile striding 9 and 10 waves LOST 12-30 %:
+        // the waves of a three-wave SIMD ran slower and everybody waited for them.)
         per_cu = std::min(per_cu, 8);
         if (const char *env = std::getenv("MSBWT_LANES_WAVES_PER_CU")) {  // experiments
             const int want = std::atoi(env);
@@ -438,10 +461,15 @@ hipError_t launch_variant(hipStream_t stream, const IndexView &ix, const QuerySo
     const uint32_t filter_mask = filter ? uint32_t((1ull << (2 * ix.table.filter_depth)) - 1ull) : 0u;
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
     const uint64_t waves = std::min<uint64_t>(tiles, resident_waves<kReads, kPair, kWords>());
-    if ((tiles + waves - 1) / waves > kMaxTilesPerWave) return hipErrorInvalidValue;  // > 3e10 queries: split the batch
+    if (tiles > kMaxTiles || !ix.tile_counter) return hipErrorInvalidValue;
+    const hipError_t zeroed = hipMemsetAsync(ix.tile_counter, 0, sizeof(unsigned long long), stream);
+    if (zeroed != hipSuccess) return zeroed;
+    // tiles per ticket: about eight tickets per wave at least, sixteen tiles at most
+    const uint32_t grain = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(16, tiles / (waves * 8))));
     hipLaunchKernelGGL((k_count_kmers_lanes<kReads, kPair, kWords>), dim3(uint32_t(waves)), dim3(64), 0, stream,
                        static_cast<const uint4 *>(ix.blocks), ix.total, table, uint32_t(ix.table.depth), ix.table.packed ? 1u : 0u, filter, filter_mask,
-                       static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags, ix.debug);
+                       static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags, ix.debug,
+                       static_cast<unsigned long long *>(ix.tile_counter), grain);
     return hipGetLastError();
 }
 
