@@ -34,7 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is achievable
-RANDOM_LINE_PEAK = 4.4e10  # dependent random 128-byte lines/s, measured (tools/ubench_gather.hip, 1-200 GB tables)
+RANDOM_LINE_PEAK = 4.8e10  # dependent random 128-byte lines/s over 100 GB, measured (tools/ubench_lds_gather.hip, 8+ waves/CU)
 HUMAN_SYMBOLS = 9e10
 KERNEL_SOURCES = ["kernels.hip", "lanes.hip", "search_common.hpp", "rank_ops.hpp", "kernels.hpp", "plane_index.hpp"]
 
