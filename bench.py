@@ -45,11 +45,15 @@ def log(msg):
 
 def kernel_stamp():
     """Identifies the query kernels a PMC summary was taken with: profiles/traffic.json entries
-    carry it, and an entry whose stamp differs from the sources in the tree is refused."""
+    carry it, and an entry whose stamp differs from the sources in the tree is refused.  Comments
+    and white space do not count (a reworded comment does not invalidate a profile)."""
+    import re
     h = hashlib.sha256()
     for name in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, "rust-msbwt_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(ROOT, "rust-msbwt_amd", "csrc", name), "r") as f:
+            text = f.read()
+        text = re.sub(r"//[^\n]*", "", text)          # the sources use // comments only
+        h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -11,7 +11,7 @@
 //      second blocks are compacted with a wave ballot + prefix count into a line list in LDS;
 //   2. the wave fetches every listed line with coalesced LDS-DMA loads (global_load_lds_dwordx4:
 //      8 lanes x 16 B = one line, eight lines per instruction, no VGPRs spent on data in flight)
-//      -- 64..128 lines in flight per wave instead of 8..16;
+//      -- 64..112 lines in flight per wave instead of 8..16;
 //   3. after s_waitcnt vmcnt(0) every lane reads its own line(s) back from LDS (bank-conflict
 //      free, see line_base) and ranks both bounds itself: XOR / AND / popcount on the bit planes,
 //      no cross-lane reduction at all.
@@ -20,9 +20,10 @@
 // code (stage the tile's bytes, validate, pack, suffix-table lookup -- the pieces of
 // search_common.hpp) keeps topped up, so all 64 lanes stay busy whatever the mix of early exits.
 // Setup never waits for memory by itself: a tile's bytes are fetched an iteration early and its
-// table entries ride along with the next search step's lines.  Counts go straight to the caller's
-// buffer.  Block layouts: plane_index.hpp,
-// rank_ops.hpp.  One wave per workgroup, 17.75 KiB of LDS each; 8 waves per CU (launch_variant).
+// table entries ride along with the next search step's lines.  Tiles are dealt out by atomic
+// tickets, so slow waves simply take fewer.  Counts go straight to the caller's buffer.
+// Block layouts: plane_index.hpp, rank_ops.hpp.  One wave per workgroup, 17.75 KiB of LDS each;
+// 8 waves per CU (resident_waves).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
