@@ -81,6 +81,8 @@ def parse_args(argv=None):
     ap.add_argument("--query-kind", default="", choices=["", "random", "reads", "walk"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the index (tests)")
     ap.add_argument("--table-depth", type=int, default=-2, help="-2 = library default")
+    ap.add_argument("--blocks", default="planes", choices=["planes", "runs"],
+                    help="index block format: planes (default) or the memory-lean run blocks (no pair index)")
     ap.add_argument("--fused", action="store_true",
                     help="c2/c3: queries = every k-mer window of every read, prepared in-kernel from the reads "
                          "(msbwt_rle_count_read_kmers_device); BASELINE.json configs[2] is --workload c3 --fused")
@@ -224,6 +226,7 @@ def main():
     symbols = int((HUMAN_SYMBOLS if human else args.big_symbols) * (args.scale if human else 1.0))
 
     bwt = msbwt.RleBWT(device=local_rank)
+    bwt.set_block_format(args.blocks)
     if args.table_depth > -2:
         bwt.set_table_depth(args.table_depth)
     t0 = time.time()
@@ -424,7 +427,7 @@ def main():
         "config": {
             "workload": wl, "k": k, "queries_per_step": job_queries, "queries_per_gpu": mine_n if strong else nq,
             "bwt_symbols": total, "index_bytes": bwt.device_bytes(),
-            "table_depth": bwt.get_table_depth(), "pair_index": bwt.get_pair_index(),
+            "table_depth": bwt.get_table_depth(), "pair_index": bwt.get_pair_index(), "block_format": bwt.get_block_format(),
             "parallelism": ("index replicated x%d; %s; per step one %s all_gather of all counts (%s payload, widened to u64 on "
                             "arrival), overlapped with the next step's kernel"
                             % (world, "ONE fixed batch sharded over the ranks" if strong else "every rank its own whole batch",

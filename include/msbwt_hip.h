@@ -177,6 +177,15 @@ int msbwt_rle_get_presence_filter(const msbwt_rle *bwt);
  * (default; MSBWT_PAIR_INDEX=0/1 in the environment overrides).  Results never change. */
 int msbwt_rle_set_pair_index(msbwt_rle *bwt, int mode);
 int msbwt_rle_get_pair_index(const msbwt_rle *bwt);
+/* Block format of the index, chosen BEFORE a load (MSBWT_BLOCKS=runs in the environment sets the
+ * initial choice): 0 = bit-plane blocks (default: 0.5 byte per symbol, fastest, the only format the
+ * pair index and the lane-per-query kernel work on), 1 = run blocks -- the layout of the reference's
+ * run_block_av_flat (src/run_block_av_flat.rs:43-56,97-125): 128-byte blocks of 512 positions with
+ * per-block counts and 96 one-byte runs, ~0.3 byte per symbol on 30x short-read BWTs, single-symbol
+ * steps only (no pair index), ~1.4x the work per rank.  For replicas that must leave HBM to others.
+ * Results never change. */
+int msbwt_rle_set_block_format(msbwt_rle *bwt, int format);
+int msbwt_rle_get_block_format(const msbwt_rle *bwt);
 /* Search kernel for 1 <= k <= 64: 0 = automatic (default), 1 = 8 lanes per query, lines in
  * registers (kernels.hip; best when most of a query is decided by the suffix table), 2 = one
  * query per lane, lines staged through LDS by LDS-DMA (lanes.hip; best for long searches -- it
@@ -198,6 +207,11 @@ const char *msbwt_rle_last_error(const msbwt_rle *bwt);
  * them to out_blocks (may be NULL), the symbol total to *out_total. SIZE_MAX on bad input. */
 size_t msbwt_build_plane_blocks(const uint8_t *rle_bytes, size_t len, void *out_blocks, size_t cap_blocks,
                                 uint64_t *out_total);
+/* The same for the run-block format (layout: rust-msbwt_amd/csrc/run_index.hpp): returns the number
+ * of 128-byte blocks (= total/512 + 1); out_overflow receives 256 bytes per overflowing block
+ * (*out_noverflow of them).  Call with NULL outputs to size.  SIZE_MAX on bad input. */
+size_t msbwt_build_run_blocks(const uint8_t *rle_bytes, size_t len, void *out_blocks, size_t cap_blocks,
+                              void *out_overflow, size_t cap_overflow, uint64_t *out_total, uint64_t *out_noverflow);
 /* Copies the index as it sits in HBM back to the host (same layout as
  * msbwt_build_plane_blocks); returns the block count, SIZE_MAX on error.  Lets tests compare
  * the device-side builder with the host one. */

@@ -43,6 +43,8 @@ SIGNATURES = {
     "msbwt_rle_get_table_packed": (_int, [_vp]),
     "msbwt_rle_set_presence_filter": (_int, [_vp, _int]),
     "msbwt_rle_get_presence_filter": (_int, [_vp]),
+    "msbwt_rle_set_block_format": (_int, [_vp, _int]),
+    "msbwt_rle_get_block_format": (_int, [_vp]),
     "msbwt_rle_set_search_kernel": (_int, [_vp, _int]),
     "msbwt_rle_get_search_kernel": (_int, [_vp]),
     "msbwt_rle_set_pair_index": (_int, [_vp, _int]),
@@ -54,6 +56,7 @@ SIGNATURES = {
     "msbwt_rle_last_error": (C.c_char_p, [_vp]),
     "msbwt_version": (C.c_char_p, []),
     "msbwt_build_plane_blocks": (_sz, [_vp, _sz, _vp, _sz, _pu64]),
+    "msbwt_build_run_blocks": (_sz, [_vp, _sz, _vp, _sz, _vp, _sz, _pu64, _pu64]),
     "msbwt_rle_download_blocks": (_sz, [_vp, _vp, _sz]),
     "msbwt_convert_to_vec": (_sz, [_vp, _sz, _vp, _sz]),
     "msbwt_save_bwt_numpy": (_int, [_vp, _sz, C.c_char_p]),

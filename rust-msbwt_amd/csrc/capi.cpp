@@ -19,6 +19,7 @@
 #include "pair_index.hpp"
 #include "plane_index.hpp"
 #include "rle_codec.hpp"
+#include "run_index.hpp"
 
 using namespace msbwt;
 
@@ -29,6 +30,10 @@ struct msbwt_rle {
     Totals totals{};
     void *d_blocks = nullptr;
     uint64_t nblocks = 0;
+    int block_format = kBlocksPlanes;         // format of d_blocks
+    int wanted_block_format = kBlocksPlanes;  // takes effect at the next load
+    void *d_overflow = nullptr;               // run blocks: plane-shaped lines of the overflowing blocks
+    uint64_t overflow_bytes = 0;
     void *d_pair_blocks = nullptr;  // optional pair index (two symbols per step)
     void *d_pair_super = nullptr;
     uint64_t pair_bytes = 0;
@@ -111,6 +116,9 @@ int hip_fail(msbwt_rle *h, hipError_t e, const char *what) {
 
 void release_index(msbwt_rle *h) {
     if (h->d_blocks) (void)hipFree(h->d_blocks);
+    if (h->d_overflow) (void)hipFree(h->d_overflow);
+    h->d_overflow = nullptr;
+    h->overflow_bytes = 0;
     if (h->d_table) (void)hipFree(h->d_table);
     if (h->d_filter) (void)hipFree(h->d_filter);
     h->d_filter = nullptr;
@@ -130,6 +138,8 @@ void release_index(msbwt_rle *h) {
 IndexView view_of(msbwt_rle *h) {
     IndexView v;
     v.blocks = h->d_blocks;
+    v.block_format = h->block_format;
+    v.overflow = h->d_overflow;
     v.nblocks = h->nblocks;
     v.total = h->totals.total;
     v.table.entries = h->d_table;
@@ -277,7 +287,7 @@ int rebuild_pair_index(msbwt_rle *h) {
     if (h->d_pair_super) (void)hipFree(h->d_pair_super);
     h->d_pair_blocks = h->d_pair_super = nullptr;
     h->pair_bytes = 0;
-    if (h->wanted_pair == 0 || h->totals.total == 0) return MSBWT_OK;
+    if (h->wanted_pair == 0 || h->totals.total == 0 || h->block_format != kBlocksPlanes) return MSBWT_OK;  // built from plane blocks
     const PairIndexSizes sz = pair_index_sizes(h->nblocks);
     if (h->wanted_pair < 0) {
         size_t free_b = 0, total_b = 0;
@@ -371,7 +381,25 @@ int build_on_device(msbwt_rle *h, const uint8_t *rle, size_t n, Totals *t_out) {
     return MSBWT_OK;
 }
 
-// Common tail of both load entry points: build the plane blocks in HBM, then the table.
+// Run blocks (the memory-lean format, run_index.hpp): built on the host, uploaded.
+int build_run_index(msbwt_rle *h, const uint8_t *rle, size_t n, Totals *t_out) {
+    Totals t;
+    if (!compute_totals(rle, n, &t)) return fail(h, MSBWT_ERR_INVALID_SYMBOL, "RLE stream holds a symbol code >= 6");
+    if (t.total > kMaxTotal) return fail(h, MSBWT_ERR_TOO_LARGE, "BWT has 2^40 symbols or more");
+    RunIndex ri;
+    build_run_blocks(rle, n, t, &ri, 0);
+    HIP_TRY(h, hipMalloc(&h->d_blocks, ri.blocks.size() * sizeof(uint32_t)));
+    HIP_TRY(h, hipMemcpy(h->d_blocks, ri.blocks.data(), ri.blocks.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (!ri.overflow.empty()) {
+        h->overflow_bytes = ri.overflow.size() * sizeof(uint32_t);
+        HIP_TRY(h, hipMalloc(&h->d_overflow, h->overflow_bytes));
+        HIP_TRY(h, hipMemcpy(h->d_overflow, ri.overflow.data(), h->overflow_bytes, hipMemcpyHostToDevice));
+    }
+    *t_out = t;
+    return MSBWT_OK;
+}
+
+// Common tail of both load entry points: build the blocks in HBM, then the pair index and the table.
 // The previous index is released FIRST (two human-scale indexes do not fit one GPU): a failed load
 // leaves the handle unloaded -- total size and symbol counts 0, queries MSBWT_ERR_NOT_LOADED.
 int install(msbwt_rle *h, const uint8_t *rle, size_t n) {
@@ -382,13 +410,15 @@ int install(msbwt_rle *h, const uint8_t *rle, size_t n) {
     if (rc) return rc;
     Totals t{};
     const char *mode = std::getenv("MSBWT_BUILD");
-    rc = (mode && std::strcmp(mode, "host") == 0) ? build_on_host(h, rle, n, &t) : build_on_device(h, rle, n, &t);
+    h->block_format = h->wanted_block_format;
+    if (h->block_format == kBlocksRuns) rc = build_run_index(h, rle, n, &t);
+    else rc = (mode && std::strcmp(mode, "host") == 0) ? build_on_host(h, rle, n, &t) : build_on_device(h, rle, n, &t);
     if (rc) {
         release_index(h);
         return rc;
     }
     h->totals = t;
-    h->nblocks = plane_block_count(t.total);
+    h->nblocks = h->block_format == kBlocksRuns ? run_block_count(t.total) : plane_block_count(t.total);
     h->loaded = true;
     rc = rebuild_pair_index(h);  // first: the table may be packed with its help
     if (!rc) rc = rebuild_table(h);
@@ -471,6 +501,7 @@ msbwt_rle *msbwt_rle_new_on_device(uint8_t bin_power, int device) {
     if (const char *env = std::getenv("MSBWT_TABLE_PACKED")) h->wanted_table_packed = std::atoi(env) ? 1 : 0;
     if (const char *env = std::getenv("MSBWT_PAIR_INDEX")) h->wanted_pair = std::atoi(env) ? 1 : 0;
     if (const char *env = std::getenv("MSBWT_FILTER")) h->wanted_filter = std::atoi(env) ? -1 : 0;
+    if (const char *env = std::getenv("MSBWT_BLOCKS")) h->wanted_block_format = std::strcmp(env, "runs") == 0 ? kBlocksRuns : kBlocksPlanes;
     if (const char *env = std::getenv("MSBWT_SEARCH"))
         h->search_kernel = std::strcmp(env, "groups") == 0 ? kSearchGroups : std::strcmp(env, "lanes") == 0 ? kSearchLanes : kSearchAuto;
     return h;
@@ -759,6 +790,8 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
     if (!h) return nullptr;
     h->wanted_table_depth = src->wanted_table_depth;
     h->wanted_table_packed = src->wanted_table_packed;
+    h->wanted_block_format = src->wanted_block_format;
+    h->block_format = src->block_format;
     h->wanted_pair = src->wanted_pair;
     h->wanted_filter = src->wanted_filter;
     h->search_kernel = src->search_kernel;
@@ -785,6 +818,7 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
     struct Piece { void *const *from; void **to; size_t bytes; };
     const Piece pieces[] = {
         {&src->d_blocks, &h->d_blocks, size_t(src->nblocks) * kBlockBytes},
+        {&src->d_overflow, &h->d_overflow, src->d_overflow ? size_t(src->overflow_bytes) : 0},
         {&src->d_table, &h->d_table, src->d_table ? src->table_bytes : 0},
         {reinterpret_cast<void *const *>(&src->d_filter), reinterpret_cast<void **>(&h->d_filter), src->d_filter ? (size_t(1) << (2 * src->filter_depth)) / 8 : 0},
         {&src->d_pair_blocks, &h->d_pair_blocks, src->d_pair_blocks ? psz.pair_block_bytes : 0},
@@ -800,6 +834,7 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
     if (e != hipSuccess) return give_up(e, "replicate: copy index to the other device");
     h->totals = src->totals;
     h->nblocks = src->nblocks;
+    h->overflow_bytes = src->overflow_bytes;
     h->table_depth = src->table_depth;
     h->table_packed = src->table_packed;
     h->table_bytes = src->table_bytes;
@@ -967,6 +1002,15 @@ int msbwt_rle_get_table_packed(const msbwt_rle *h) { return (h && h->d_table && 
 
 int msbwt_rle_get_presence_filter(const msbwt_rle *h) { return (h && h->d_filter) ? h->filter_depth : 0; }
 
+int msbwt_rle_set_block_format(msbwt_rle *h, int format) {
+    if (!h || (format != kBlocksPlanes && format != kBlocksRuns)) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->wanted_block_format = format;  // the next load builds it
+    return MSBWT_OK;
+}
+
+int msbwt_rle_get_block_format(const msbwt_rle *h) { return h ? (h->loaded ? h->block_format : h->wanted_block_format) : 0; }
+
 int msbwt_rle_set_search_kernel(msbwt_rle *h, int mode) {
     if (!h || mode < kSearchAuto || mode > kSearchLanes) return MSBWT_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
@@ -978,7 +1022,7 @@ int msbwt_rle_get_search_kernel(const msbwt_rle *h) { return h ? h->search_kerne
 
 uint64_t msbwt_rle_device_bytes(const msbwt_rle *h) {
     if (!h || !h->loaded) return 0;
-    return h->nblocks * kBlockBytes + (h->d_table ? uint64_t(h->table_bytes) : 0) + h->pair_bytes +
+    return h->nblocks * kBlockBytes + h->overflow_bytes + (h->d_table ? uint64_t(h->table_bytes) : 0) + h->pair_bytes +
            (h->d_filter ? (uint64_t(1) << (2 * h->filter_depth)) / 8 : 0);
 }
 
@@ -1027,7 +1071,7 @@ const char *msbwt_rle_last_error(const msbwt_rle *ch) {
 
 size_t msbwt_rle_download_blocks(const msbwt_rle *ch, void *out_blocks, size_t cap_blocks) {
     msbwt_rle *h = const_cast<msbwt_rle *>(ch);
-    if (!h || !h->loaded) return SIZE_MAX;
+    if (!h || !h->loaded || h->block_format != kBlocksPlanes) return SIZE_MAX;
     std::lock_guard<std::mutex> lock(h->mu);
     DeviceScope scope(h->device);
     if (!scope.ok()) return SIZE_MAX;
@@ -1045,6 +1089,19 @@ size_t msbwt_build_plane_blocks(const uint8_t *rle_bytes, size_t len, void *out_
     const uint64_t nblocks = plane_block_count(t.total);
     if (out_blocks && cap_blocks >= nblocks) build_plane_blocks(rle_bytes, len, t, static_cast<uint32_t *>(out_blocks), 0);
     return size_t(nblocks);
+}
+
+size_t msbwt_build_run_blocks(const uint8_t *rle_bytes, size_t len, void *out_blocks, size_t cap_blocks, void *out_overflow,
+                              size_t cap_overflow, uint64_t *out_total, uint64_t *out_noverflow) {
+    Totals t;
+    if ((!rle_bytes && len) || !compute_totals(rle_bytes, len, &t) || t.total > kMaxTotal) return SIZE_MAX;
+    RunIndex ri;
+    build_run_blocks(rle_bytes, len, t, &ri, 0);
+    if (out_total) *out_total = t.total;
+    if (out_noverflow) *out_noverflow = ri.noverflow;
+    if (out_blocks && cap_blocks >= ri.nblocks) std::memcpy(out_blocks, ri.blocks.data(), ri.blocks.size() * sizeof(uint32_t));
+    if (out_overflow && cap_overflow >= ri.noverflow && ri.noverflow) std::memcpy(out_overflow, ri.overflow.data(), ri.overflow.size() * sizeof(uint32_t));
+    return size_t(ri.nblocks);
 }
 
 size_t msbwt_convert_to_vec(const uint8_t *ascii, size_t n, uint8_t *out, size_t cap) {

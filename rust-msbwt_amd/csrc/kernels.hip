@@ -33,7 +33,8 @@ namespace {
 constexpr int kWavesPerBlock = 4;
 
 // ---- count_kmers, any k: one query per group at a time, symbols read as needed ----------
-__global__ __launch_bounds__(256) void k_count_kmers_generic(const uint4 *__restrict__ blocks, uint64_t total,
+__global__ __launch_bounds__(256) void k_count_kmers_generic(const uint4 *__restrict__ blocks, uint32_t format,
+                                                             const uint4 *__restrict__ overflow, uint64_t total,
                                                              const uint8_t *__restrict__ kmers, uint32_t k,
                                                              uint64_t n, uint64_t *__restrict__ counts,
                                                              uint32_t *__restrict__ flags) {
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void k_count_kmers_generic(const uint4 *__rest
             if (sub == 0) atomicOr(flags, kFlagInvalidSymbol);
         } else {
             Range r{0, total};
-            for (uint32_t i = k; i-- > 0 && r.l != r.h;) r = constrain(blocks, kmer[i], r.l, r.h, sub);
+            for (uint32_t i = k; i-- > 0 && r.l != r.h;) r = constrain_any(format, blocks, overflow, kmer[i], r.l, r.h, sub);
             result = r.h - r.l;
         }
         if (sub == 0) counts[q] = result;
@@ -69,9 +70,9 @@ struct WaveScratchT {
 
 template <bool kReads, int kWords>
 __global__ __launch_bounds__(256, kWords == 6 ? 5 : 8) void k_count_kmers_tiled(
-    const uint4 *__restrict__ blocks, uint64_t total, const uint4 *__restrict__ table, uint32_t depth,
-    uint32_t table_packed, const uint32_t *__restrict__ filter, uint32_t filter_mask, const QuerySource src,
-    uint32_t *__restrict__ flags) {
+    const uint4 *__restrict__ blocks, uint32_t format, const uint4 *__restrict__ overflow, uint64_t total,
+    const uint4 *__restrict__ table, uint32_t depth, uint32_t table_packed, const uint32_t *__restrict__ filter,
+    uint32_t filter_mask, const QuerySource src, uint32_t *__restrict__ flags) {
     constexpr int kLanes = kGroup;
     using Scratch = WaveScratchT<kWords>;
     using WorkItem = WorkItemT<kWords>;
@@ -204,7 +205,8 @@ __global__ __launch_bounds__(256, kWords == 6 ? 5 : 8) void k_count_kmers_tiled(
                 }
                 if (busy == 0ull) break;
                 if (have) {
-                    const Range r = constrain_split(blocks, w[0] & 7u, l, h, sub);
+                    const Range r = format == 0u ? constrain_split(blocks, w[0] & 7u, l, h, sub)
+                                                 : constrain_any(format, blocks, overflow, w[0] & 7u, l, h, sub);
                     l = r.l;
                     h = r.h;
                     consume_symbols<kWords>(w, 3);
@@ -227,8 +229,8 @@ __global__ __launch_bounds__(256, kWords == 6 ? 5 : 8) void k_count_kmers_tiled(
 // with x_0 the LAST symbol of the k-mer (the first one searched).  A group reads one parent
 // (level j-1, index p) and writes its four children p + c * 4^(j-1); child 0 overwrites the
 // parent only after the group has read it.
-__global__ __launch_bounds__(256) void k_table_level(const uint4 *__restrict__ blocks, uint4 *__restrict__ table,
-                                                     uint32_t level) {
+__global__ __launch_bounds__(256) void k_table_level(const uint4 *__restrict__ blocks, uint32_t format,
+                                                     const uint4 *__restrict__ overflow, uint4 *__restrict__ table, uint32_t level) {
     const uint32_t sub = threadIdx.x & (kGroup - 1);
     const uint64_t parents = 1ull << (2u * (level - 1u));
     const uint64_t ngroups = (uint64_t(gridDim.x) * blockDim.x) / kGroup;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256) void k_table_level(const uint4 *__restrict__ b
         Range mine{0, 0};  // lane c of the group keeps child c
         for (uint32_t c = 0; c < 4u; ++c) {
             const uint32_t s = c == 3u ? 5u : c + 1u;  // A C G T
-            const Range r = (l == h) ? Range{0, 0} : constrain(blocks, s, l, h, sub);
+            const Range r = (l == h) ? Range{0, 0} : constrain_any(format, blocks, overflow, s, l, h, sub);
             if (sub == c) mine = r;
         }
         if (sub < 4u)
@@ -328,7 +330,8 @@ __global__ void k_table_root(uint4 *table, uint64_t total) {
     if (threadIdx.x == 0 && blockIdx.x == 0) table[0] = make_uint4(0u, 0u, uint32_t(total), uint32_t(total >> 32));
 }
 
-__global__ __launch_bounds__(256) void k_constrain_ranges(const uint4 *__restrict__ blocks, uint64_t total,
+__global__ __launch_bounds__(256) void k_constrain_ranges(const uint4 *__restrict__ blocks, uint32_t format,
+                                                          const uint4 *__restrict__ overflow, uint64_t total,
                                                           const uint8_t *__restrict__ syms,
                                                           const uint64_t *__restrict__ l, const uint64_t *__restrict__ h,
                                                           uint64_t n, uint64_t *__restrict__ out_l,
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(256) void k_constrain_ranges(const uint4 *__restric
         if (err) {
             if (sub == 0) atomicOr(flags, err);
         } else {
-            r = constrain(blocks, s, li, hi, sub);
+            r = constrain_any(format, blocks, overflow, s, li, hi, sub);
         }
         if (sub == 0) {
             out_l[i] = r.l;
@@ -367,6 +370,7 @@ inline bool long_search(const IndexView &ix, uint32_t k) {
 }
 
 inline bool use_lanes_kernel(const IndexView &ix, uint32_t k) {
+    if (ix.block_format != kBlocksPlanes) return false;  // the lanes kernel reads plane and pair blocks
     return ix.search_kernel == kSearchLanes || (ix.search_kernel == kSearchAuto && long_search(ix, k));
 }
 
@@ -377,11 +381,12 @@ void launch_tiled(bool longk, dim3 grid, hipStream_t stream, const IndexView &ix
     const uint32_t depth = uint32_t(ix.table.depth);
     const uint32_t *filter = table ? ix.table.filter : nullptr;
     const uint32_t filter_mask = filter ? uint32_t((1ull << (2 * ix.table.filter_depth)) - 1ull) : 0u;
-    const uint32_t packed = ix.table.packed ? 1u : 0u;
+    const uint32_t packed = ix.table.packed ? 1u : 0u, format = uint32_t(ix.block_format);
+    const uint4 *overflow = static_cast<const uint4 *>(ix.overflow);
     if (longk)  // 33 <= k <= 64
-        hipLaunchKernelGGL((k_count_kmers_tiled<kReads, 6>), grid, dim3(256), 0, stream, blocks, ix.total, table, depth, packed, filter, filter_mask, src, flags);
+        hipLaunchKernelGGL((k_count_kmers_tiled<kReads, 6>), grid, dim3(256), 0, stream, blocks, format, overflow, ix.total, table, depth, packed, filter, filter_mask, src, flags);
     else
-        hipLaunchKernelGGL((k_count_kmers_tiled<kReads, 3>), grid, dim3(256), 0, stream, blocks, ix.total, table, depth, packed, filter, filter_mask, src, flags);
+        hipLaunchKernelGGL((k_count_kmers_tiled<kReads, 3>), grid, dim3(256), 0, stream, blocks, format, overflow, ix.total, table, depth, packed, filter, filter_mask, src, flags);
 }
 
 }  // namespace
@@ -401,8 +406,8 @@ hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_
         if (use_lanes_kernel(ix, k)) return launch_lanes(ix, src, false, true, flags, stream);
         launch_tiled<false>(k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, ix, src, flags);
     } else {
-        hipLaunchKernelGGL(k_count_kmers_generic, dim3(grid_for(n * kGroup)), dim3(256), 0, stream, blocks,
-                           ix.total, kmers, k, n, counts, flags);
+        hipLaunchKernelGGL(k_count_kmers_generic, dim3(grid_for(n * kGroup)), dim3(256), 0, stream, blocks, uint32_t(ix.block_format),
+                           static_cast<const uint4 *>(ix.overflow), ix.total, kmers, k, n, counts, flags);
     }
     return hipGetLastError();
 }
@@ -456,7 +461,8 @@ hipError_t launch_constrain_ranges(const IndexView &ix, const uint8_t *syms, con
                                    uint32_t *flags, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_constrain_ranges, dim3(grid_for(n * kGroup)), dim3(256), 0, stream,
-                       static_cast<const uint4 *>(ix.blocks), ix.total, syms, l, h, n, out_l, out_h, flags);
+                       static_cast<const uint4 *>(ix.blocks), uint32_t(ix.block_format), static_cast<const uint4 *>(ix.overflow), ix.total, syms,
+                       l, h, n, out_l, out_h, flags);
     return hipGetLastError();
 }
 
@@ -467,7 +473,8 @@ hipError_t launch_build_table(const IndexView &ix, int depth, void *entries, hip
     for (int level = 1; level <= depth; ++level) {
         const uint64_t parents = 1ull << (2 * (level - 1));
         hipLaunchKernelGGL(k_table_level, dim3(grid_for(parents * kGroup)), dim3(256), 0, stream,
-                           static_cast<const uint4 *>(ix.blocks), table, uint32_t(level));
+                           static_cast<const uint4 *>(ix.blocks), uint32_t(ix.block_format), static_cast<const uint4 *>(ix.overflow), table,
+                           uint32_t(level));
     }
     return hipGetLastError();
 }

@@ -27,8 +27,12 @@ struct TableView {
 // which count_kmers kernel serves 1 <= k <= 64 (kernels.hip / lanes.hip)
 constexpr int kSearchAuto = 0, kSearchGroups = 1, kSearchLanes = 2;
 
+constexpr int kBlocksPlanes = 0, kBlocksRuns = 1;  // IndexView::block_format
+
 struct IndexView {
-    const void *blocks;  // plane blocks, 128 B each
+    const void *blocks;  // plane blocks (256 positions) or run blocks (512 positions, run_index.hpp), 128 B each
+    int block_format = kBlocksPlanes;
+    const void *overflow = nullptr;  // run blocks: plane-shaped lines of the overflowing blocks
     uint64_t nblocks;
     uint64_t total;
     TableView table;

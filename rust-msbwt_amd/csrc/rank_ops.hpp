@@ -57,6 +57,87 @@ __device__ __forceinline__ Range constrain(const uint4 *__restrict__ blocks, uin
 }
 
 
+__device__ __forceinline__ uint32_t low_bits(int n) { return n >= 32 ? ~0u : ((1u << n) - 1u); }  // n in 0..32
+
+// ---- run blocks (run_index.hpp): the memory-lean block format -----------------------------------
+// start_index[s] + rank(s, pos) from pos's R512 block, by the 8 lanes of a group: lanes 0,1 hold the
+// header, lanes 2..7 decode 16 one-byte runs each; a prefix sum over the lanes gives every lane the
+// block offset of its first run, each lane clips its runs against the target offset and the group
+// sums the matches.  An OVERFLOW block ranks from two plane-shaped lines of the side array instead.
+constexpr uint32_t kRunOverflowFlag = 0x80000000u;
+
+// Both positions p0 <= p1 must lie in the same block when `both` is set; then .h is p1's bound.
+__device__ __forceinline__ Range rank_runs_group(const uint4 *__restrict__ blocks, const uint4 *__restrict__ overflow,
+                                                 uint32_t s, uint64_t p0, uint64_t p1, bool both, uint32_t sub) {
+    const uint32_t lane = threadIdx.x & 63u, group_base = lane & ~7u;
+    const int r0 = int(uint32_t(p0) & 511u), r1 = int(uint32_t(p1) & 511u);
+    const uint4 c = blocks[(p0 >> 9) * 8 + sub];
+    // header: A[s] low word in word s (lane s>>2, component s&3), high byte in word 6/7 (lane 1)
+    const uint32_t w0 = uint32_t(__shfl(int(s == 0u ? c.x : s == 1u ? c.y : s == 2u ? c.z : c.w), int(group_base)));
+    const uint32_t w1 = uint32_t(__shfl(int(s == 4u ? c.x : c.y), int(group_base + 1)));
+    const uint32_t lo = (s & 4u) ? w1 : w0;
+    const uint32_t hi03 = uint32_t(__shfl(int(c.z), int(group_base + 1))), hi45 = uint32_t(__shfl(int(c.w), int(group_base + 1)));
+    const uint32_t hi = (((s >> 2) ? hi45 : hi03) >> ((s & 3u) * 8u)) & 0xFFu;
+    uint32_t cnt = 0;  // matches before r0 in the low half, before r1 in the high half (each <= 512)
+    if (hi45 & kRunOverflowFlag) {  // group-uniform
+        const uint4 *two = overflow + uint64_t(uint32_t(__shfl(int(c.x), int(group_base + 2)))) * 16;
+        const uint32_t x0 = (s & 1u) ? 0u : ~0u, x1 = (s & 2u) ? 0u : ~0u, x2 = (s & 4u) ? 0u : ~0u;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const uint4 p = two[half * 8 + sub];
+            const uint32_t m = (p.x ^ x0) & (p.y ^ x1) & (p.z ^ x2);
+            const int first = half * 256 + int(sub) * 32;
+            cnt += uint32_t(__popc(m & low_bits(min(max(r0 - first, 0), 32))));
+            if (both) cnt += uint32_t(__popc(m & low_bits(min(max(r1 - first, 0), 32)))) << 16;
+        }
+    } else {
+        const uint32_t word[4] = {c.x, c.y, c.z, c.w};
+        uint32_t mine = 0;  // symbols my 16 runs cover (lanes 0,1: none)
+        if (sub >= 2u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mine = __builtin_amdgcn_sad_u8((word[j] >> 3) & 0x1F1F1F1Fu, 0u, mine);
+        }
+        uint32_t inc = mine;  // inclusive prefix over the 8 lanes
+        for (int d = 1; d < 8; d <<= 1) {
+            const uint32_t y = uint32_t(__shfl_up(int(inc), d, 8));
+            if (int(sub) >= d) inc += y;
+        }
+        int cur = int(inc - mine);
+        if (sub >= 2u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t run = (word[j] >> (8 * b)) & 0xFFu;
+                    const int len = int(run >> 3);
+                    if ((run & 7u) == s) {
+                        cnt += uint32_t(min(max(r0 - cur, 0), len));
+                        if (both) cnt += uint32_t(min(max(r1 - cur, 0), len)) << 16;
+                    }
+                    cur += len;
+                }
+            }
+        }
+    }
+    cnt = group_sum(cnt);
+    const uint64_t a = (uint64_t(hi) << 32) | lo;
+    Range out;
+    out.l = a + (cnt & 0xFFFFu);
+    out.h = a + (cnt >> 16);
+    return out;
+}
+
+// constrain() on whichever block format the index has (uniform per launch): 0 = plane blocks, 1 = run blocks
+__device__ __forceinline__ Range constrain_any(uint32_t format, const uint4 *__restrict__ blocks, const uint4 *__restrict__ overflow,
+                                               uint32_t s, uint64_t l, uint64_t h, uint32_t sub) {
+    if (format == 0u) return constrain(blocks, s, l, h, sub);
+    if ((l >> 9) == (h >> 9)) return rank_runs_group(blocks, overflow, s, l, h, true, sub);  // one line, one decode for both bounds
+    Range r;
+    r.l = rank_runs_group(blocks, overflow, s, l, l, false, sub).l;
+    r.h = rank_runs_group(blocks, overflow, s, h, h, false, sub).l;
+    return r;
+}
+
 // ---- pair blocks: two symbols per search step ------------------------------------------------
 // With S the BWT and S2[i] = S[LF(i)], two consecutive steps (first a, then b) collapse into
 //     p'' = K[a][b] + occ2(a, b, p),   K[a][b] = C[b] + occ(b, C[a]),
@@ -80,8 +161,6 @@ constexpr int kPairValidChunk = 4, kPairLoChunk = 5, kPairHiChunk = 7;
 __device__ __forceinline__ uint32_t acgt_code(uint32_t s) { return s - 1u - (s >> 2); }  // s in {1,2,3,5}
 __device__ __forceinline__ uint32_t acgt_bit(uint32_t s) { return (0x2Eu >> (s & 7u)) & 1u; }
 __device__ __forceinline__ bool is_acgt(uint32_t s) { return acgt_bit(s) != 0u; }
-
-__device__ __forceinline__ uint32_t low_bits(int n) { return n >= 32 ? ~0u : ((1u << n) - 1u); }  // n in 0..32
 
 // ---- 8-lane groups, one bound per quad (the search loop of kernels.hip) ---------------------------
 // Lanes 0-3 of the group work on bound l, lanes 4-7 on bound h; lane q of a quad holds chunks q

@@ -242,6 +242,17 @@ class RleBWT(BWT):
     def get_pair_index(self):
         return bool(_lib.lib().msbwt_rle_get_pair_index(self._h))
 
+    BLOCK_FORMATS = {"planes": 0, "runs": 1}
+
+    def set_block_format(self, fmt):
+        """"planes" (default) or "runs" (memory-lean run blocks, no pair index); takes effect at the next load."""
+        rc = _lib.lib().msbwt_rle_set_block_format(self._h, self.BLOCK_FORMATS.get(fmt, fmt))
+        if rc:
+            _raise(rc, self._h)
+
+    def get_block_format(self):
+        return {v: k for k, v in self.BLOCK_FORMATS.items()}[int(_lib.lib().msbwt_rle_get_block_format(self._h))]
+
     SEARCH_KERNELS = {"auto": 0, "groups": 1, "lanes": 2}
 
     def set_search_kernel(self, mode):

@@ -14,13 +14,20 @@ from rle_random import random_kmers, random_stream, raw_byte_stream, runs_to_byt
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["auto", "groups", "lanes"])
+@pytest.fixture(autouse=True, params=["auto", "groups", "lanes", "runs"])
 def search_kernel(request, monkeypatch):
-    """Every test of this file runs three times: with the automatic choice of count_kmers kernel,
-    with the 8-lanes-per-query kernel forced and with the one-query-per-lane (LDS-staged) kernel
-    forced -- a handle reads MSBWT_SEARCH when it is created."""
-    monkeypatch.setenv("MSBWT_SEARCH", request.param)
+    """Every test of this file runs four times: with the automatic choice of count_kmers kernel,
+    with the 8-lanes-per-query kernel forced, with the one-query-per-lane (LDS-staged) kernel
+    forced, and on the run-block index format (MSBWT_BLOCKS=runs: no plane blocks, no pair index)
+    -- a handle reads MSBWT_SEARCH / MSBWT_BLOCKS when it is created."""
+    monkeypatch.setenv("MSBWT_SEARCH", "auto" if request.param == "runs" else request.param)
+    monkeypatch.setenv("MSBWT_BLOCKS", "runs" if request.param == "runs" else "planes")
     return request.param
+
+
+def needs_plane_blocks(mode):
+    if mode == "runs":
+        pytest.skip("pair index / packed table / block download exist on plane blocks only")
 
 CODES = {"$": 0, "A": 1, "C": 2, "G": 3, "N": 4, "T": 5}
 
@@ -351,8 +358,9 @@ def _host_blocks(rle):
 
 
 @pytest.mark.parametrize("case", ["ones", "short", "long", "mixed", "raw", "edges", "big_short"])
-def test_device_built_index_equals_host_built(case):
+def test_device_built_index_equals_host_built(case, search_kernel):
     """The device-side builder (scan + atomic paint) against the host builder, word for word."""
+    needs_plane_blocks(search_kernel)
     if case == "raw":
         streams = [raw_byte_stream(s, 500) for s in range(4)]
     elif case == "edges":
@@ -460,7 +468,7 @@ def test_pair_index_never_changes_results(pair, depth):
     b = gpu_bwt(rle)
     b.set_table_depth(depth)
     b.set_pair_index(pair)
-    assert b.get_pair_index() == bool(pair)
+    assert b.get_pair_index() == (bool(pair) and b.get_block_format() == "planes")
     rng = np.random.default_rng(depth * 2 + pair)
     for k in (1, 2, 3, 4, 9, 10, 20, 21, 31, 32, 33, 48, 59, 64):
         qs = [orc.convert_stoi(r[p:p + k]) for r in reads if len(r) >= k for p in (int(rng.integers(0, len(r) - k + 1)),)]
@@ -494,9 +502,10 @@ def test_pair_index_on_random_streams_and_superblock_borders():
 
 
 @pytest.mark.parametrize("flat_depth", [1, 3, 6])
-def test_packed_table_never_changes_results(flat_depth):
+def test_packed_table_never_changes_results(flat_depth, search_kernel):
     """The packed suffix table (two levels deeper than the flat one, 30 entries per 128-byte line,
     16-bit deltas) on a true BWT: present and absent k-mers around the effective depth."""
+    needs_plane_blocks(search_kernel)
     reads, rle = _real_bwt(12 + flat_depth, 220, 75)
     o = orc.OracleRleBWT()
     o.load_vector(rle)
@@ -524,9 +533,10 @@ def test_packed_table_never_changes_results(flat_depth):
     assert np.array_equal(b.count_kmers(qs), exp)
 
 
-def test_packed_table_escape_lines_on_long_run_streams():
+def test_packed_table_escape_lines_on_long_run_streams(search_kernel):
     """Arbitrary symbol streams with runs of up to 10^5: ranges far wider than 16 bits, so most packed
     lines are ESCAPE lines and their queries must search from scratch -- same counts."""
+    needs_plane_blocks(search_kernel)
     for seed, kind in ((51, "long"), (52, "mixed"), (53, "short")):
         rle = random_stream(seed, 30_000, kind)
         o = orc.OracleRleBWT()
@@ -595,7 +605,8 @@ def test_concurrent_queries_from_host_threads():
         assert np.array_equal(got[i], exp[i])
 
 
-def test_introspection():
+def test_introspection(search_kernel):
+    needs_plane_blocks(search_kernel)
     rle = random_stream(2, 30000, "short")
     b = gpu_bwt(rle)
     blocks = b.get_total_size() // 256 + 1
@@ -687,3 +698,30 @@ def test_replicas_and_sharded_batches_match_a_single_handle():
     with pytest.raises(msbwt.MsbwtError) as err:
         rle_bwt.count_kmers_multi(replicas, bad)
     assert err.value.code == msbwt._lib.ERR_INVALID_SYMBOL
+
+
+def test_run_block_format_is_selectable_and_lean():
+    """msbwt_rle_set_block_format: the same handle loads the same stream as plane blocks and as run
+    blocks; identical answers, about 0.3 instead of 0.5 bytes per symbol, no pair index in run mode."""
+    import synth
+    rle, total = synth.rle_stream(30_000_000, 6.0, 5)
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    q1, q2 = random_kmers(3, 20000, 25), random_kmers(4, 3000, 9, alphabet=(0, 1, 2, 3, 4, 5))
+    exp = o.count_kmers(q1), o.count_kmers(q2)
+    sizes = {}
+    for fmt in ("planes", "runs"):
+        b = RleBWT()
+        b.set_block_format(fmt)
+        b.set_table_depth(0)
+        b.set_pair_index(0)
+        b.load_vector(rle)
+        assert b.get_block_format() == fmt and b.get_total_size() == total
+        sizes[fmt] = b.device_bytes()
+        assert np.array_equal(b.count_kmers(q1), exp[0])
+        assert np.array_equal(b.count_kmers(q2), exp[1])
+        b.set_table_depth(6)
+        b.set_pair_index(1)
+        assert b.get_pair_index() == (fmt == "planes")
+        assert np.array_equal(b.count_kmers(q1), exp[0])
+    assert 0.25 * total < sizes["runs"] < 0.36 * total and 0.49 * total < sizes["planes"] < 0.51 * total

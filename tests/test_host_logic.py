@@ -156,3 +156,51 @@ def test_default_bench_has_a_fresh_pmc_traffic_entry():
     assert e["bwt_symbols"] == int(bench.HUMAN_SYMBOLS) and e["query_kind"] == "walk"
     assert os.path.exists(os.path.join(ROOT, e["source"]))
     assert 0 < e["traffic_bytes_per_query"] < 31 * 2 * 184  # far below the reference algorithm's worst case
+
+
+@pytest.mark.parametrize("kind", ["ones", "short", "long", "mixed", "raw"])
+def test_run_blocks_decode_back_to_the_bwt(kind):
+    """The host builder of the run-block format (csrc/run_index.cpp; no GPU needed): decoding the 96
+    one-byte runs (or the plane-shaped overflow lines) of every block gives the BWT back, and every
+    header equals start_index + symbol counts before the block."""
+    nruns = {"ones": 3000, "short": 3000, "long": 40, "mixed": 150, "raw": 2500}[kind]
+    rle = np.ascontiguousarray(raw_byte_stream(5, nruns) if kind == "raw" else random_stream(7, nruns, kind))
+    sym = orc.decompress(rle)
+    total = len(sym)
+    assert total < 20_000_000
+    L = msbwt._lib.lib()
+    tot, nover = C.c_uint64(), C.c_uint64()
+    nblocks = L.msbwt_build_run_blocks(rle.ctypes.data_as(C.c_void_p), rle.size, None, 0, None, 0, C.byref(tot), C.byref(nover))
+    assert nblocks == total // 512 + 1 and tot.value == total
+    blocks = np.zeros((nblocks, 32), dtype=np.uint32)
+    over = np.zeros((max(nover.value, 1), 2, 8, 4), dtype=np.uint32)
+    assert L.msbwt_build_run_blocks(rle.ctypes.data_as(C.c_void_p), rle.size, blocks.ctypes.data_as(C.c_void_p), nblocks,
+                                    over.ctypes.data_as(C.c_void_p), nover.value, C.byref(tot), C.byref(nover)) == nblocks
+    counts = np.bincount(sym, minlength=6)
+    start = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64)
+    # headers, vectorised: A[s] of block b = start[s] + #s before 512 b
+    onehot = (sym[:, None] == np.arange(6, dtype=np.uint8)[None, :])
+    before = np.concatenate([np.zeros((1, 6), dtype=np.uint64), np.cumsum(onehot, axis=0, dtype=np.uint64)])[np.minimum(np.arange(nblocks) * 512, total)]
+    want_a = before + start[None, :]
+    lo = blocks[:, :6].astype(np.uint64)
+    hi = np.stack([(blocks[:, 6] >> (8 * s)) & 0xFF for s in range(4)] + [(blocks[:, 7] >> (8 * s)) & 0xFF for s in range(2)], axis=1).astype(np.uint64)
+    assert np.array_equal((hi << np.uint64(32)) | lo, want_a)
+    is_over = (blocks[:, 7] & np.uint32(0x80000000)) != 0
+    assert int(is_over.sum()) == nover.value
+    # payloads: every overflow block, and a sample of the ordinary ones (all of them when there are few)
+    check = np.arange(nblocks) if nblocks <= 3000 else np.unique(np.concatenate([np.flatnonzero(is_over)[:300], np.random.default_rng(1).integers(0, nblocks, 2000), [0, nblocks - 1]]))
+    for b in check:
+        w = blocks[b]
+        want = sym[512 * b:512 * b + 512]
+        if is_over[b]:
+            o = over[int(w[8])]
+            i = np.arange(len(want))
+            words = o[i >> 8, (i & 255) >> 5]                      # (len, 4)
+            got = (((words[:, 0] >> (i & 31)) & 1) | (((words[:, 1] >> (i & 31)) & 1) << 1) | (((words[:, 2] >> (i & 31)) & 1) << 2)).astype(np.uint8)
+        else:
+            runs = w[8:].view(np.uint8)
+            got = np.repeat(runs & 7, runs >> 3).astype(np.uint8)
+            assert (runs >> 3).max(initial=0) <= 31
+        assert np.array_equal(got, want), b
+    if kind == "ones":
+        assert nover.value > 0      # run length 1: 512 pieces per block, every full block overflows
