@@ -258,7 +258,8 @@ int rebuild_table(msbwt_rle *h) {
     if (h->wanted_table_packed < 0) {
         size_t free_b = 0, total_b = 0;
         if (h->wanted_table_depth >= 0 ||  // an explicit depth is taken literally
-            (uint64_t(1) << (2 * (depth + 2))) > 8 * h->totals.total ||  // most entries would be empty hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
+            (uint64_t(1) << (2 * (depth + 2))) > 8 * h->totals.total ||  // most entries would be empty
+            hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
             2 * pbytes > uint64_t(free_b) + bytes)
             return MSBWT_OK;
     }
