@@ -528,7 +528,7 @@ def main():
             for ent in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["entries"]:
                 same = (ent["workload"] == args.workload and ent["k"] == k and ent["table_depth"] == bwt.get_table_depth()
                         and ent.get("pair_index", False) == bwt.get_pair_index() and ent.get("query_kind", cfg["queries"]) == kind
-                        and ent.get("bwt_symbols", total) == total and args.scale == 1.0 and not fused)
+                        and ent.get("bwt_symbols", total) == total and args.scale == 1.0 and bool(ent.get("fused", False)) == bool(fused))
                 if same and ent.get("kernel_stamp") != stamp:
                     traffic_note = "stale: %s was taken with kernel sources %s, the tree has %s" % (ent["source"], ent.get("kernel_stamp"), stamp)
                 elif same:
