@@ -177,6 +177,14 @@ int msbwt_rle_get_presence_filter(const msbwt_rle *bwt);
  * (default; MSBWT_PAIR_INDEX=0/1 in the environment overrides).  Results never change. */
 int msbwt_rle_set_pair_index(msbwt_rle *bwt, int mode);
 int msbwt_rle_get_pair_index(const msbwt_rle *bwt);
+/* Spacing of the pair blocks: 128 = disjoint blocks (1 byte per symbol); 96 = overlapping blocks that
+ * also hold the first 32 positions of their successor (1.33 bytes per symbol), so that a range up to
+ * 32 wide is ranked from ONE line -- on real 30x data ranges stay ~25 wide to the last step and every
+ * fifth step would otherwise fetch a second line.  0 = automatic (default: 96 when that takes at most a
+ * quarter of the free HBM; MSBWT_PAIR_STRIDE=96|128 overrides).  get returns 0 without a pair index.
+ * Results never change. */
+int msbwt_rle_set_pair_stride(msbwt_rle *bwt, int stride);
+int msbwt_rle_get_pair_stride(const msbwt_rle *bwt);
 /* Block format of the index, chosen BEFORE a load (MSBWT_BLOCKS=runs in the environment sets the
  * initial choice): 0 = bit-plane blocks (default: 0.5 byte per symbol, fastest, the only format the
  * pair index and the lane-per-query kernel work on), 1 = run blocks -- the layout of the reference's

@@ -38,6 +38,8 @@ struct msbwt_rle {
     void *d_pair_super = nullptr;
     uint64_t pair_bytes = 0;
     int wanted_pair = -1;           // -1 = on when it fits comfortably, 0 = off, 1 = on
+    int pair_stride = 128;          // spacing of the pair blocks in HBM: 128, or 96 (overlapping)
+    int wanted_pair_stride = 0;     // 0 = overlapping when that takes at most a quarter of the free HBM
     void *d_table = nullptr;
     int table_depth = 0;         // symbols a table entry stands for (of the table currently in HBM)
     bool table_packed = false;   // packed lines (two levels deeper than the flat table it was made from)
@@ -149,6 +151,7 @@ IndexView view_of(msbwt_rle *h) {
     v.table.filter_depth = h->filter_depth;
     v.pair_blocks = h->d_pair_blocks;
     v.pair_super = static_cast<const uint64_t *>(h->d_pair_super);
+    v.pair_stride96 = h->d_pair_blocks && h->pair_stride == 96;
     v.search_kernel = h->search_kernel;
     v.debug = h->d_flags ? reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(h->d_flags) + 64) : nullptr;
     // one ticket counter per launch, round robin over 64: launches on one stream are ordered anyway, and 64
@@ -290,16 +293,25 @@ int rebuild_pair_index(msbwt_rle *h) {
     h->d_pair_blocks = h->d_pair_super = nullptr;
     h->pair_bytes = 0;
     if (h->wanted_pair == 0 || h->totals.total == 0 || h->block_format != kBlocksPlanes) return MSBWT_OK;  // built from plane blocks
-    const PairIndexSizes sz = pair_index_sizes(h->nblocks);
+    // Overlapping blocks (stride 96, 1.33 bytes per symbol) rank ranges up to 32 wide from one line:
+    // taken when they are cheap in HBM (a quarter of what is free), e.g. C3 / C4-sized indexes; a
+    // human-scale index keeps stride 128 (90 GB instead of 120 GB).
+    size_t free_b = 0, total_b = 0;
+    const bool know_free = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    int stride = h->wanted_pair_stride;
+    if (stride != 96 && stride != 128) {
+        const PairIndexSizes wide = pair_index_sizes(h->nblocks, 96);
+        stride = (know_free && wide.pair_block_bytes + wide.scratch_bytes <= free_b / 4) ? 96 : 128;
+    }
+    const PairIndexSizes sz = pair_index_sizes(h->nblocks, stride);
     if (h->wanted_pair < 0) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || sz.pair_block_bytes + sz.scratch_bytes > free_b / 2) return MSBWT_OK;
+        if (!know_free || sz.pair_block_bytes + sz.scratch_bytes > free_b / 2) return MSBWT_OK;
     }
     void *scratch = nullptr;
     hipError_t e = hipMalloc(&h->d_pair_blocks, sz.pair_block_bytes);
     if (e == hipSuccess) e = hipMalloc(&h->d_pair_super, sz.super_bytes);
     if (e == hipSuccess) e = hipMalloc(&scratch, sz.scratch_bytes);
-    if (e == hipSuccess) e = build_pair_index(h->d_blocks, h->nblocks, h->totals.start_index, h->d_pair_blocks, h->d_pair_super, scratch, h->stream);
+    if (e == hipSuccess) e = build_pair_index(h->d_blocks, h->nblocks, h->totals.start_index, h->d_pair_blocks, h->d_pair_super, scratch, h->stream, stride);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (scratch) (void)hipFree(scratch);
     if (e != hipSuccess) {
@@ -309,6 +321,7 @@ int rebuild_pair_index(msbwt_rle *h) {
         if (h->wanted_pair < 0 && e == hipErrorOutOfMemory) return MSBWT_OK;  // optional structure
         return hip_fail(h, e, "build pair index");
     }
+    h->pair_stride = stride;
     h->pair_bytes = sz.pair_block_bytes + sz.super_bytes;
     return MSBWT_OK;
 }
@@ -502,6 +515,7 @@ msbwt_rle *msbwt_rle_new_on_device(uint8_t bin_power, int device) {
     if (const char *env = std::getenv("MSBWT_TABLE_DEPTH")) h->wanted_table_depth = std::atoi(env);
     if (const char *env = std::getenv("MSBWT_TABLE_PACKED")) h->wanted_table_packed = std::atoi(env) ? 1 : 0;
     if (const char *env = std::getenv("MSBWT_PAIR_INDEX")) h->wanted_pair = std::atoi(env) ? 1 : 0;
+    if (const char *env = std::getenv("MSBWT_PAIR_STRIDE")) h->wanted_pair_stride = std::atoi(env);
     if (const char *env = std::getenv("MSBWT_FILTER")) h->wanted_filter = std::atoi(env) ? -1 : 0;
     if (const char *env = std::getenv("MSBWT_BLOCKS")) h->wanted_block_format = std::strcmp(env, "runs") == 0 ? kBlocksRuns : kBlocksPlanes;
     if (const char *env = std::getenv("MSBWT_SEARCH"))
@@ -795,6 +809,8 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
     h->wanted_block_format = src->wanted_block_format;
     h->block_format = src->block_format;
     h->wanted_pair = src->wanted_pair;
+    h->wanted_pair_stride = src->wanted_pair_stride;
+    h->pair_stride = src->pair_stride;
     h->wanted_filter = src->wanted_filter;
     h->search_kernel = src->search_kernel;
     auto give_up = [&](hipError_t e, const char *what) -> msbwt_rle * {
@@ -816,7 +832,7 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
             if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
         }
     }
-    const PairIndexSizes psz = pair_index_sizes(src->nblocks);
+    const PairIndexSizes psz = pair_index_sizes(src->nblocks, src->pair_stride);
     struct Piece { void *const *from; void **to; size_t bytes; };
     const Piece pieces[] = {
         {&src->d_blocks, &h->d_blocks, size_t(src->nblocks) * kBlockBytes},
@@ -979,6 +995,19 @@ int msbwt_rle_set_pair_index(msbwt_rle *h, int mode) {
 }
 
 int msbwt_rle_get_pair_index(const msbwt_rle *h) { return (h && h->d_pair_blocks) ? 1 : 0; }
+
+int msbwt_rle_set_pair_stride(msbwt_rle *h, int stride) {
+    if (!h || (stride != 0 && stride != 96 && stride != 128)) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->wanted_pair_stride = stride;
+    if (!h->loaded) return MSBWT_OK;
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    const int rc = rebuild_pair_index(h);
+    return rc ? rc : rebuild_table(h);
+}
+
+int msbwt_rle_get_pair_stride(const msbwt_rle *h) { return (h && h->d_pair_blocks) ? h->pair_stride : 0; }
 
 int msbwt_rle_set_presence_filter(msbwt_rle *h, int mode) {
     if (!h || mode < -1 || mode > 1) return MSBWT_ERR_INVALID_ARG;

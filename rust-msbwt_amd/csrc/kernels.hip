@@ -265,15 +265,16 @@ __global__ __launch_bounds__(256) void k_table_filter(const uint4 *__restrict__ 
 // ---- packed table: two more levels in the HBM of one -------------------------------------------
 // occ2(a, b, pos) + K[a][b] by ONE thread straight from global memory (pair block layout: rank_ops.hpp)
 __device__ __forceinline__ uint64_t pair_bound_thread(const uint4 *__restrict__ pair_blocks, const uint64_t *__restrict__ pair_super,
-                                                      uint32_t a2, uint32_t b2, uint64_t pos) {
-    const uint4 *blk = pair_blocks + (pos >> kPairShift) * 8;
+                                                      bool stride96, uint32_t a2, uint32_t b2, uint64_t pos) {
+    const uint64_t pb = pair_block_of(pos, stride96);
+    const uint4 *blk = pair_blocks + pb * 8;
     const uint4 a0 = blk[0], a1 = blk[1], b0 = blk[2], b1 = blk[3], v = blk[kPairValidChunk];
     const uint32_t na0 = (a2 & 1u) - 1u, na1 = ((a2 >> 1) & 1u) - 1u, nb0 = (b2 & 1u) - 1u, nb1 = ((b2 >> 1) & 1u) - 1u;
     const uint32_t m0 = (a0.x ^ na0) & (a1.x ^ na1) & (b0.x ^ nb0) & (b1.x ^ nb1) & v.x;
     const uint32_t m1 = (a0.y ^ na0) & (a1.y ^ na1) & (b0.y ^ nb0) & (b1.y ^ nb1) & v.y;
     const uint32_t m2 = (a0.z ^ na0) & (a1.z ^ na1) & (b0.z ^ nb0) & (b1.z ^ nb1) & v.z;
     const uint32_t m3 = (a0.w ^ na0) & (a1.w ^ na1) & (b0.w ^ nb0) & (b1.w ^ nb1) & v.w;
-    const uint32_t r = uint32_t(pos) & 127u, p = a2 * 4u + b2;
+    const uint32_t r = uint32_t(pos - pair_block_start(pb, stride96)), p = a2 * 4u + b2;
     const uint64_t t = (1ull << (r & 63u)) - 1ull;
     const bool upper = r >= 64u;
     const uint64_t lo = upper ? ~0ull : t, hi = upper ? t : 0ull;
@@ -281,14 +282,14 @@ __device__ __forceinline__ uint64_t pair_bound_thread(const uint4 *__restrict__ 
                          uint32_t(__popc(m2 & uint32_t(hi))) + uint32_t(__popc(m3 & uint32_t(hi >> 32)));
     const uint32_t field = uint32_t(reinterpret_cast<const uint16_t *>(blk + kPairLoChunk)[p]) |
                            (uint32_t(reinterpret_cast<const uint8_t *>(blk + kPairHiChunk)[p]) << 16);
-    return pair_super[(pos >> kPairSuperShift) * 16u + p] + field + cnt;
+    return pair_super[(pb >> kPairSuperBlocks) * 16u + p] + field + cnt;
 }
 
 // One half-wave (32 lanes) writes one packed line: lane i < 30 extends flat entry
 // (t mod 4^flat_depth) by the two symbols in t's top four bits, t = 30 line + i.
 __global__ __launch_bounds__(256) void k_table_pack(const uint4 *__restrict__ flat, uint32_t flat_depth,
                                                     const uint4 *__restrict__ pair_blocks, const uint64_t *__restrict__ pair_super,
-                                                    uint32_t *__restrict__ packed, uint64_t nlines) {
+                                                    uint32_t stride96, uint32_t *__restrict__ packed, uint64_t nlines) {
     const uint32_t lane = threadIdx.x & 63u, i = lane & 31u, team_first = lane & 32u;
     const uint64_t entries = 1ull << (2u * (flat_depth + 2u)), parent_mask = (1ull << (2u * flat_depth)) - 1ull;
     const uint64_t nteams = (uint64_t(gridDim.x) * blockDim.x) / 32;
@@ -302,8 +303,8 @@ __global__ __launch_bounds__(256) void k_table_pack(const uint4 *__restrict__ fl
             h = (uint64_t(e.w) << 32) | e.z;
             if (l != h) {
                 const uint32_t a2 = uint32_t(t >> (2u * flat_depth)) & 3u, b2 = uint32_t(t >> (2u * flat_depth + 2u)) & 3u;
-                l = pair_bound_thread(pair_blocks, pair_super, a2, b2, l);
-                h = pair_bound_thread(pair_blocks, pair_super, a2, b2, h);
+                l = pair_bound_thread(pair_blocks, pair_super, stride96 != 0u, a2, b2, l);
+                h = pair_bound_thread(pair_blocks, pair_super, stride96 != 0u, a2, b2, h);
             }
         }
         const bool nonempty = valid && l != h;
@@ -484,7 +485,7 @@ hipError_t launch_pack_table(const IndexView &ix, int flat_depth, const void *fl
     if (flat_depth < 1 || flat_depth > 16 || !ix.pair_blocks || !ix.pair_super) return hipErrorInvalidValue;
     const uint64_t nlines = packed_table_bytes(flat_depth + 2) / 128;
     hipLaunchKernelGGL(k_table_pack, dim3(grid_for(nlines * 32)), dim3(256), 0, stream, static_cast<const uint4 *>(flat_entries),
-                       uint32_t(flat_depth), static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super,
+                       uint32_t(flat_depth), static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, ix.pair_stride96 ? 1u : 0u,
                        static_cast<uint32_t *>(packed_entries), nlines);
     return hipGetLastError();
 }

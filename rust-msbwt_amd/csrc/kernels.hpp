@@ -38,6 +38,7 @@ struct IndexView {
     TableView table;
     const void *pair_blocks = nullptr;      // optional: two symbols per step (rank_ops.hpp)
     const uint64_t *pair_super = nullptr;
+    bool pair_stride96 = false;             // pair blocks overlap (start every 96 positions)
     int search_kernel = kSearchAuto;
     uint64_t *debug = nullptr;  // 8 words: [0] != 0 once a consistency check has recorded its values in [1..]
     void *tile_counter = nullptr;  // u64 ticket counter of the lanes kernel's dynamic tile scheduling (zeroed per launch)

@@ -132,8 +132,8 @@ __device__ __forceinline__ uint32_t pair_line_count(const PairLine &L, uint32_t 
            uint32_t(__popc(L.m[2] & uint32_t(hi))) + uint32_t(__popc(L.m[3] & uint32_t(hi >> 32)));
 }
 
-__device__ __forceinline__ uint64_t pair_line_bound(const PairLine &L, uint64_t super_base, uint64_t pos) {
-    return super_base + L.field + pair_line_count(L, uint32_t(pos) & 127u);
+__device__ __forceinline__ uint64_t pair_line_bound(const PairLine &L, uint64_t super_base, uint32_t r) {  // r = position - block start
+    return super_base + L.field + pair_line_count(L, r);
 }
 
 template <bool kReads, bool kPair, int kWords>
@@ -141,7 +141,8 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
                                                           const uint4 *__restrict__ table, uint32_t depth, uint32_t table_packed,
                                                           const uint32_t *__restrict__ filter, uint32_t filter_mask,
                                                           const uint4 *__restrict__ pair_blocks,
-                                                          const uint64_t *__restrict__ pair_super, const QuerySource src,
+                                                          const uint64_t *__restrict__ pair_super, uint32_t pair_stride96,
+                                                          const QuerySource src,
                                                           uint32_t *__restrict__ flags, uint64_t *__restrict__ debug,
                                                           unsigned long long *__restrict__ tile_counter, uint32_t grain) {
     using Scratch = LaneScratchT<kWords>;
@@ -356,10 +357,16 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
         const uint32_t s1 = w[0] & 7u, s2 = (w[0] >> 3) & 7u;
         const bool pair = kPair && have && rem >= 2u && (acgt_bit(s1) & acgt_bit(s2)) != 0u;
         const uint32_t a2 = acgt_code(s1) & 3u, b2 = acgt_code(s2) & 3u;
-        const uint32_t shift = pair ? uint32_t(kPairShift) : 8u;
+        const bool s96 = pair_stride96 != 0u;
         const uint64_t base = pair ? reinterpret_cast<uint64_t>(pair_blocks) : reinterpret_cast<uint64_t>(blocks);
-        const uint64_t bl = l >> shift, bh = h >> shift;
-        const bool second = have && bh != bl;
+        // the block of l -- and h's own block only when h does not fit the same line (overlapping pair
+        // blocks hold 32 positions beyond their own 96)
+        const uint64_t bl = pair ? pair_block_of(l, s96) : l >> 8;
+        const uint64_t start_l = pair ? pair_block_start(bl, s96) : bl << 8;
+        const bool same = pair ? (h - start_l) < 128u : (h >> 8) == bl;
+        const uint64_t bh = same ? bl : (pair ? pair_block_of(h, s96) : h >> 8);
+        const uint32_t r_l = uint32_t(l - start_l), r_h = uint32_t(h - (same ? start_l : (pair ? pair_block_start(bh, s96) : bh << 8)));
+        const bool second = have && !same;
         const uint64_t second_mask = __ballot(second);
         const uint32_t second_rank = __builtin_amdgcn_mbcnt_hi(uint32_t(second_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(second_mask), 0u));
         const uint32_t nsecond = min(uint32_t(__popcll(second_mask)), kMaxSecond);
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
             // one 8-byte load per lane is a separate L2 request each (64 per wave): fetch the second
             // bound's base only in the rare case that it lies in another superblock
             const uint32_t p = a2 * 4u + b2;
-            const uint64_t sbl = l >> kPairSuperShift, sbh = h >> kPairSuperShift;
+            const uint64_t sbl = bl >> kPairSuperBlocks, sbh = bh >> kPairSuperBlocks;
             super_l = pair_super[sbl * 16u + p];
             super_h = super_l;
             if (sbh != sbl) super_h = pair_super[sbh * 16u + p];
@@ -401,9 +408,9 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
             if (pair) {
                 PairLine L;
                 read_pair_line(ws.lines, slot_l, a2, b2, L);
-                nl = pair_line_bound(L, super_l, l);
+                nl = pair_line_bound(L, super_l, r_l);
                 if (second) read_pair_line(ws.lines, slot_h, a2, b2, L);
-                nh = pair_line_bound(L, super_h, h);
+                nh = pair_line_bound(L, super_h, r_h);
                 consume_symbols<kWords>(w, 6);
                 rem -= 2u;
             } else {
@@ -469,7 +476,7 @@ hipError_t launch_variant(hipStream_t stream, const IndexView &ix, const QuerySo
     const uint32_t grain = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(16, tiles / (waves * 8))));
     hipLaunchKernelGGL((k_count_kmers_lanes<kReads, kPair, kWords>), dim3(uint32_t(waves)), dim3(64), 0, stream,
                        static_cast<const uint4 *>(ix.blocks), ix.total, table, uint32_t(ix.table.depth), ix.table.packed ? 1u : 0u, filter, filter_mask,
-                       static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags, ix.debug,
+                       static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, ix.pair_stride96 ? 1u : 0u, src, flags, ix.debug,
                        static_cast<unsigned long long *>(ix.tile_counter), grain);
     return hipGetLastError();
 }

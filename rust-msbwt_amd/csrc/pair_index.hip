@@ -18,7 +18,7 @@
 namespace msbwt {
 namespace {
 
-constexpr int kTilePairBlocks = 1024;  // pair blocks per tile (131072 positions); 128 tiles = one superblock
+constexpr int kTilePairBlocks = 1024;  // pair blocks per tile; 128 tiles = one superblock (2^17 blocks)
 constexpr int kThreads = 256;
 constexpr int kBlocksPerThread = kTilePairBlocks / kThreads;  // 4
 
@@ -49,7 +49,8 @@ __device__ __forceinline__ uint32_t group_exclusive_scan(uint32_t x, uint32_t su
     return inc - x;
 }
 
-__global__ __launch_bounds__(256) void k_pair_paint(const uint4 *__restrict__ blocks, uint64_t nblocks, uint4 *__restrict__ pair_blocks) {
+__global__ __launch_bounds__(256) void k_pair_paint(const uint4 *__restrict__ blocks, uint64_t nblocks, uint4 *__restrict__ pair_blocks,
+                                                    uint32_t stride96) {
     const uint32_t sub = threadIdx.x & 7u;
     const uint32_t lane = threadIdx.x & 63u, group_base = lane & ~7u;
     const uint64_t ngroups = (uint64_t(gridDim.x) * blockDim.x) / 8;
@@ -90,24 +91,39 @@ __global__ __launch_bounds__(256) void k_pair_paint(const uint4 *__restrict__ bl
                 ++target;
             }
         }
-        // my 32 positions are word (sub & 3) of every plane of pair block 2b + (sub >> 2)
-        uint32_t *out = reinterpret_cast<uint32_t *>(pair_blocks + (2 * b + (sub >> 2)) * 8) + (sub & 3u);
+        // my 32 positions are 32-position word W = 8 b + sub of the BWT.  stride 128: word W & 3 of pair
+        // block W >> 2.  stride 96: word W % 3 of block W / 3 -- and, when that is word 0, also word 3 of
+        // the block before (its look-ahead).
+        const uint64_t W = b * 8 + sub;
+        const uint64_t pb = stride96 ? W / 3u : W >> 2;
+        const uint32_t slot = stride96 ? uint32_t(W - pb * 3u) : uint32_t(W & 3u);
+        uint32_t *out = reinterpret_cast<uint32_t *>(pair_blocks + pb * 8) + slot;
         out[0] = a0;
         out[4] = a1;
         out[8] = b0;
         out[12] = b1;
         out[16] = valid;
+        if (stride96 && slot == 0u && pb > 0) {
+            uint32_t *prev = reinterpret_cast<uint32_t *>(pair_blocks + (pb - 1) * 8) + 3;
+            prev[0] = a0;
+            prev[4] = a1;
+            prev[8] = b0;
+            prev[12] = b1;
+            prev[16] = valid;
+        }
     }
 }
 
-// the 16 pair counts of one pair block, added into acc[]
-__device__ __forceinline__ void add_block_pair_counts(const uint4 *__restrict__ blk, uint32_t acc[16]) {
+// the 16 pair counts of one pair block's OWN positions (its first `words` 32-position words: 4, or 3
+// when blocks overlap), added into acc[]
+__device__ __forceinline__ void add_block_pair_counts(const uint4 *__restrict__ blk, uint32_t acc[16], int words) {
     const uint4 a0 = blk[0], a1 = blk[1], b0 = blk[2], b1 = blk[3], v = blk[kPairValidChunk];
     const uint32_t A0[4] = {a0.x, a0.y, a0.z, a0.w}, A1[4] = {a1.x, a1.y, a1.z, a1.w};
     const uint32_t B0[4] = {b0.x, b0.y, b0.z, b0.w}, B1[4] = {b1.x, b1.y, b1.z, b1.w};
     const uint32_t V[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
+        if (w >= words) break;
         uint32_t ia[4], ib[4];  // positions whose first / second symbol is A C G T
         ia[0] = ~A0[w] & ~A1[w] & V[w]; ia[1] = A0[w] & ~A1[w] & V[w]; ia[2] = ~A0[w] & A1[w] & V[w]; ia[3] = A0[w] & A1[w] & V[w];
         ib[0] = ~B0[w] & ~B1[w]; ib[1] = B0[w] & ~B1[w]; ib[2] = ~B0[w] & B1[w]; ib[3] = B0[w] & B1[w];
@@ -117,13 +133,13 @@ __device__ __forceinline__ void add_block_pair_counts(const uint4 *__restrict__ 
 }
 
 __global__ __launch_bounds__(kThreads) void k_pair_tile_sums(const uint4 *__restrict__ pair_blocks, uint64_t npair,
-                                                             Sixteen *__restrict__ tiles) {
+                                                             Sixteen *__restrict__ tiles, int words) {
     __shared__ uint32_t red[16][kThreads / 64];
     for (uint64_t tile = blockIdx.x; tile * kTilePairBlocks < npair; tile += gridDim.x) {
         uint32_t acc[16] = {0};
         for (int i = 0; i < kBlocksPerThread; ++i) {
             const uint64_t pb = tile * kTilePairBlocks + uint64_t(threadIdx.x) * kBlocksPerThread + i;
-            if (pb < npair) add_block_pair_counts(pair_blocks + pb * 8, acc);
+            if (pb < npair) add_block_pair_counts(pair_blocks + pb * 8, acc, words);
         }
         __syncthreads();
 #pragma unroll
@@ -173,14 +189,14 @@ __global__ __launch_bounds__(1024) void k_pair_scan(Sixteen *__restrict__ tiles,
 }
 
 __global__ __launch_bounds__(kThreads) void k_pair_headers(uint4 *__restrict__ pair_blocks, uint64_t npair,
-                                                           const Sixteen *__restrict__ tiles) {
+                                                           const Sixteen *__restrict__ tiles, int words) {
     __shared__ uint32_t wave_tot[kThreads / 64];
     for (uint64_t tile = blockIdx.x; tile * kTilePairBlocks < npair; tile += gridDim.x) {
         const uint64_t first = tile * kTilePairBlocks + uint64_t(threadIdx.x) * kBlocksPerThread;
         // pass A: my blocks' totals -> where my first block starts inside the tile
         uint32_t mine[16] = {0};
         for (int i = 0; i < kBlocksPerThread; ++i)
-            if (first + i < npair) add_block_pair_counts(pair_blocks + (first + i) * 8, mine);
+            if (first + i < npair) add_block_pair_counts(pair_blocks + (first + i) * 8, mine, words);
         uint32_t run[16];
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -198,7 +214,7 @@ __global__ __launch_bounds__(kThreads) void k_pair_headers(uint4 *__restrict__ p
             run[p] = before + inc - mine[p];
         }
         // pass B: header fields = counts before the block, relative to its superblock start
-        const uint64_t sb_tile = tile & ~uint64_t(127);  // 128 tiles x 131072 positions = 2^24
+        const uint64_t sb_tile = tile & ~uint64_t(127);  // 128 tiles of 1024 blocks = one superblock
         uint32_t rel[16];
 #pragma unroll
         for (int p = 0; p < 16; ++p) rel[p] = uint32_t(tiles[tile].v[p] - tiles[sb_tile].v[p]) + run[p];
@@ -207,7 +223,7 @@ __global__ __launch_bounds__(kThreads) void k_pair_headers(uint4 *__restrict__ p
             if (pb >= npair) break;
             uint4 *blk = pair_blocks + pb * 8;
             uint32_t add[16] = {0};
-            add_block_pair_counts(blk, add);
+            add_block_pair_counts(blk, add, words);
             uint32_t lo[8], hi[4] = {0, 0, 0, 0};  // 16 x u16 low halves, 16 x u8 high bytes
 #pragma unroll
             for (int j = 0; j < 8; ++j) lo[j] = (rel[2 * j] & 0xFFFFu) | ((rel[2 * j + 1] & 0xFFFFu) << 16);
@@ -232,9 +248,9 @@ __global__ void k_pair_super(const Sixteen *__restrict__ tiles, uint64_t ntiles,
 
 }  // namespace
 
-PairIndexSizes pair_index_sizes(uint64_t nblocks) {
+PairIndexSizes pair_index_sizes(uint64_t nblocks, int stride) {
     PairIndexSizes s;
-    s.pair_blocks = 2 * nblocks;
+    s.pair_blocks = stride == 96 ? (nblocks * 256) / 96 + 2 : 2 * nblocks;
     s.tiles = (s.pair_blocks + kTilePairBlocks - 1) / kTilePairBlocks;
     s.supers = (s.tiles + 127) / 128;
     s.pair_block_bytes = size_t(s.pair_blocks) * 128;
@@ -244,8 +260,13 @@ PairIndexSizes pair_index_sizes(uint64_t nblocks) {
 }
 
 hipError_t build_pair_index(const void *d_blocks, uint64_t nblocks, const uint64_t start_index[6], void *d_pair_blocks,
-                            void *d_super, void *d_scratch, hipStream_t stream) {
-    const PairIndexSizes sz = pair_index_sizes(nblocks);
+                            void *d_super, void *d_scratch, hipStream_t stream, int stride) {
+    const PairIndexSizes sz = pair_index_sizes(nblocks, stride);
+    const uint32_t stride96 = stride == 96 ? 1u : 0u;
+    const int words = stride96 ? 3 : 4;
+    // with overlapping blocks not every (block, word) is painted (the tail): start from zeros
+    hipError_t zeroed = hipMemsetAsync(d_pair_blocks, 0, sz.pair_block_bytes, stream);
+    if (zeroed != hipSuccess) return zeroed;
     const uint4 *blocks = static_cast<const uint4 *>(d_blocks);
     uint4 *pair = static_cast<uint4 *>(d_pair_blocks);
     uint64_t *K = static_cast<uint64_t *>(d_scratch);
@@ -255,11 +276,11 @@ hipError_t build_pair_index(const void *d_blocks, uint64_t nblocks, const uint64
     hipLaunchKernelGGL(k_pair_consts, dim3(1), dim3(128), 0, stream, blocks, st, K);
     const uint64_t groups_blocks = (nblocks * 8 + 255) / 256;
     hipLaunchKernelGGL(k_pair_paint, dim3(uint32_t(groups_blocks > 8192 ? 8192 : (groups_blocks ? groups_blocks : 1))), dim3(256), 0,
-                       stream, blocks, nblocks, pair);
+                       stream, blocks, nblocks, pair, stride96);
     const uint32_t tgrid = uint32_t(sz.tiles > 4096 ? 4096 : (sz.tiles ? sz.tiles : 1));
-    hipLaunchKernelGGL(k_pair_tile_sums, dim3(tgrid), dim3(kThreads), 0, stream, pair, sz.pair_blocks, tiles);
+    hipLaunchKernelGGL(k_pair_tile_sums, dim3(tgrid), dim3(kThreads), 0, stream, pair, sz.pair_blocks, tiles, words);
     hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, stream, tiles, sz.tiles);
-    hipLaunchKernelGGL(k_pair_headers, dim3(tgrid), dim3(kThreads), 0, stream, pair, sz.pair_blocks, tiles);
+    hipLaunchKernelGGL(k_pair_headers, dim3(tgrid), dim3(kThreads), 0, stream, pair, sz.pair_blocks, tiles, words);
     hipLaunchKernelGGL(k_pair_super, dim3(uint32_t((sz.supers * 16 + 255) / 256)), dim3(256), 0, stream, tiles, sz.tiles, K,
                        sz.supers, static_cast<uint64_t *>(d_super));
     return hipGetLastError();

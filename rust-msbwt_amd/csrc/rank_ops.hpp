@@ -153,8 +153,16 @@ __device__ __forceinline__ Range constrain_any(uint32_t format, const uint4 *__r
 //                            relative to the block's 2^24-position superblock, pair p = 4 a + b
 //     chunk 7                16 x u8: their high bytes
 // `super` holds K + occ2(superblock start) as u64 x 16 per superblock.
-constexpr int kPairShift = 7;         // 128 positions per pair block
-constexpr int kPairSuperShift = 24;   // 2^24 positions per superblock
+// Blocks come in two spacings.  stride 128: block b covers [128 b, 128 b + 128).  stride 96
+// ("overlapping"): block b covers [96 b, 96 b + 128) -- every block also holds the first 32
+// positions of the next one, so a range up to 32 wide that starts in a block's own 96 positions is
+// ranked from ONE line (on real 30x data ranges stay ~25 wide to the last step: with stride 128 every
+// fifth step needs a second line).  1.33 bytes per symbol instead of 1.  Header counts are those at
+// the block's first position either way; a superblock is 2^17 blocks.
+constexpr int kPairSuperBlocks = 17;  // log2(blocks per superblock)
+
+__device__ __forceinline__ uint64_t pair_block_of(uint64_t pos, bool stride96) { return stride96 ? (pos >> 5) / 3u : pos >> 7; }
+__device__ __forceinline__ uint64_t pair_block_start(uint64_t blk, bool stride96) { return stride96 ? blk * 96u : blk << 7; }
 constexpr int kPairValidChunk = 4, kPairLoChunk = 5, kPairHiChunk = 7;
 
 // branch-free: codes 1,2,3,5 are bits 1,2,3,5 of 0x2E; A C G T -> 0 1 2 3 is s - 1 - (s >> 2)

@@ -242,6 +242,15 @@ class RleBWT(BWT):
     def get_pair_index(self):
         return bool(_lib.lib().msbwt_rle_get_pair_index(self._h))
 
+    def set_pair_stride(self, stride):
+        """128 = disjoint pair blocks, 96 = overlapping (one line for ranges up to 32 wide), 0 = automatic."""
+        rc = _lib.lib().msbwt_rle_set_pair_stride(self._h, stride)
+        if rc:
+            _raise(rc, self._h)
+
+    def get_pair_stride(self):
+        return int(_lib.lib().msbwt_rle_get_pair_stride(self._h))
+
     BLOCK_FORMATS = {"planes": 0, "runs": 1}
 
     def set_block_format(self, fmt):

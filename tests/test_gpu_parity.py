@@ -22,6 +22,9 @@ def search_kernel(request, monkeypatch):
     -- a handle reads MSBWT_SEARCH / MSBWT_BLOCKS when it is created."""
     monkeypatch.setenv("MSBWT_SEARCH", "auto" if request.param == "runs" else request.param)
     monkeypatch.setenv("MSBWT_BLOCKS", "runs" if request.param == "runs" else "planes")
+    # pair blocks: the forced-lanes mode keeps the disjoint 128-position blocks, the others take the
+    # automatic choice (overlapping stride-96 blocks on indexes this small)
+    monkeypatch.setenv("MSBWT_PAIR_STRIDE", "128" if request.param == "lanes" else "0")
     return request.param
 
 
@@ -304,11 +307,11 @@ def test_table_rebuilt_on_reload_and_auto_depth():
     o.load_vector(rle)
     b = gpu_bwt(rle)
     d = b.get_table_depth()
-    assert 1 <= d <= 15 and 4 ** d <= o.get_total_size()
+    assert 1 <= d <= 17 and 4 ** d <= 8 * o.get_total_size()   # flat: 4^d <= T; packed (two deeper): 4^d <= 8 T
     qs = random_kmers(1, 3000, 12)
     assert np.array_equal(b.count_kmers(qs), o.count_kmers(qs))
     b.load_vector(msbwt.bwt_converter.convert_to_vec("TG$$CAGCCG"))   # tiny: table depth shrinks
-    assert b.get_table_depth() <= 1
+    assert b.get_table_depth() <= 3                                   # flat 1 (4 <= 10), packed 3 (64 <= 80)
     assert b.count_kmer(stoi("CG")) == 2
 
 
@@ -486,7 +489,7 @@ def test_pair_index_never_changes_results(pair, depth):
 
 def test_pair_index_on_random_streams_and_superblock_borders():
     """Synthetic streams (not BWTs): the pair identity must hold for any symbol string.  The
-    second stream is longer than one 2^24-position superblock."""
+    second stream is longer than one superblock (2^17 pair blocks)."""
     for rle, nq in ((random_stream(41, 50000, "short"), 4000), (random_stream(43, 20_000, "long"), 4000)):
         o = orc.OracleRleBWT()
         o.load_vector(rle)

@@ -49,6 +49,7 @@ def main():
         for _ in range(3):
             depth = int(rng.integers(0, 9))
             b.set_table_depth(depth)
+            b.set_pair_stride(int(rng.choice([0, 96, 128])))
             b.set_pair_index(int(rng.integers(0, 2)))
             b.set_presence_filter(int(rng.integers(0, 2)))
             b.set_table_packed(int(rng.integers(-1, 2)))           # packed table when a pair index exists
