@@ -136,13 +136,12 @@ __device__ __forceinline__ uint64_t pair_line_bound(const PairLine &L, uint64_t 
     return super_base + L.field + pair_line_count(L, r);
 }
 
-template <bool kReads, bool kPair, int kWords>
+template <bool kReads, bool kPair, int kWords, bool kStride96>
 __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restrict__ blocks, uint64_t total,
                                                           const uint4 *__restrict__ table, uint32_t depth, uint32_t table_packed,
                                                           const uint32_t *__restrict__ filter, uint32_t filter_mask,
                                                           const uint4 *__restrict__ pair_blocks,
-                                                          const uint64_t *__restrict__ pair_super, uint32_t pair_stride96,
-                                                          const QuerySource src,
+                                                          const uint64_t *__restrict__ pair_super, const QuerySource src,
                                                           uint32_t *__restrict__ flags, uint64_t *__restrict__ debug,
                                                           unsigned long long *__restrict__ tile_counter, uint32_t grain) {
     using Scratch = LaneScratchT<kWords>;
@@ -357,7 +356,7 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
         const uint32_t s1 = w[0] & 7u, s2 = (w[0] >> 3) & 7u;
         const bool pair = kPair && have && rem >= 2u && (acgt_bit(s1) & acgt_bit(s2)) != 0u;
         const uint32_t a2 = acgt_code(s1) & 3u, b2 = acgt_code(s2) & 3u;
-        const bool s96 = pair_stride96 != 0u;
+        constexpr bool s96 = kStride96;  // compile-time: the stride-128 kernel carries no division
         const uint64_t base = pair ? reinterpret_cast<uint64_t>(pair_blocks) : reinterpret_cast<uint64_t>(blocks);
         // the block of l -- and h's own block only when h does not fit the same line (overlapping pair
         // blocks hold 32 positions beyond their own 96)
@@ -438,13 +437,13 @@ constexpr uint64_t kMaxTiles = 1ull << 32;
 
 // The kernel is persistent: the grid is what the device keeps resident -- workgroups per CU
 // (occupancy API: LDS- and VGPR-bound, capped below) x CUs; tiles are dealt out by atomic tickets.
-template <bool kReads, bool kPair, int kWords>
+template <bool kReads, bool kPair, int kWords, bool kStride96>
 uint32_t resident_waves() {
     static const uint32_t cached = [] {
         int device = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&device) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_count_kmers_lanes<kReads, kPair, kWords>, 64, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_count_kmers_lanes<kReads, kPair, kWords, kStride96>, 64, 0) != hipSuccess ||
             cus <= 0 || per_cu <= 0)
             return 7u * 256u;
         // Measured on MI355X (tools/sweep_waves.sh, human-scale index): throughput rises up to 8 waves
@@ -456,35 +455,36 @@ uint32_t resident_waves() {
             const int want = std::atoi(env);
             if (want > 0) per_cu = want;
         }
-        if (std::getenv("MSBWT_VERBOSE")) std::fprintf(stderr, "[msbwt] lanes kernel <%d,%d,%d>: %d workgroups per CU x %d CUs\n", int(kReads), int(kPair), kWords, per_cu, cus);
+        if (std::getenv("MSBWT_VERBOSE")) std::fprintf(stderr, "[msbwt] lanes kernel <%d,%d,%d,%d>: %d workgroups per CU x %d CUs\n", int(kReads), int(kPair), kWords, int(kStride96), per_cu, cus);
         return uint32_t(cus) * uint32_t(per_cu);
     }();
     return cached;
 }
 
-template <bool kReads, bool kPair, int kWords>
+template <bool kReads, bool kPair, int kWords, bool kStride96>
 hipError_t launch_variant(hipStream_t stream, const IndexView &ix, const QuerySource &src, uint32_t *flags) {
     const uint4 *table = static_cast<const uint4 *>(ix.table.entries);
     const uint32_t *filter = table ? ix.table.filter : nullptr;
     const uint32_t filter_mask = filter ? uint32_t((1ull << (2 * ix.table.filter_depth)) - 1ull) : 0u;
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
-    const uint64_t waves = std::min<uint64_t>(tiles, resident_waves<kReads, kPair, kWords>());
+    const uint64_t waves = std::min<uint64_t>(tiles, resident_waves<kReads, kPair, kWords, kStride96>());
     if (tiles > kMaxTiles || !ix.tile_counter) return hipErrorInvalidValue;
     const hipError_t zeroed = hipMemsetAsync(ix.tile_counter, 0, sizeof(unsigned long long), stream);
     if (zeroed != hipSuccess) return zeroed;
     // tiles per ticket: about eight tickets per wave at least, sixteen tiles at most
     const uint32_t grain = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(16, tiles / (waves * 8))));
-    hipLaunchKernelGGL((k_count_kmers_lanes<kReads, kPair, kWords>), dim3(uint32_t(waves)), dim3(64), 0, stream,
+    hipLaunchKernelGGL((k_count_kmers_lanes<kReads, kPair, kWords, kStride96>), dim3(uint32_t(waves)), dim3(64), 0, stream,
                        static_cast<const uint4 *>(ix.blocks), ix.total, table, uint32_t(ix.table.depth), ix.table.packed ? 1u : 0u, filter, filter_mask,
-                       static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, ix.pair_stride96 ? 1u : 0u, src, flags, ix.debug,
+                       static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags, ix.debug,
                        static_cast<unsigned long long *>(ix.tile_counter), grain);
     return hipGetLastError();
 }
 
 template <bool kReads>
 hipError_t launch_shape(bool pair, bool longk, hipStream_t stream, const IndexView &ix, const QuerySource &src, uint32_t *flags) {
-    if (longk) return pair ? launch_variant<kReads, true, 6>(stream, ix, src, flags) : launch_variant<kReads, false, 6>(stream, ix, src, flags);
-    return pair ? launch_variant<kReads, true, 3>(stream, ix, src, flags) : launch_variant<kReads, false, 3>(stream, ix, src, flags);
+    if (!pair) return longk ? launch_variant<kReads, false, 6, false>(stream, ix, src, flags) : launch_variant<kReads, false, 3, false>(stream, ix, src, flags);
+    if (ix.pair_stride96) return longk ? launch_variant<kReads, true, 6, true>(stream, ix, src, flags) : launch_variant<kReads, true, 3, true>(stream, ix, src, flags);
+    return longk ? launch_variant<kReads, true, 6, false>(stream, ix, src, flags) : launch_variant<kReads, true, 3, false>(stream, ix, src, flags);
 }
 
 }  // namespace
