@@ -44,6 +44,7 @@ def main():
         o.load_vector(rle)
         total = o.get_total_size()
         b = msbwt.RleBWT()
+        b.set_block_format("runs" if rng.random() < 0.25 else "planes")   # the memory-lean format now and then
         b.load_vector(rle)
         assert b.get_total_size() == total
         for _ in range(3):
