@@ -100,6 +100,9 @@ def parse_args(argv=None):
                     help="profiling passes only: skip parity, algorithmic-byte counters and the CPU baseline (prints a lean line)")
     ap.add_argument("--no-c5", action="store_true", help="skip the extra 1e9-random-31-mer line of the default workload")
     ap.add_argument("--no-weak", action="store_true", help="N>1: skip the extra weak-scaling measurement")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N>1 code path (process group, all_gather of the counts, barriers) even with one rank: "
+                         "a one-GPU rehearsal of the RCCL calls themselves")
     ap.add_argument("--c5-queries", type=int, default=1_000_000_000)
     ap.add_argument("--parity-sample", type=int, default=200_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
@@ -203,7 +206,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.force_dist  # the exchange step exists
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         import torch.distributed as dist
         # rank 0 may spend a minute building an index file while the others wait at a barrier
         patience = datetime.timedelta(minutes=30)
@@ -244,7 +250,7 @@ def main():
         # rank 0 builds (and caches) the index file, everyone loads it
         if rank == 0:
             npy, reads = synth.workload_index(args.workload, args.scale)
-        if world > 1:
+        if multi:
             dist.barrier()
         if rank != 0:
             npy, reads = synth.workload_index(args.workload, args.scale)
@@ -279,7 +285,7 @@ def main():
     log("rank %d: %d %s %d-mers in HBM in %.1fs" % (rank, nq, kind, k, time.time() - t0))
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    strong = world > 1 and args.scaling == "strong" and not fused
+    strong = multi and args.scaling == "strong" and not fused
     if strong:
         lo, hi = msbwt.sharded.shard_bounds(nq, world, rank)  # 16-query aligned: every shard keeps the tiled kernel
         cap = msbwt.sharded.shard_capacity(nq, world)
@@ -294,7 +300,7 @@ def main():
             bwt.count_kmers_device(d_q.data_ptr() + a * k, k, b - a, out.data_ptr(), stream)
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -309,7 +315,7 @@ def main():
     def run_steps(nsteps, narrow, a, b, per_rank):
         """nsteps passes over queries [a, b) of the batch; N > 1: + all_gather of `per_rank` counts per rank"""
         outs = [torch.zeros(per_rank, dtype=torch.int64, device=dev) for _ in range(2)]
-        if world == 1:
+        if not multi:
             for _ in range(nsteps):
                 count_into(outs[0], a, b)
             return outs[0], None, False
@@ -359,7 +365,7 @@ def main():
         bwt.set_kernel_timing(False)
         k_ms, n_launch = bwt.kernel_time_ms()
         bwt.device_status(stream)
-        if world > 1:
+        if multi:
             flag = torch.tensor([1.0 if bool(ovf) else 0.0, dt], dtype=torch.float64,
                                 device=dev if args.dist_backend == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
@@ -367,7 +373,7 @@ def main():
         return d_mine, d_everything, dt, k_ms, n_launch, False
 
     def measure(a, b, per_rank):
-        narrow = world > 1 and args.payload == "auto"
+        narrow = multi and args.payload == "auto"
         res = timed(narrow, a, b, per_rank)
         if res[5]:  # some count did not fit int16: measure again with u64 payloads (always exact)
             log("counts exceed int16: re-running with 64-bit payloads")
@@ -376,10 +382,10 @@ def main():
         return res[:5] + (narrow,)
 
     d_out, d_all, elapsed, kernel_ms, launches, narrow = measure(lo, hi, cap)
-    if world > 1:  # the gathered vector must contain this rank's own counts where they belong
+    if multi:  # the gathered vector must contain this rank's own counts where they belong
         assert torch.equal(d_all[rank * cap:rank * cap + mine_n], d_out[:mine_n]), "gathered counts differ from the local ones"
     ms_per_step = elapsed / args.steps * 1e3
-    job_queries = nq if (strong or world == 1) else nq * world
+    job_queries = nq if (strong or not multi) else nq * world
     value = job_queries * args.steps / elapsed
 
     # the whole batch's counts as one vector (strong: stitched from the gathered shards)
@@ -432,7 +438,7 @@ def main():
                             "arrival), overlapped with the next step's kernel"
                             % (world, "ONE fixed batch sharded over the ranks" if strong else "every rank its own whole batch",
                                "RCCL" if args.dist_backend == "nccl" else "gloo (rehearsal)",
-                               "int16" if narrow else "int64")) if world > 1 else "1 GPU",
+                               "int16" if narrow else "int64")) if multi else "1 GPU",
         },
     }
     if weak is not None:
@@ -567,7 +573,7 @@ def main():
                 "all_cores": {"value": nst / t_all, "cores": ncpu, "note": "same sample, static partition, instrumented build"},
             }
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     return rc

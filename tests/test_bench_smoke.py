@@ -87,3 +87,25 @@ def test_bench_two_ranks_rehearsal(payload):
     assert "cpu_baseline" not in r            # reported at N=1 only
     assert r["value"] > 0 and "x2" in r["config"]["parallelism"]
     assert ("int16" if payload == "auto" else "int64") in r["config"]["parallelism"]
+
+
+@pytest.mark.parametrize("payload", ["auto", "int64"])
+def test_bench_rccl_calls_on_one_rank(payload):
+    """The N>1 code path on REAL RCCL (nccl backend), with the only communicator this box allows: one
+    rank.  Process-group init with a device id, the asynchronous all_gather_into_tensor of int16/int64
+    counts shipped as raw bytes, its overlap with the next step, widening, the float64 all_reduce of the
+    timing, barriers -- everything but a second GPU on the other end of xGMI."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--dist-backend", "nccl", "--scale", "0.00003",
+                          "--steps", "4", "--warmup", "1", "--parity-sample", "5000", "--payload", payload, "--no-c5"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][-1])
+    assert r["n_gpus"] == 1 and r["scaling"] == "strong" and r["parity"]["mismatches"] == 0 and r["value"] > 0
+    assert "RCCL" in r["config"]["parallelism"] and ("int16" if payload == "auto" else "int64") in r["config"]["parallelism"]
+    assert r["weak_scaling"]["value"] > 0
