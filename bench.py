@@ -191,6 +191,14 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
+    # stdout carries ONE line, the JSON result: everything else that writes to fd 1 (RCCL prints a
+    # version banner there, libraries may follow) is sent to stderr
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(result_fd, (json.dumps(obj) + "\n").encode())
 
     import numpy as np
     import torch
@@ -488,7 +496,7 @@ def main():
         if c5 is not None:
             del c5["_q"], c5["_got"]
             result["c5_random_1e9"] = c5
-        print(json.dumps(result), flush=True)
+        emit(result)
     elif rank == 0:
         # ---- parity + algorithmic bytes (the oracle is the checker, never the thing timed as `value`) ----
         from oracle import oracle as orc
@@ -572,7 +580,7 @@ def main():
                 "sample": "%d queries sampled from the same batch, same RLE stream / comp_msbwt.npy, 1 thread (the reference is single-threaded), -O3 C restatement" % ncs,
                 "all_cores": {"value": nst / t_all, "cores": ncpu, "note": "same sample, static partition, instrumented build"},
             }
-        print(json.dumps(result), flush=True)
+        emit(result)
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -105,7 +105,9 @@ def test_bench_rccl_calls_on_one_rank(payload):
                           "--steps", "4", "--warmup", "1", "--parity-sample", "5000", "--payload", payload, "--no-c5"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    r = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][-1])
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "stdout must carry the JSON line only (RCCL's banner belongs on stderr): %r" % out.stdout[:500]
+    r = json.loads(lines[0])
     assert r["n_gpus"] == 1 and r["scaling"] == "strong" and r["parity"]["mismatches"] == 0 and r["value"] > 0
     assert "RCCL" in r["config"]["parallelism"] and ("int16" if payload == "auto" else "int64") in r["config"]["parallelism"]
     assert r["weak_scaling"]["value"] > 0
