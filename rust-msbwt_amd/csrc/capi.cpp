@@ -941,7 +941,9 @@ int msbwt_rle_count_kmers_multi_device(const msbwt_rle *const *replicas, size_t 
         DeviceScope scope(h->device);
         if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
         const size_t m = hi - lo;
-        if (h->device == home) {
+        // MSBWT_FORCE_PEER_COPIES=1: take the staging + peer-copy path even on the home device (tests on one GPU)
+        static const bool force_peer = [] { const char *e = std::getenv("MSBWT_FORCE_PEER_COPIES"); return e && std::atoi(e) != 0; }();
+        if (h->device == home && !(force_peer && r > 0)) {
             const int rc = launch_count(h, src + lo * k, k, m, dst + lo, h->stream, kHostFlags);
             if (rc) return rc;
         } else {

@@ -664,7 +664,8 @@ def test_presence_filter_never_changes_results(filt):
     assert dense.get_presence_filter() == 0
 
 
-def test_replicas_and_sharded_batches_match_a_single_handle():
+def test_replicas_and_sharded_batches_match_a_single_handle(monkeypatch):
+    monkeypatch.setenv("MSBWT_FORCE_PEER_COPIES", "1")  # shards of replicas 1.. go through hipMemcpyPeerAsync staging
     """The C ABI's multi-device entry points, rehearsed on this box's one GPU (devices = {0, 0, 0}):
     replicas are GPU -> GPU copies of the loaded index, a batch is sharded over them, and the counts
     must equal a single handle's (and the oracle's) bit for bit -- host and device forms."""
