@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -423,6 +424,16 @@ int install(msbwt_rle *h, const uint8_t *rle, size_t n) {
     release_index(h);
     int rc = ensure_runtime(h);
     if (rc) return rc;
+    // MSBWT_VERBOSE=1: one stderr line per load stage (the reference logs its load milestones with
+    // log::info!, rle_bwt.rs:62,149,347,383)
+    const bool verbose = std::getenv("MSBWT_VERBOSE") != nullptr;
+    auto clock = std::chrono::steady_clock::now();
+    auto stage = [&](const char *what, uint64_t bytes) {
+        if (!verbose) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[msbwt] load: %-22s %7.2f s  %8.2f GB in HBM\n", what, std::chrono::duration<double>(now - clock).count(), double(bytes) / 1e9);
+        clock = now;
+    };
     Totals t{};
     const char *mode = std::getenv("MSBWT_BUILD");
     h->block_format = h->wanted_block_format;
@@ -435,12 +446,18 @@ int install(msbwt_rle *h, const uint8_t *rle, size_t n) {
     h->totals = t;
     h->nblocks = h->block_format == kBlocksRuns ? run_block_count(t.total) : plane_block_count(t.total);
     h->loaded = true;
+    stage(h->block_format == kBlocksRuns ? "run blocks (host build)" : "plane blocks", h->nblocks * kBlockBytes + h->overflow_bytes);
     rc = rebuild_pair_index(h);  // first: the table may be packed with its help
+    if (!rc) stage(h->pair_stride == 96 ? "pair blocks, stride 96" : "pair blocks, stride 128", h->pair_bytes);
     if (!rc) rc = rebuild_table(h);
+    if (!rc) stage(h->table_packed ? "suffix table, packed" : "suffix table, flat", h->table_bytes);
     if (rc) {
         release_index(h);
         return rc;
     }
+    if (verbose)
+        std::fprintf(stderr, "[msbwt] load: %llu symbols, table depth %d, %.2f GB of HBM in all\n", (unsigned long long)t.total, h->table_depth,
+                     double(h->nblocks * kBlockBytes + h->overflow_bytes + h->pair_bytes + h->table_bytes) / 1e9);
     h->err.clear();
     return MSBWT_OK;
 }
