@@ -41,20 +41,35 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void global_void;
 
 constexpr int kRing = 64;        // undecided queries waiting for a lane: one tile's worth (the next tile waits in registers)
-constexpr int kRegions = 14;     // LDS-DMA regions of 8 lines: 64 first-bound lines + up to 48 second-bound lines
-constexpr int kLineSlots = kRegions * 8;
-constexpr uint32_t kMaxSecond = uint32_t(kLineSlots) - 64u;  // lanes beyond that with a second line sit the step out
+// LDS-DMA regions of 8 lines per wave: 8 for the 64 first-bound lines + the rest for second-bound
+// lines.  Fewer regions = less LDS = more resident waves, and lines in flight per CU are what the
+// throughput follows: measured at human scale (tools/sweep_variants.sh), 14 regions / 8 waves per CU
+// 5.05, 12 / 10 4.88 (uneven SIMDs), 10 / 8 4.77, 10 / 12 5.32 x 10^9 q/s -- sixteen second-line slots
+// cost 7 % (the queries of a tile take their first, widest step together), four more waves bring 13 %.
+// Searches of k > 32 carry 3 KiB of ring: they keep 14 regions and 8 waves.
+#ifdef MSBWT_LANES_REGIONS  // experiments
+template <int kWords> constexpr int kRegionsFor = MSBWT_LANES_REGIONS;
+#else
+template <int kWords> constexpr int kRegionsFor = kWords == 3 ? 10 : 14;
+#endif
+#ifndef MSBWT_LANES_WAVE_CAP
+#define MSBWT_LANES_WAVE_CAP 12
+#endif
 
 template <int kWords>
 struct LaneScratchT {
     static constexpr int kMaxK = kWords * 32 / 3;  // 32 or 64
+    static constexpr int kRegions = kRegionsFor<kWords>;
+    static constexpr int kLineSlots = kRegions * 8;
+    static constexpr uint32_t kMaxSecond = uint32_t(kLineSlots) - 64u;  // lanes beyond that with a second line sit the step out
+    static_assert(kRegions >= 10 && kRegions % 2 == 0, "first-bound lines take 8 regions; regions come in padded pairs");
     // Region i (one LDS-DMA instruction: lane j writes 16 bytes at 16 j) starts at uint4 index
     // region_base(i): every odd region is pushed 128 bytes further, so that the 64 lanes'
     // read-back of "chunk j of my line" touches every bank exactly once per 16 lanes (lanes 16 m ..
     // 16 m + 15 own the lines of regions 2 m and 2 m + 1, whose bank phases differ by 128 bytes).
     // During phase 1 the same memory stages the tile's query bytes (2 or 4 KiB).
-    uint4 lines[(kRegions / 2) * 136];   // 14.9 KiB
-    uint64_t list[kLineSlots];        // this step's line addresses (896 B)
+    uint4 lines[(kRegions / 2) * 136];   // 10.6 or 14.9 KiB
+    uint64_t list[kLineSlots];        // this step's line addresses (640 or 896 B)
     WorkItemT<kWords> ring[kRing];    // 2 or 3 KiB
 };
 
@@ -147,6 +162,8 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
     using Scratch = LaneScratchT<kWords>;
     using WorkItem = WorkItemT<kWords>;
     constexpr int kPieces = Scratch::kMaxK / 16;  // 16-byte pieces of a tile per lane: 2 or 4
+    constexpr int kRegions = Scratch::kRegions, kLineSlots = Scratch::kLineSlots;
+    constexpr uint32_t kMaxSecond = Scratch::kMaxSecond;
     __shared__ Scratch ws;
     const uint8_t *__restrict__ kmers = src.data;
     const uint32_t k = src.k;
@@ -379,15 +396,18 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
         ws.list[lane] = act ? base + bl * 128u : dummy;
         if (second && act) ws.list[slot_h] = base + bh * 128u;
         if (lane < 8u && 64u + nsecond + lane < uint32_t(kLineSlots)) ws.list[64u + nsecond + lane] = dummy;  // the ragged end of the last second-bound region
-        uint64_t super_l = 0, super_h = 0;  // pair steps: K[a][b] + occ2 at the superblock start (L2-resident table)
+        // pair steps: K[a][b] + occ2 at the superblock start (L2-resident table).  One 8-byte load per lane
+        // is a separate L2 request each (64 per wave): the second bound's base is fetched only in the rare
+        // case that it lies in another superblock -- into a register of its own, so that nothing here waits
+        // for the first load (a copy of super_l would: a whole L2 round trip before the lines are even asked for)
+        uint64_t super_l = 0, super_far = 0;
+        uint32_t far = 0;
         if (pair) {
-            // one 8-byte load per lane is a separate L2 request each (64 per wave): fetch the second
-            // bound's base only in the rare case that it lies in another superblock
             const uint32_t p = a2 * 4u + b2;
             const uint64_t sbl = bl >> kPairSuperBlocks, sbh = bh >> kPairSuperBlocks;
             super_l = pair_super[sbl * 16u + p];
-            super_h = super_l;
-            if (sbh != sbl) super_h = pair_super[sbh * 16u + p];
+            far = sbh != sbl ? 1u : 0u;
+            if (far != 0u) super_far = pair_super[sbh * 16u + p];
         }
         wave_lds_sync();
         {   // all line addresses first (one LDS round trip), then the LDS-DMA loads back to back
@@ -409,7 +429,8 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
                 read_pair_line(ws.lines, slot_l, a2, b2, L);
                 nl = pair_line_bound(L, super_l, r_l);
                 if (second) read_pair_line(ws.lines, slot_h, a2, b2, L);
-                nh = pair_line_bound(L, super_h, r_h);
+                asm volatile("" : "+v"(far));  // opaque here: the compiler must not fold this select back into the branch above
+                nh = pair_line_bound(L, far != 0u ? super_far : super_l, r_h);
                 consume_symbols<kWords>(w, 6);
                 rem -= 2u;
             } else {
@@ -446,11 +467,10 @@ uint32_t resident_waves() {
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_count_kmers_lanes<kReads, kPair, kWords, kStride96>, 64, 0) != hipSuccess ||
             cus <= 0 || per_cu <= 0)
             return 7u * 256u;
-        // Measured on MI355X (tools/sweep_waves.sh, human-scale index): throughput rises up to 8 waves
-        // per CU -- two per SIMD -- and is flat beyond (8, 9, 10, 12: 5.15 x 10^9 q/s each): the memory
-        // system's random-line rate is reached.  (With static tile striding 9 and 10 waves LOST 12-30 %:
-        // the waves of a three-wave SIMD ran slower and everybody waited for them.)
-        per_cu = std::min(per_cu, 8);
+        // LDS decides (13.25 KiB -> 12 waves, 18.4 KiB -> 8); whole multiples of the four SIMDs only: with
+        // 10 waves the two three-wave SIMDs run slower and throughput FELL (tools/sweep_variants.sh)
+        per_cu = std::min(per_cu, MSBWT_LANES_WAVE_CAP);
+        if (per_cu > 4) per_cu -= per_cu % 4;
         if (const char *env = std::getenv("MSBWT_LANES_WAVES_PER_CU")) {  // experiments
             const int want = std::atoi(env);
             if (want > 0) per_cu = want;
