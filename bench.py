@@ -34,7 +34,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is achievable
-RANDOM_LINE_PEAK = 4.8e10  # dependent random 128-byte lines/s over 100 GB, measured (tools/ubench_lds_gather.hip, 8+ waves/CU)
+RANDOM_LINE_PEAK = 4.86e10  # random 128-byte lines/s, measured: independent gathers over 8-250 GiB (tools/ubench_granule.hip; 64-, 32- and 16-byte
+# granules are served at the same rate), dependent LDS-DMA gathers over 100 GB 4.8e10 (tools/ubench_lds_gather.hip)
 HUMAN_SYMBOLS = 9e10
 KERNEL_SOURCES = ["kernels.hip", "lanes.hip", "search_common.hpp", "rank_ops.hpp", "kernels.hpp", "plane_index.hpp"]
 
@@ -65,6 +66,16 @@ def cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def kernel_label(bwt, k, fused):
+    """Name (as in the rocprofv3 kernel trace) of the kernel the library runs for this index and k."""
+    which = bwt.search_kernel_for(k)
+    reads, words = ("true" if fused else "false"), (3 if k <= 32 else 6)
+    if which == "lanes":
+        pair, s96 = bwt.get_pair_index(), bwt.get_pair_index() and bwt.get_pair_stride() == 96
+        return "k_count_kmers_lanes<%s,%s,%d,%s>" % (reads, "true" if pair else "false", words, "true" if s96 else "false")
+    return "k_count_kmers_tiled<%s,%d>" % (reads, words) if which == "groups" else "k_count_kmers_generic"
 
 
 def parse_args(argv=None):
@@ -555,7 +566,7 @@ def main():
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": None if achieved is None else achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note, "kernel_stamp": stamp,
-            "kernel": "k_count_kmers_tiled<reads>" if fused else "k_count_kmers_tiled" if 1 <= k <= 64 else "k_count_kmers_generic",
+            "kernel": kernel_label(bwt, k, fused),
             "kernel_ms": kernel_ms, "kernel_launches": launches,
             "algorithmic": {
                 "bytes_per_launch": int(alg_bytes), "bytes_per_query": alg_bytes / per_launch_q,

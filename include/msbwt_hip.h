@@ -201,6 +201,9 @@ int msbwt_rle_get_block_format(const msbwt_rle *bwt);
  * sets the initial mode.  Results never change. */
 int msbwt_rle_set_search_kernel(msbwt_rle *bwt, int mode);
 int msbwt_rle_get_search_kernel(const msbwt_rle *bwt);
+/* The kernel a batch of k-symbol queries runs on with the index and mode as they are now: 1 or 2 as
+ * above, 0 for k > 64 (generic 8-lane kernel, no suffix table); negative = error. */
+int msbwt_rle_search_kernel_for(const msbwt_rle *bwt, size_t k);
 /* Bytes of HBM held by the index (blocks + table + filter + pair index). */
 uint64_t msbwt_rle_device_bytes(const msbwt_rle *bwt);
 /* Average duration in ms of the count kernel launches since the last reset, measured with

@@ -132,6 +132,7 @@ class RleBWT final : public BWT {
     void set_table_packed(int mode) { check(msbwt_rle_set_table_packed(raw_, mode)); }
     void set_pair_index(int mode) { check(msbwt_rle_set_pair_index(raw_, mode)); }
     void set_search_kernel(int mode) { check(msbwt_rle_set_search_kernel(raw_, mode)); }
+    int search_kernel_for(size_t k) const { return msbwt_rle_search_kernel_for(raw_, k); }
     msbwt_rle *raw() const { return raw_; }
 
     /// A copy of the loaded index on another GPU of the node (GPU -> GPU, no rebuild).

@@ -47,6 +47,7 @@ SIGNATURES = {
     "msbwt_rle_get_block_format": (_int, [_vp]),
     "msbwt_rle_set_search_kernel": (_int, [_vp, _int]),
     "msbwt_rle_get_search_kernel": (_int, [_vp]),
+    "msbwt_rle_search_kernel_for": (_int, [_vp, _sz]),
     "msbwt_rle_set_pair_index": (_int, [_vp, _int]),
     "msbwt_rle_get_pair_index": (_int, [_vp]),
     "msbwt_rle_set_pair_stride": (_int, [_vp, _int]),

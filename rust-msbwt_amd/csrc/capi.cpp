@@ -1070,6 +1070,14 @@ int msbwt_rle_set_search_kernel(msbwt_rle *h, int mode) {
 
 int msbwt_rle_get_search_kernel(const msbwt_rle *h) { return h ? h->search_kernel : 0; }
 
+int msbwt_rle_search_kernel_for(const msbwt_rle *h, size_t k) {
+    if (!h || !h->loaded) return MSBWT_ERR_INVALID_ARG;
+    if (k > 0xFFFFFFFFull) return 0;
+    msbwt_rle *m = const_cast<msbwt_rle *>(h);
+    std::lock_guard<std::mutex> lock(m->mu);
+    return search_kernel_for(view_of(m), uint32_t(k));
+}
+
 uint64_t msbwt_rle_device_bytes(const msbwt_rle *h) {
     if (!h || !h->loaded) return 0;
     return h->nblocks * kBlockBytes + h->overflow_bytes + (h->d_table ? uint64_t(h->table_bytes) : 0) + h->pair_bytes +

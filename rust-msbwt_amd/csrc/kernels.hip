@@ -392,6 +392,11 @@ void launch_tiled(bool longk, dim3 grid, hipStream_t stream, const IndexView &ix
 
 }  // namespace
 
+int search_kernel_for(const IndexView &ix, uint32_t k) {
+    if (k < 1 || k > uint32_t(kMaxTiledK)) return 0;
+    return use_lanes_kernel(ix, k) ? kSearchLanes : kSearchGroups;
+}
+
 hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_t k, uint64_t n,
                               uint64_t *counts, uint32_t *flags, hipStream_t stream) {
     if (n == 0) return hipSuccess;

@@ -46,6 +46,9 @@ struct IndexView {
 
 // counts[q] = count_kmer(kmers[q*k .. q*k+k)) for q < n.  Sets kFlagInvalidSymbol in *flags
 // (and writes UINT64_MAX) for a query holding a code >= 6.
+// Which kernel a count_kmers / count_read_kmers launch for k-symbol queries runs on this index:
+// kSearchLanes (lanes.hip), kSearchGroups (the tiled kernel of kernels.hip) or 0 (k > 64: generic kernel)
+int search_kernel_for(const IndexView &ix, uint32_t k);
 hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_t k, uint64_t n,
                               uint64_t *counts, uint32_t *flags, hipStream_t stream);
 

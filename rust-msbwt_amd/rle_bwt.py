@@ -273,6 +273,13 @@ class RleBWT(BWT):
     def get_search_kernel(self):
         return {v: k for k, v in self.SEARCH_KERNELS.items()}[int(_lib.lib().msbwt_rle_get_search_kernel(self._h))]
 
+    def search_kernel_for(self, k):
+        """The kernel a batch of k-symbol queries runs on right now: "lanes", "groups" or "generic" (k > 64)."""
+        rc = int(_lib.lib().msbwt_rle_search_kernel_for(self._h, int(k)))
+        if rc < 0:
+            _raise(rc, self._h)
+        return {0: "generic", 1: "groups", 2: "lanes"}[rc]
+
     def device_bytes(self):
         return int(_lib.lib().msbwt_rle_device_bytes(self._h))
 

@@ -623,6 +623,16 @@ def test_introspection(search_kernel):
     assert b.get_pair_index() and b.device_bytes() > blocks * 128 * 3
     assert b.device_ordinal() == 0
     assert "gfx950" in msbwt.version()
+    # which kernel a batch runs on (bench.py labels its roofline with it)
+    b.set_search_kernel("auto")  # pair index + depth-4 table: long searches go to the lanes kernel
+    assert b.search_kernel_for(31) == "lanes" and b.search_kernel_for(8) == "groups" and b.search_kernel_for(70) == "generic"
+    b.set_search_kernel("groups")
+    assert b.search_kernel_for(31) == "groups"
+    b.set_search_kernel("lanes")
+    assert b.search_kernel_for(8) == "lanes" and b.search_kernel_for(65) == "generic"
+    b.set_pair_index(0)
+    b.set_search_kernel("auto")
+    assert b.search_kernel_for(31) == "groups"
 
 
 def test_sharded_counter_single_gpu_worker():
