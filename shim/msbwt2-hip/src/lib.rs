@@ -1,70 +1,15 @@
-# INTEGRATION — binding `libmsbwt_hip.so` into rust-msbwt (`msbwt2`)
-
-The drop-in boundary is the C ABI in `include/msbwt_hip.h`, built by
-`python -c "import __graft_entry__ as g; g.build()"` into
-`rust-msbwt_amd/libmsbwt_hip.so` (hipcc, `--offload-arch=gfx950`).  Every entry point is
-`extern "C"`, takes plain pointers and sizes, never unwinds, and names the reference
-interface it replaces.  This file shows the reference-side binding a maintainer would add:
-a `GpuRleBWT` type that implements `msbwt2::msbwt_core::BWT` (the trait `RleBWT` implements,
-`src/msbwt_core.rs:28-162`) over those symbols.
-
-> Status: the Rust below — shipped as a crate in `shim/msbwt2-hip/` (`Cargo.toml`, `build.rs`,
-> `src/lib.rs`, `tests/trait_parity.rs`: depends on `msbwt2 = "0.3.2"` for the trait) — was written
-> against the header but **not compiled**: this build image has no `cargo`/`rustc`.
-> `tests/test_shim_matches_header.py` checks every `extern "C"` declaration of both copies against
-> `include/msbwt_hip.h` (name, arity, each type).  The same ABI is exercised end to end by the ctypes
-> binding (`rust-msbwt_amd/_lib.py`, `rle_bwt.py`) that the parity tests run through.
-
-## 1. Mapping
-
-| reference (`trait BWT`, `src/msbwt_core.rs`) | C ABI | notes |
-|---|---|---|
-| `RleBWT::new()` / `with_bin_power(u8)` (`src/rle_bwt.rs:297,309`) | `msbwt_rle_new(bin_power)` / `msbwt_rle_new_on_device(bin_power, device)` | `bin_power` accepted, results never depend on it |
-| `Drop` | `msbwt_rle_free` | frees HBM |
-| `fn load_vector(&mut self, Vec<u8>)` `:43` | `msbwt_rle_load_vector(h, ptr, len)` | copies; trait method cannot fail → shim panics on error, as the reference would on a bad symbol |
-| `fn load_numpy_file(&mut self,&str)->io::Result<()>` `:58` | `msbwt_rle_load_numpy_file(h, path)` | `MSBWT_ERR_IO` → `io::Error`, `MSBWT_ERR_UNEXPECTED_EOF` → `ErrorKind::UnexpectedEof`, `MSBWT_ERR_BAD_HEADER` → `panic!` (reference panics, `src/rle_bwt.rs:91-93,115,123-125`) |
-| `fn get_symbol_count(&self,u8)->u64` `:75` | `msbwt_rle_get_symbol_count` | |
-| `fn get_total_size(&self)->u64` `:90` | `msbwt_rle_get_total_size` | |
-| `unsafe fn constrain_range(&self,u8,&BWTRange)->BWTRange` `:99` | `msbwt_rle_constrain_range(h, sym, l, h, &out_l, &out_h)` | `BWTRange` is not `repr(C)`: scalars cross the ABI |
-| `fn count_kmer(&self,&[u8])->u64` `:124-161` | `msbwt_rle_count_kmer(h, ptr, k, &out)` | `MSBWT_ERR_INVALID_SYMBOL` → `panic!` (reference `assert!`, `:127`) |
-| — (no batch API in the reference) | `msbwt_rle_count_kmers`, `msbwt_rle_constrain_ranges` (+ `_device` forms) | the GPU entry points proper; inherent methods on `GpuRleBWT` |
-| the caller's loop `convert_stoi` → windows → `reverse_complement_i` → `count_kmer` (`src/string_util.rs:45-67`) | `msbwt_rle_count_read_kmers` (+ `_device`) | fused: reads (ASCII or codes) in, counts of every k-mer window on either/both strands out |
-| `bwt_converter::convert_to_vec` / `save_bwt_numpy` / `save_bwt_runs_numpy` | `msbwt_convert_to_vec`, `msbwt_save_bwt_numpy`, `msbwt_save_bwt_runs_numpy` | optional: the crate's own functions keep working |
-| `string_util::convert_stoi` / `convert_itos` / `reverse_complement_i` | `msbwt_convert_stoi`, `msbwt_convert_itos`, `msbwt_reverse_complement_i` | optional |
-
-A single `count_kmer` call costs a kernel launch + two tiny copies (~30 µs); the GPU pays off
-through `count_kmers` (millions of k-mers per call; through these HOST-pointer entry points, PCIe
-included: 2.0–2.4·10^9 21-mers/s and 4.9·10^9 read windows/s, a pinned three-stage pipeline inside
-the library; device-resident batches: DESIGN.md §5).
-`msbwt_rle_set_table_depth` / `msbwt_rle_set_table_packed` / `msbwt_rle_set_pair_index` /
-`msbwt_rle_set_pair_stride` trade HBM for
-speed (all on by default when they fit: 208 GB for a 30× human BWT); `msbwt_rle_set_block_format(h, 1)`
-before a load selects the memory-lean run blocks instead (45 GB, ~7× slower); results never depend on
-any of them.
-Callers that loop over k-mers — fmlrc-style correctors — should collect them into a batch.
-
-## 2. `build.rs`
-
-```rust
-// build.rs of the crate that hosts GpuRleBWT (e.g. msbwt2 behind a `gpu` feature)
-fn main() {
-    // directory that holds libmsbwt_hip.so (rust-msbwt_amd/ of this repository)
-    let dir = std::env::var("MSBWT_HIP_LIB_DIR").expect("set MSBWT_HIP_LIB_DIR");
-    println!("cargo:rustc-link-search=native={dir}");
-    println!("cargo:rustc-link-lib=dylib=msbwt_hip");
-    println!("cargo:rustc-link-arg=-Wl,-rpath,{dir}");
-    println!("cargo:rerun-if-env-changed=MSBWT_HIP_LIB_DIR");
-}
-```
-
-## 3. `src/gpu_rle_bwt.rs`
-
-```rust
-//! MI355X-backed drop-in for `rle_bwt::RleBWT`.
+//! `msbwt2-hip`: `GpuRleBWT`, an MI355X-backed drop-in for `msbwt2::rle_bwt::RleBWT`, over the C ABI of
+//! `libmsbwt_hip.so` (include/msbwt_hip.h of the rust-msbwt_amd repository).  It implements
+//! `msbwt2::msbwt_core::BWT` (src/msbwt_core.rs:28-162 of rust-msbwt), so code written against the
+//! trait runs unchanged; the batch methods (`count_kmers`, `constrain_ranges`, `count_read_kmers`) are
+//! where the GPU pays off.
+//!
+//! NOT COMPILED in the repository's build image (no cargo/rustc there): written against the header;
+//! tests/test_shim_matches_header.py keeps every `extern "C"` declaration below in step with it.
 use std::ffi::{c_char, c_int, c_void, CStr, CString};
 use std::io;
 
-use crate::msbwt_core::{BWTRange, BWT};
+use msbwt2::msbwt_core::{BWTRange, BWT, VC_LEN};
 
 #[repr(C)]
 pub struct MsbwtRle { _private: [u8; 0] }
@@ -226,7 +171,7 @@ impl BWT for GpuRleBWT {
 
     #[inline]
     fn get_symbol_count(&self, symbol: u8) -> u64 {
-        assert!((symbol as usize) < crate::msbwt_core::VC_LEN); // reference: array index panic
+        assert!((symbol as usize) < VC_LEN); // reference: array index panic
         unsafe { msbwt_rle_get_symbol_count(self.raw, symbol) }
     }
 
@@ -248,46 +193,3 @@ impl BWT for GpuRleBWT {
         out
     }
 }
-```
-
-`src/lib.rs` gains `#[cfg(feature = "gpu")] pub mod gpu_rle_bwt;`.  The reference's own tests
-for the trait carry over by substituting the type, e.g. `src/rle_bwt.rs:677-710`:
-
-```rust
-let mut bwt = GpuRleBWT::with_bin_power(bin_power);
-bwt.load_vector(compressed_bwt.clone());
-assert_eq!(bwt.count_kmer(&string_util::convert_stoi(&"ACG")), 4);
-```
-
-(`tests/test_gpu_parity.py::test_count_kmer_literals` is that test, run through ctypes.)
-
-## 4. Other hosts
-
-* **C++**: `include/msbwt_hip.hpp` is a header-only mirror of the trait (`msbwt::BWT`,
-  `msbwt::RleBWT`, `BWTRange`, `convert_stoi`, `convert_to_vec`, ...) over the C ABI, with the
-  reference's error behaviour mapped to exceptions; `tests/cpp/test_rle_bwt.cpp` is the
-  reference's own `rle_bwt.rs` test module written against it.
-
-* **Python / ctypes**: `rust-msbwt_amd/_lib.py` is the complete binding (`SIGNATURES` lists
-  every symbol with its types); `rust_msbwt_amd.RleBWT` is the trait mirror.
-* **PyTorch**: torch is only a source of HBM buffers and streams —
-  `bwt.count_kmers_device(t.data_ptr(), k, n, out.data_ptr(), torch.cuda.current_stream().cuda_stream)`.
-  When torch is installed the Python binding maps torch's bundled `libamdhip64.so` first so
-  that the process holds a single HIP runtime (`_lib._share_hip_runtime_with_torch`).
-* **Multi-GPU, one process**: `msbwt_rle_replicate` + `msbwt_rle_count_kmers_multi` /
-  `msbwt_rle_count_read_kmers_multi` (host batches) and `msbwt_rle_count_kmers_multi_device`
-  (device batch on replica 0's GPU; shards and counts cross xGMI as peer copies) -- the
-  `GpuRleBWTSet` above; `rle_bwt.count_kmers_multi(...)` in Python.
-* **Multi-GPU, one process per GPU**: `rust-msbwt_amd/sharded.py` (`ShardedCounter`): 16-query-
-  aligned contiguous shards, one `all_gather` of counts over RCCL (`bench.py --gpus N`).
-
-## 5. Error codes
-
-`MSBWT_OK 0`, `MSBWT_ERR_IO -1`, `MSBWT_ERR_UNEXPECTED_EOF -2`, `MSBWT_ERR_BAD_HEADER -3`,
-`MSBWT_ERR_INVALID_SYMBOL -4`, `MSBWT_ERR_INVALID_RANGE -5`, `MSBWT_ERR_HIP -6`,
-`MSBWT_ERR_NOT_LOADED -7`, `MSBWT_ERR_TOO_LARGE -8` (T ≥ 2^40), `MSBWT_ERR_INVALID_ARG -9`,
-`MSBWT_ERR_INTERNAL -10` (a device-side consistency check failed: a bug, never bad input);
-`msbwt_rle_last_error(h)` returns the text (a copy owned by the calling thread).  Device-pointer
-calls are asynchronous; invalid input in them is reported by `msbwt_rle_device_status(h, stream)`,
-which has its own status word (host-pointer calls never see or clear it).  A failed load leaves
-the handle unloaded: total size and symbol counts read 0.
