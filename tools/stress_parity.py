@@ -31,7 +31,11 @@ def main():
     rng = np.random.default_rng(int(os.environ.get("STRESS_SEED", "1")))
     t0 = time.time()
     rounds = checks = 0
+    last_report = t0
     while time.time() - t0 < budget:
+        if time.time() - last_report > 60:  # a silent GPU job is taken for a hung one
+            print("... %d indexes, %d query checks after %.0fs" % (rounds, checks, time.time() - t0), flush=True)
+            last_report = time.time()
         kind = rng.choice(["bwt", "ones", "short", "long", "mixed", "raw"])
         reads = None
         if kind == "bwt":
