@@ -71,9 +71,9 @@ struct msbwt_rle {
 namespace {
 
 constexpr int kMaxTableDepth = 16;  // 4^16 x 16 B = 64 GiB
-constexpr size_t kStatusBytes = 1024;  // flags + debug record (first 128 bytes), then 64 u64 tile-ticket counters
-constexpr size_t kCounterOffset = 512;
-constexpr unsigned kCounters = 64;
+constexpr size_t kCounterOffset = 1024;  // flags + debug record first, then the tile-ticket counters of kCounterSets launches
+constexpr unsigned kCounterSets = 8;
+constexpr size_t kStatusBytes = kCounterOffset + kCounterSets * kTicketBytes;
 constexpr int kHostFlags = 0, kDeviceFlags = 1;  // words of the status block
 
 const char *kVersion = "rust-msbwt_amd 0.1.0 (gfx950 plane-block index)";
@@ -155,9 +155,9 @@ IndexView view_of(msbwt_rle *h) {
     v.pair_stride96 = h->d_pair_blocks && h->pair_stride == 96;
     v.search_kernel = h->search_kernel;
     v.debug = h->d_flags ? reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(h->d_flags) + 64) : nullptr;
-    // one ticket counter per launch, round robin over 64: launches on one stream are ordered anyway, and 64
+    // one set of ticket counters per launch, round robin over 8: launches on one stream are ordered anyway, and 8
     // launches of one handle in flight on different streams at once is beyond any sensible use
-    if (h->d_flags) v.tile_counter = reinterpret_cast<char *>(h->d_flags) + kCounterOffset + 8 * (h->launch_seq++ % kCounters);
+    if (h->d_flags) v.tile_counter = reinterpret_cast<char *>(h->d_flags) + kCounterOffset + kTicketBytes * (h->launch_seq++ % kCounterSets);
     return v;
 }
 

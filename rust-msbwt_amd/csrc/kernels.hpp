@@ -29,6 +29,12 @@ constexpr int kSearchAuto = 0, kSearchGroups = 1, kSearchLanes = 2;
 
 constexpr int kBlocksPlanes = 0, kBlocksRuns = 1;  // IndexView::block_format
 
+// The lanes kernel deals tiles out by atomic tickets.  One address takes only ~7 x 10^7 atomics/s, so a
+// launch uses kTicketCounters counters on separate 128-byte lines (waves are spread over them; counter c
+// hands out tickets c, c + 16, c + 32, ...).
+constexpr int kTicketCounters = 16;
+constexpr size_t kTicketBytes = size_t(kTicketCounters) * 128;
+
 struct IndexView {
     const void *blocks;  // plane blocks (256 positions) or run blocks (512 positions, run_index.hpp), 128 B each
     int block_format = kBlocksPlanes;
@@ -41,7 +47,7 @@ struct IndexView {
     bool pair_stride96 = false;             // pair blocks overlap (start every 96 positions)
     int search_kernel = kSearchAuto;
     uint64_t *debug = nullptr;  // 8 words: [0] != 0 once a consistency check has recorded its values in [1..]
-    void *tile_counter = nullptr;  // u64 ticket counter of the lanes kernel's dynamic tile scheduling (zeroed per launch)
+    void *tile_counter = nullptr;  // kTicketBytes of ticket counters for the lanes kernel's tile dealing (zeroed per launch)
 };
 
 // counts[q] = count_kmer(kmers[q*k .. q*k+k)) for q < n.  Sets kFlagInvalidSymbol in *flags

@@ -176,26 +176,31 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
     // this lane's part in the line fetches: 16 bytes (one chunk) of the line in list slot 8 i + dma_group
     const uint32_t dma_group = lane >> 3, dma_chunk_bytes = ((lane & 7u) ^ dma_group) * 16u;
 
-    // Tiles are dealt out dynamically, `grain` consecutive tiles per atomic ticket (one address takes
-    // only ~10^8 atomics/s: a ticket per tile would cap a human-scale launch), one ticket ahead so
-    // that neither the ticket nor a tile's bytes are ever waited for.  Waves that run slower -- a SIMD
-    // shared with a third wave, a CU shared with an RCCL kernel -- simply take fewer tiles.
-    auto take_ticket = [&]() -> uint64_t {
+    // Tiles are dealt out dynamically, `grain` consecutive tiles per ticket, so that waves that run slower
+    // -- the third wave of a SIMD, more survivors, a CU shared with an RCCL kernel, a workgroup that became
+    // resident late -- simply take fewer (owning a fixed share instead cost 30 % at 12 waves per CU).  A
+    // wave's first ticket is its own index; further ones come from one of kTicketCounters counters
+    // (counter c of n hands out tickets W + c, W + c + n, ...: one address takes only ~7 x 10^7 atomics/s,
+    // which would be most of a SHORT launch's time), taken one segment ahead so that nobody waits for them.
+    const uint32_t ncounters = min(uint32_t(kTicketCounters), max(1u, gridDim.x >> 3));  // every counter in use has waves drawing from it
+    const uint32_t my_counter = (blockIdx.x >> 3) % ncounters;  // consecutive workgroups sit on different XCDs
+    auto take_ticket = [&]() -> uint64_t {  // first tile of this wave's next `grain` tiles (>= ntiles: there are none)
         unsigned long long t = 0;
-        if (lane == 0) t = atomicAdd(tile_counter, 1ull);
-        return ((uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(t >> 32))))) << 32) |
-                uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(t))))) * grain;
+        if (lane == 0) t = atomicAdd(tile_counter + my_counter * 16u, 1ull);
+        const uint64_t drawn = (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(t >> 32))))) << 32) |
+                               uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(t))));
+        return (uint64_t(gridDim.x) + my_counter + drawn * uint64_t(ncounters)) * grain;
     };
-    uint64_t batch = take_ticket(), batch_after = take_ticket();
-    uint32_t in_batch = 0;
-    uint64_t next_tile = batch;          // next tile to set up (its bytes are being fetched)
+    uint64_t next_tile = uint64_t(blockIdx.x) * grain;  // next tile to set up (its bytes are being fetched)
+    uint32_t seg_left = grain;                          // tiles left in the current run of consecutive tiles
+    uint64_t seg_after = take_ticket();
     auto advance_tile = [&]() {
-        if (++in_batch == grain) {
-            batch = batch_after;
-            in_batch = 0;
-            batch_after = take_ticket();
+        ++next_tile;
+        if (--seg_left == 0u) {
+            next_tile = seg_after;
+            seg_left = grain;
+            seg_after = take_ticket();
         }
-        next_tile = batch + in_batch;
     };
     uint32_t ring_head = 0, ring_count = 0;  // wave-uniform
     uint32_t filter_pause = 0;           // as in the tiled kernel: the filter rests while nearly everything passes
@@ -364,10 +369,14 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
             wave_lds_sync();         // every lane has read its staged bytes: the line area may be overwritten
             fetch_tile_bytes(next_tile);  // the following tile's bytes start their trip now
         }
-        if (busy == 0ull) {
-            if (prepared) continue;  // nothing to search yet: go and take the prepared tile (waits for its table entries)
-            break;                   // nothing in flight, nothing waiting, no tiles left
-        }
+        // A search step costs the same whether 5 or 64 lanes take it: while lanes are idle and another
+        // tile is on its way (prepared; the ring is empty then), fetch that tile's survivors first.  When
+        // most queries end in the filter or the table (random k-mers) search steps become rare and full.
+#ifndef MSBWT_LANES_MIN_BUSY
+#define MSBWT_LANES_MIN_BUSY 64
+#endif
+        if (prepared && uint32_t(__popcll(busy)) < uint32_t(MSBWT_LANES_MIN_BUSY)) continue;  // (waits for the tile's table entries)
+        if (busy == 0ull) break;     // nothing in flight, nothing waiting, no tiles left
 
         // ---- D: one search step of every busy lane ----
         const uint32_t s1 = w[0] & 7u, s2 = (w[0] >> 3) & 7u;
@@ -489,7 +498,7 @@ hipError_t launch_variant(hipStream_t stream, const IndexView &ix, const QuerySo
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
     const uint64_t waves = std::min<uint64_t>(tiles, resident_waves<kReads, kPair, kWords, kStride96>());
     if (tiles > kMaxTiles || !ix.tile_counter) return hipErrorInvalidValue;
-    const hipError_t zeroed = hipMemsetAsync(ix.tile_counter, 0, sizeof(unsigned long long), stream);
+    const hipError_t zeroed = hipMemsetAsync(ix.tile_counter, 0, kTicketBytes, stream);
     if (zeroed != hipSuccess) return zeroed;
     // tiles per ticket: about eight tickets per wave at least, sixteen tiles at most
     const uint32_t grain = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(16, tiles / (waves * 8))));

@@ -624,8 +624,9 @@ def test_introspection(search_kernel):
     assert b.device_ordinal() == 0
     assert "gfx950" in msbwt.version()
     # which kernel a batch runs on (bench.py labels its roofline with it)
-    b.set_search_kernel("auto")  # pair index + depth-4 table: long searches go to the lanes kernel
-    assert b.search_kernel_for(31) == "lanes" and b.search_kernel_for(8) == "groups" and b.search_kernel_for(70) == "generic"
+    b.set_search_kernel("auto")  # with a pair index everything but the shortest k-mers goes to the lanes kernel
+    assert b.search_kernel_for(31) == "lanes" and b.search_kernel_for(8) == "lanes" and b.search_kernel_for(4) == "groups"
+    assert b.search_kernel_for(70) == "generic"
     b.set_search_kernel("groups")
     assert b.search_kernel_for(31) == "groups"
     b.set_search_kernel("lanes")
