@@ -194,10 +194,10 @@ int msbwt_rle_get_pair_stride(const msbwt_rle *bwt);
  * Results never change. */
 int msbwt_rle_set_block_format(msbwt_rle *bwt, int format);
 int msbwt_rle_get_block_format(const msbwt_rle *bwt);
-/* Search kernel for 1 <= k <= 64: 0 = automatic (default), 1 = 8 lanes per query, lines in
- * registers (kernels.hip; best when most of a query is decided by the suffix table), 2 = one
- * query per lane, lines staged through LDS by LDS-DMA (lanes.hip; best for long searches -- it
- * keeps 8x more random lines in flight per wave).  MSBWT_SEARCH=groups|lanes in the environment
+/* Search kernel for 1 <= k <= 64: 0 = automatic (default: 2 whenever a pair index exists and k >= 6),
+ * 1 = 8 lanes per query, lines in registers (kernels.hip; one symbol per step; needs no pair index),
+ * 2 = one query per lane, lines staged through LDS by LDS-DMA (lanes.hip; two symbols per step,
+ * 8x more random lines in flight per wave).  MSBWT_SEARCH=groups|lanes in the environment
  * sets the initial mode.  Results never change. */
 int msbwt_rle_set_search_kernel(msbwt_rle *bwt, int mode);
 int msbwt_rle_get_search_kernel(const msbwt_rle *bwt);
