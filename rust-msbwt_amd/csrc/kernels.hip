@@ -63,13 +63,13 @@ __global__ __launch_bounds__(256) void k_count_kmers_generic(const uint4 *__rest
 template <int kWords>
 struct WaveScratchT {
     static constexpr int kMaxK = kWords * 32 / 3;  // 32 or 64
-    uint4 stage[kTile * kMaxK / 16];               // the tile's query bytes (2 or 4 KiB)
+    uint4 stage[kStageLead / 16 + kTile * kMaxK / 16];  // kStageLead free bytes (search_common.hpp), then the tile's query bytes (2 or 4 KiB)
     WorkItemT<kWords> work[kTile];                 // 2 or 3 KiB
     uint64_t result[kTile];                        // 512 B
 };
 
 template <bool kReads, int kWords>
-__global__ __launch_bounds__(256, kWords == 6 ? 5 : 8) void k_count_kmers_tiled(
+__global__ __launch_bounds__(256, kWords == 6 ? 4 : 6) void k_count_kmers_tiled(
     const uint4 *__restrict__ blocks, uint32_t format, const uint4 *__restrict__ overflow, uint64_t total,
     const uint4 *__restrict__ table, uint32_t depth, uint32_t table_packed, const uint32_t *__restrict__ filter,
     uint32_t filter_mask, const QuerySource src, uint32_t *__restrict__ flags) {
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, kWords == 6 ? 5 : 8) void k_count_kmers_tiled(
     const uint32_t group_first_lane = lane & ~uint32_t(kLanes - 1);
     constexpr uint64_t kGroupLeaders = 0x0101010101010101ull;
     Scratch &ws = scratch[threadIdx.x >> 6];
-    const uint8_t *stage_bytes = reinterpret_cast<const uint8_t *>(ws.stage);
+    const uint8_t *stage_bytes = reinterpret_cast<const uint8_t *>(ws.stage) + kStageLead;
 
     const uint64_t ntiles = (n + kTile - 1) / kTile;
     const uint64_t wave_id = uint64_t(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, kWords == 6 ? 5 : 8) void k_count_kmers_tiled(
                 for (int i = 0; i < kPieces; ++i) staged[i] = load_piece(kmers + q0 * k, in_tile * k, lane + 64u * i);
             }
 #pragma unroll
-            for (int i = 0; i < kPieces; ++i) ws.stage[lane + 64u * i] = staged[i];
+            for (int i = 0; i < kPieces; ++i) ws.stage[kStageLead / 16 + lane + 64u * i] = staged[i];
             const uint64_t next_tile = tile + nwaves;
             if (kPrefetch && next_tile < ntiles) {
                 const uint64_t nq0 = next_tile * kTile;
@@ -410,7 +410,7 @@ hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_
         src.k = k;
         src.out_fwd = counts;
         if (use_lanes_kernel(ix, k)) return launch_lanes(ix, src, false, true, flags, stream);
-        launch_tiled<false>(k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, ix, src, flags);
+        launch_tiled<false>(k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64, k > uint32_t(kMaxShortK) ? 4 : 6)), stream, ix, src, flags);
     } else {
         hipLaunchKernelGGL(k_count_kmers_generic, dim3(grid_for(n * kGroup)), dim3(256), 0, stream, blocks, uint32_t(ix.block_format),
                            static_cast<const uint4 *>(ix.overflow), ix.total, kmers, k, n, counts, flags);
@@ -432,10 +432,11 @@ hipError_t launch_count_read_kmers(const IndexView &ix, const uint8_t *reads, ui
     src.ascii = ascii ? 1u : 0u;
     src.out_fwd = out_fwd;
     src.out_rc = out_rc;
+    src.n_reads = n_reads;
     src.n = n_reads * src.windows * (src.strands == 3u ? 2u : 1u);
     if (use_lanes_kernel(ix, k)) return launch_lanes(ix, src, true, true, flags, stream);
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
-    launch_tiled<true>(k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, ix, src, flags);
+    launch_tiled<true>(k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64, k > uint32_t(kMaxShortK) ? 4 : 6)), stream, ix, src, flags);
     return hipGetLastError();
 }
 
@@ -458,7 +459,7 @@ hipError_t launch_count_ragged_read_kmers(const IndexView &ix, const uint8_t *re
     src.n = n_windows * (src.strands == 3u ? 2u : 1u);
     if (use_lanes_kernel(ix, k)) return launch_lanes(ix, src, true, true, flags, stream);
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
-    launch_tiled<true>(k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64)), stream, ix, src, flags);
+    launch_tiled<true>(k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64, k > uint32_t(kMaxShortK) ? 4 : 6)), stream, ix, src, flags);
     return hipGetLastError();
 }
 

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
     const uint32_t k = src.k;
     const uint64_t n = src.n;
     const uint32_t lane = threadIdx.x;
-    const uint8_t *stage_bytes = reinterpret_cast<const uint8_t *>(ws.lines);
+    const uint8_t *stage_bytes = reinterpret_cast<const uint8_t *>(ws.lines) + kStageLead;  // pack_query reads in front of a query
     const uint64_t ntiles = (n + kTile - 1) / kTile;
     const bool use_table = table != nullptr && depth > 0 && k >= depth;
     const TableEnv env{table, depth, use_table, table_packed != 0u, filter, filter_mask, total};
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
             bool looked_up = false, passed = false;
             if (!kReads) {  // the tile's bytes go through LDS (the line area is free between two steps)
 #pragma unroll
-                for (int i = 0; i < kPieces; ++i) ws.lines[lane + 64u * i] = staged_next[i];
+                for (int i = 0; i < kPieces; ++i) ws.lines[kStageLead / 16 + lane + 64u * i] = staged_next[i];
             }
             wave_lds_sync();
             prep_kind = 0;

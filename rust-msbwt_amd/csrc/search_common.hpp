@@ -148,6 +148,17 @@ __device__ __forceinline__ void store_count(const QuerySource &src, uint64_t v, 
 // table lookup: env.table[tidx] behind the presence filter -- issued by the caller, so that the
 //               lanes kernel can leave the load in flight across a search step.
 // unpack_words: drop the table's symbols, hand the rest over as kWords dwords.
+// bits |= value << pos over an array of u64 words (pos is a compile-time constant after unrolling; value < 8)
+template <int kBits>
+__device__ __forceinline__ void constexpr_shift_or(uint64_t (&bits)[kBits], uint32_t value, uint32_t pos) {
+    const uint32_t word = pos >> 6, off = pos & 63u;
+#pragma unroll
+    for (int j = 0; j < kBits; ++j) {
+        if (word == uint32_t(j)) bits[j] |= uint64_t(value) << off;
+        if (j > 0 && word == uint32_t(j - 1) && off > 61u) bits[j] |= uint64_t(value) >> (64u - off);
+    }
+}
+
 template <int kWords>
 struct PackedQuery {
     static constexpr int kBits = (kWords + 1) / 2;
@@ -157,53 +168,77 @@ struct PackedQuery {
     bool acgt;             // steps 0..depth-1 are all ACGT: the table applies
 };
 
+// Bytes kept free in front of a tile's staged query bytes (matrix mode): pack_query reads the 32 or 64
+// bytes that END at a query's last symbol, which for the tile's first queries start before the tile.
+constexpr uint32_t kStageLead = 64;
+
 template <bool kReads, int kWords>
 __device__ __forceinline__ void pack_query(const QuerySource &src, uint32_t depth, const uint8_t *staged, uint64_t v,
                                            PackedQuery<kWords> &pq) {
     constexpr int kBits = PackedQuery<kWords>::kBits;
+    constexpr uint32_t kBlock = kWords == 3 ? 32u : 64u;  // >= k: the bytes of a query arrive as ONE block of wide loads
     const uint32_t k = src.k;
-#pragma unroll
-    for (int j = 0; j < kBits; ++j) pq.bits[j] = 0;
-    uint32_t bad = 0, acgt = 1;
-    uint64_t tidx = 0;
-    const uint8_t *mine = staged;
+    // The search consumes a k-mer from its last symbol: step t reads byte k-1-t of a forward query --
+    // byte kBlock-1-t of the block that ENDS at the query's last byte -- and comp(byte t) of a window
+    // taken as its reverse complement (q'[j] = comp(window[k-1-j])): byte t of the block that STARTS at
+    // the window.  Either way the byte of step t sits at a compile-time place in registers: no
+    // byte-sized load (and its wait) per symbol.
+    uint32_t raw[kBlock / 4];
     bool rc = false;
-    if (kReads) {  // window g of read r, forward or reverse-complemented
+    if (!kReads) {
+        __builtin_memcpy(raw, staged + k - kBlock, kBlock);  // LDS; the caller keeps kStageLead bytes in front of the tile
+    } else {  // window g of read r, forward or reverse-complemented
         const uint64_t g = src.strands == 3u ? (v >> 1) : v;
         rc = src.strands == 3u ? (v & 1u) != 0 : src.strands == 2u;
+        uint64_t first, data_len;  // the window's first byte; bytes in the caller's buffer
         if (src.win_off == nullptr) {
-            mine = src.data + (g / src.windows) * src.read_len + (g % src.windows);
+            first = (g / src.windows) * src.read_len + (g % src.windows);
+            data_len = src.n_reads * src.read_len;
         } else {  // last read whose first window is <= g (reads shorter than k own none)
             uint64_t lo = 0, hi = src.n_reads;
             while (hi - lo > 1) {
                 const uint64_t mid = (lo + hi) >> 1;
                 if (src.win_off[mid] <= g) lo = mid; else hi = mid;
             }
-            mine = src.data + src.read_off[lo] + (g - src.win_off[lo]);
+            first = src.read_off[lo] + (g - src.win_off[lo]);
+            data_len = src.read_off[src.n_reads];
+        }
+        const uint64_t block = rc ? first : first + k - kBlock;  // may lie partly outside the buffer (wraps below 0)
+        if (block + kBlock <= data_len && block <= first) {
+            __builtin_memcpy(raw, src.data + block, kBlock);
+        } else {  // the batch's first / last windows: bytewise, nothing outside the caller's buffer is touched
+#pragma unroll
+            for (uint32_t i = 0; i < kBlock / 4; ++i) raw[i] = 0;
+            for (uint32_t i = 0; i < kBlock; ++i) {
+                const uint64_t at = block + i;  // wraps for bytes in front of the buffer
+                const uint32_t byte = at < data_len ? uint32_t(src.data[at]) : 0u;
+#pragma unroll
+                for (uint32_t j = 0; j < kBlock / 4; ++j)
+                    if ((i >> 2) == j) raw[j] |= byte << ((i & 3u) * 8u);
+            }
         }
     }
-#pragma unroll 4
-    for (uint32_t t = 0; t < k; ++t) {
-        uint32_t s;
-        if (!kReads) {
-            s = mine[k - 1u - t];
-        } else {
-            // the search consumes a k-mer from its last symbol: forward window -> byte k-1-t;
-            // reverse complement q'[j] = comp(window[k-1-j]) -> step t reads comp(window[t])
-            s = rc ? mine[t] : mine[k - 1u - t];
-            if (src.ascii) s = ascii_to_code(s);
-            if (rc) s = complement_code(s);
-        }
-        bad |= (s >= 6u) ? 1u : 0u;
-        const uint32_t pos = 3u * t, word = pos >> 6, off = pos & 63u;
 #pragma unroll
-        for (int j = 0; j < kBits; ++j) {
-            if (word == uint32_t(j)) pq.bits[j] |= uint64_t(s & 7u) << off;
-            if (j > 0 && word == uint32_t(j - 1) && off > 61u) pq.bits[j] |= uint64_t(s & 7u) >> (64u - off);
-        }
-        if (t < depth) {
-            acgt &= acgt_bit(s);
-            tidx |= uint64_t(acgt_code(s) & 3u) << (2u * t);
+    for (int j = 0; j < kBits; ++j) pq.bits[j] = 0;
+    uint32_t bad = 0, acgt = 1;
+    uint64_t tidx = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < kBlock; ++t) {
+        if (t < k) {  // wave-uniform
+            const uint32_t from_end = (raw[(kBlock - 1u - t) >> 2] >> (((kBlock - 1u - t) & 3u) * 8u)) & 0xFFu;
+            uint32_t s = from_end;
+            if (kReads) {
+                const uint32_t from_start = (raw[t >> 2] >> ((t & 3u) * 8u)) & 0xFFu;
+                s = rc ? from_start : from_end;
+                if (src.ascii) s = ascii_to_code(s);
+                if (rc) s = complement_code(s);
+            }
+            bad |= (s >= 6u) ? 1u : 0u;
+            constexpr_shift_or<kBits>(pq.bits, s & 7u, 3u * t);
+            if (t < depth) {
+                acgt &= acgt_bit(s);
+                tidx |= uint64_t(acgt_code(s) & 3u) << (2u * t);
+            }
         }
     }
     pq.tidx = tidx;
@@ -271,10 +306,10 @@ __device__ __forceinline__ bool prepare_query(const QuerySource &src, const Tabl
     return true;
 }
 
-// 256 CUs x 8 blocks of 256 threads fill the chip; smaller batches get just enough blocks
-inline uint32_t grid_for(uint64_t threads_wanted) {
-    const uint64_t blocks = (threads_wanted + 255) / 256;
-    return uint32_t(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
+// 256 CUs x blocks_per_cu resident blocks of 256 threads fill the chip; smaller batches get just enough blocks
+inline uint32_t grid_for(uint64_t threads_wanted, uint32_t blocks_per_cu = 8) {
+    const uint64_t blocks = (threads_wanted + 255) / 256, cap = 256ull * blocks_per_cu;
+    return uint32_t(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
 }
 
 }  // namespace
