@@ -52,8 +52,11 @@ __global__ __launch_bounds__(256) void k_count_kmers_generic(const uint4 *__rest
             if (sub == 0) atomicOr(flags, kFlagInvalidSymbol);
         } else {
             Range r{0, total};
-            for (uint32_t i = k; i-- > 0 && r.l != r.h;) r = constrain_any(format, blocks, overflow, kmer[i], r.l, r.h, sub);
-            result = r.h - r.l;
+            bool broken = false;  // a range outside the index (never seen on a well-formed one) must not become a block address
+            for (uint32_t i = k; i-- > 0 && r.l != r.h && !(broken = r.h > total || r.l > r.h);)
+                r = constrain_any(format, blocks, overflow, kmer[i], r.l, r.h, sub);
+            result = broken ? ~0ull : r.h - r.l;
+            if (broken && sub == 0) atomicOr(flags, kFlagInternal);
         }
         if (sub == 0) counts[q] = result;
     }
@@ -204,6 +207,15 @@ __global__ __launch_bounds__(256, kWords == 6 ? 4 : 6) void k_count_kmers_tiled(
                     busy = __ballot(have);
                 }
                 if (busy == 0ull) break;
+                if (have && (h > total || l > h)) {
+                    // a range outside the index would turn into a wild block address: end such a query with u64::MAX and
+                    // MSBWT_ERR_INTERNAL instead (never seen on a well-formed index; the lanes kernel has the same guard)
+                    if (sub == 0u) {
+                        atomicOr(flags, kFlagInternal);
+                        ws.result[slot] = ~0ull;
+                    }
+                    have = false;
+                }
                 if (have) {
                     const Range r = format == 0u ? constrain_split(blocks, w[0] & 7u, l, h, sub)
                                                  : constrain_any(format, blocks, overflow, w[0] & 7u, l, h, sub);
