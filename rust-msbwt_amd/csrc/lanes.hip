@@ -1,6 +1,6 @@
 // gfx950 (MI355X, CDNA4): count_kmers with ONE QUERY PER LANE and the index lines staged through
-// LDS -- the search kernel for long searches (k-mers with many symbols left after the suffix
-// table), where throughput is set by how many random 128-byte lines are in flight.
+// LDS -- the search kernel for 6 <= k <= 64 on an index with pair blocks (kernels.hip, long_search);
+// throughput is set by how many random 128-byte lines are in flight.
 //
 // The 8-lanes-per-query kernel (kernels.hip) keeps 8 queries x 1-2 lines in flight per wave and
 // pays the whole instruction stream of a step once per 8 queries.  Here a wave is persistent,
@@ -11,7 +11,7 @@
 //      second blocks are compacted with a wave ballot + prefix count into a line list in LDS;
 //   2. the wave fetches every listed line with coalesced LDS-DMA loads (global_load_lds_dwordx4:
 //      8 lanes x 16 B = one line, eight lines per instruction, no VGPRs spent on data in flight)
-//      -- 64..112 lines in flight per wave instead of 8..16;
+//      -- 64..80 lines in flight per wave (64..112 for k > 32) instead of 8..16;
 //   3. after s_waitcnt vmcnt(0) every lane reads its own line(s) back from LDS (bank-conflict
 //      free, see line_base) and ranks both bounds itself: XOR / AND / popcount on the bit planes,
 //      no cross-lane reduction at all.
@@ -20,10 +20,11 @@
 // code (stage the tile's bytes, validate, pack, suffix-table lookup -- the pieces of
 // search_common.hpp) keeps topped up, so all 64 lanes stay busy whatever the mix of early exits.
 // Setup never waits for memory by itself: a tile's bytes are fetched an iteration early and its
-// table entries ride along with the next search step's lines.  Tiles are dealt out by atomic
-// tickets, so slow waves simply take fewer.  Counts go straight to the caller's buffer.
-// Block layouts: plane_index.hpp, rank_ops.hpp.  One wave per workgroup, 17.75 KiB of LDS each;
-// 8 waves per CU (resident_waves).
+// table entries ride along with the next search step's lines; while lanes are idle and a tile is on
+// its way, its survivors are fetched before a search step is spent.  Tiles are dealt out by atomic
+// tickets (sharded counters), so slow waves simply take fewer.  Counts go straight to the caller's
+// buffer.  Block layouts: plane_index.hpp, rank_ops.hpp.  One wave per workgroup, 13.25 KiB of LDS
+// each and 12 waves per CU for k <= 32 (18.4 KiB and 8 for k > 32; kRegionsFor, resident_waves).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
