@@ -204,3 +204,41 @@ def test_run_blocks_decode_back_to_the_bwt(kind):
         assert np.array_equal(got, want), b
     if kind == "ones":
         assert nover.value > 0      # run length 1: 512 pieces per block, every full block overflows
+
+
+def test_sharded_ticket_scheme_covers_every_tile_once():
+    """The lanes kernel's tile dealing (csrc/lanes.hip: a wave's first ticket is its own index, further
+    tickets come from counter c of n as W + c + n * drawn, a wave stops at the first ticket beyond the
+    batch) restated and run with waves advancing in random order: every tile is taken exactly once."""
+    import random
+    rng = random.Random(5)
+    for _ in range(300):
+        waves = rng.choice([1, 5, 8, 9, 64, 127, 128, 200, 3072])
+        tiles = rng.randint(waves, waves * rng.choice([1, 2, 9, 40, 300]))  # the launcher never starts more waves than tiles
+        grain = max(1, min(16, tiles // (waves * 8)))
+        ncounters = min(16, max(1, waves >> 3))
+        counters = [0] * ncounters
+        taken = [0] * tiles
+
+        def draw(w):
+            c = (w >> 3) % ncounters
+            t = counters[c]
+            counters[c] += 1
+            return (waves + c + t * ncounters) * grain
+
+        state = {}  # wave -> [next_tile, seg_left, seg_after]
+        for w in rng.sample(range(waves), waves):  # start-up in any order
+            state[w] = [w * grain, grain, draw(w)]
+        live = list(state)
+        while live:
+            w = rng.choice(live)
+            nxt, left, after = state[w]
+            if nxt >= tiles:
+                live.remove(w)
+                continue
+            taken[nxt] += 1
+            nxt, left = nxt + 1, left - 1
+            if left == 0:
+                nxt, left, after = after, grain, draw(w)
+            state[w] = [nxt, left, after]
+        assert all(t == 1 for t in taken), (waves, tiles, grain)
