@@ -162,6 +162,10 @@ int msbwt_rle_get_table_depth(const msbwt_rle *bwt);
  * msbwt_rle_get_table_depth reports the effective depth (flat depth + 2).  Lines whose deltas do not
  * fit 16 bits are marked and their queries search from scratch.  Results never change. */
 int msbwt_rle_set_table_packed(msbwt_rle *bwt, int mode);
+/* The automatic choice, as a pure function (no device needed): levels of the flat table built first and of
+ * the packed table it becomes (0 = stays flat), for an index of `total_symbols` symbols with `free_hbm_bytes`
+ * of HBM free once plane and pair blocks are in place. */
+int msbwt_auto_table_depths(uint64_t total_symbols, uint64_t free_hbm_bytes, int pair_index, int *flat_depth, int *packed_depth);
 int msbwt_rle_get_table_packed(const msbwt_rle *bwt);
 /* Presence filter: one bit per ACGT suffix of length min(12, table depth), set when some table
  * entry with that suffix is a non-empty range; at most 2 MiB, so it lives in L2 and decides

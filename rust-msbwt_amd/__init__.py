@@ -20,3 +20,15 @@ __all__ = ["BWT", "BWTRange", "RleBWT", "MsbwtError", "string_util", "bwt_conver
 
 def version():
     return _lib.lib().msbwt_version().decode()
+
+
+def auto_table_depths(total_symbols, free_hbm_bytes, pair_index=True):
+    """(flat, packed) levels of the suffix table the library builds by default for an index of that size
+    with that much HBM free after plane and pair blocks (packed 0 = the table stays flat).  Pure host logic."""
+    import ctypes
+    flat, packed = ctypes.c_int(0), ctypes.c_int(0)
+    rc = _lib.lib().msbwt_auto_table_depths(int(total_symbols), int(free_hbm_bytes), 1 if pair_index else 0,
+                                            ctypes.byref(flat), ctypes.byref(packed))
+    if rc:
+        raise MsbwtError(rc, "msbwt_auto_table_depths")
+    return flat.value, packed.value

@@ -58,6 +58,7 @@ SIGNATURES = {
     "msbwt_rle_device_ordinal": (_int, [_vp]),
     "msbwt_rle_last_error": (C.c_char_p, [_vp]),
     "msbwt_version": (C.c_char_p, []),
+    "msbwt_auto_table_depths": (_int, [_u64, _u64, _int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "msbwt_build_plane_blocks": (_sz, [_vp, _sz, _vp, _sz, _pu64]),
     "msbwt_build_run_blocks": (_sz, [_vp, _sz, _vp, _sz, _vp, _sz, _pu64, _pu64]),
     "msbwt_rle_download_blocks": (_sz, [_vp, _vp, _sz]),

@@ -16,6 +16,7 @@
 #include "device_build.hpp"
 #include "host_pipeline.hpp"
 #include "kernels.hpp"
+#include "table_policy.hpp"
 #include "npy_io.hpp"
 #include "pair_index.hpp"
 #include "plane_index.hpp"
@@ -180,19 +181,6 @@ int ensure_stage(msbwt_rle *h, size_t bytes) {
     return MSBWT_OK;
 }
 
-// Chooses the suffix-table depth.  Every search step is at least one random 128-byte line
-// and the memory system serves a fixed number of such lines per second whether they come
-// from HBM or the Infinity Cache (tools/ubench_gather.hip: ~41-50 G lines/s), so each table
-// level removes one or two line fetches per query for the price of memory only -- which is
-// what a 288 GB part has.  Policy: the deepest table that the data warrants (4^depth <= T)
-// within max(1 GiB, 2 x the block array), at most 15 levels (16 GiB).
-int auto_table_depth(uint64_t total, uint64_t block_bytes) {
-    const uint64_t budget = std::max<uint64_t>(uint64_t(1) << 30, 2 * block_bytes);
-    int d = 0;
-    while (d < 15 && (uint64_t(4) << (2 * d)) <= total && (uint64_t(64) << (2 * d)) <= budget) ++d;
-    return d;
-}
-
 // Presence filter over the finished table: 4^min(12, depth) bits (<= 2 MiB, L2-sized).  Kept
 // only if it can reject something (less than 90 % of its bits set) -- on a large genome every
 // 12-mer occurs and the filter would be a wasted lookup.
@@ -234,24 +222,12 @@ int rebuild_table(msbwt_rle *h) {
     h->table_depth = 0;
     h->table_packed = false;
     h->table_bytes = 0;
-    int depth = h->wanted_table_depth < 0 ? auto_table_depth(h->totals.total, h->nblocks * kBlockBytes) : h->wanted_table_depth;
-    if (h->wanted_table_depth < 0 && h->wanted_table_packed != 0 && h->d_pair_blocks) {
-        // Beside a pair index the flat table is only the (temporary) parent of a packed one, two levels
-        // deeper: aim for the deepest packed table -- at most 17 levels, 73 GB -- that the data warrant
-        // (4^p <= 16 T) and HBM allows (as below: its lines take at most half of what is free).  A level
-        // pair removes one search step = one or two random lines per surviving query, and memory is
-        // what a 288 GB part has: C4's 8 GB index gets a 73 GB table and answers 15 % more queries.
+    int depth = h->wanted_table_depth;
+    if (depth < 0) {  // automatic (table_policy.hpp): beside a pair index the flat table is built as deep as the packed one needs
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            for (int p = 17; p - 2 > depth; --p) {
-                const uint64_t flat_b = uint64_t(16) << (2 * (p - 2));
-                if ((uint64_t(1) << (2 * p)) <= 16 * h->totals.total && 2 * packed_table_bytes(p) <= uint64_t(free_b) &&
-                    flat_b + packed_table_bytes(p) <= uint64_t(free_b)) {
-                    depth = p - 2;
-                    break;
-                }
-            }
-        }
+        const bool know_free = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+        depth = choose_table_depths(h->totals.total, h->nblocks * kBlockBytes, know_free ? uint64_t(free_b) : 0, h->d_pair_blocks != nullptr,
+                                    h->wanted_table_packed != 0).flat;
     }
     if (depth <= 0) return MSBWT_OK;
     const size_t bytes = (size_t(1) << (2 * depth)) * 16;
@@ -1078,6 +1054,14 @@ int msbwt_rle_set_block_format(msbwt_rle *h, int format) {
 }
 
 int msbwt_rle_get_block_format(const msbwt_rle *h) { return h ? (h->loaded ? h->block_format : h->wanted_block_format) : 0; }
+
+int msbwt_auto_table_depths(uint64_t total_symbols, uint64_t free_hbm_bytes, int pair_index, int *flat_depth, int *packed_depth) {
+    if (!flat_depth || !packed_depth) return MSBWT_ERR_INVALID_ARG;
+    const TableChoice c = choose_table_depths(total_symbols, plane_block_count(total_symbols) * kBlockBytes, free_hbm_bytes, pair_index != 0, true);
+    *flat_depth = c.flat;
+    *packed_depth = c.packed;
+    return MSBWT_OK;
+}
 
 int msbwt_rle_set_search_kernel(msbwt_rle *h, int mode) {
     if (!h || mode < kSearchAuto || mode > kSearchLanes) return MSBWT_ERR_INVALID_ARG;

@@ -1,0 +1,48 @@
+// Automatic suffix-table depths (host only; no HIP here, so that the CPU suite can pin the policy through
+// msbwt_auto_table_depths).  Every search step is at least one random 128-byte line and the memory
+// system serves a fixed number of such lines per second whether they come from HBM or the Infinity Cache
+// (tools/ubench_granule.hip: 4.86 x 10^10 lines/s), so each table level removes one or two line fetches
+// per surviving query for the price of memory only -- which is what a 288 GB part has.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+
+#include "kernels.hpp"
+
+namespace msbwt {
+
+struct TableChoice {
+    int flat;    // levels of the flat table that is built first (16 bytes per entry); 0 = no table
+    int packed;  // levels of the packed table it is turned into (flat + 2), 0 = the flat table stays
+};
+
+// Flat table: the deepest that the data warrant (4^depth <= T) within max(1 GiB, 2 x the block array),
+// at most 15 levels (16 GiB).
+inline int auto_flat_table_depth(uint64_t total, uint64_t block_bytes) {
+    const uint64_t budget = std::max<uint64_t>(uint64_t(1) << 30, 2 * block_bytes);
+    int d = 0;
+    while (d < 15 && (uint64_t(4) << (2 * d)) <= total && (uint64_t(64) << (2 * d)) <= budget) ++d;
+    return d;
+}
+
+// Beside a pair index the flat table is only the (temporary) parent of a packed one, two levels deeper
+// (kernels.hpp, launch_pack_table): aim for the deepest packed table -- at most 17 levels, 73 GB --
+// that the data warrant (4^p <= 16 T: beyond that nearly every entry is empty) and HBM allows (its
+// lines take at most half of what is free, and parent and packed table fit side by side while packing).
+inline TableChoice choose_table_depths(uint64_t total, uint64_t block_bytes, uint64_t free_bytes, bool pair_index, bool packing_allowed) {
+    TableChoice c{auto_flat_table_depth(total, block_bytes), 0};
+    if (!pair_index || !packing_allowed) return c;
+    const auto fits = [&](int p) {
+        const uint64_t flat_b = uint64_t(16) << (2 * (p - 2));
+        return (uint64_t(1) << (2 * p)) <= 16 * total && 2 * packed_table_bytes(p) <= free_bytes && flat_b + packed_table_bytes(p) <= free_bytes;
+    };
+    for (int p = 17; p - 2 > c.flat; --p)
+        if (fits(p)) {
+            c.flat = p - 2;
+            break;
+        }
+    if (c.flat > 0 && fits(c.flat + 2)) c.packed = c.flat + 2;
+    return c;
+}
+
+}  // namespace msbwt
