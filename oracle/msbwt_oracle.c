@@ -436,13 +436,14 @@ typedef struct {
     size_t k, lo, hi;
     uint64_t *out;
     orc_stats st;
+    int want_stats; /* 0: the loop runs without the byte counters (the timed CPU baseline) */
     int rc;
 } batch_job;
 
 static void *batch_worker(void *arg) {
     batch_job *j = (batch_job *)arg;
     for (size_t q = j->lo; q < j->hi; ++q) {
-        int rc = orc_rle_count_kmer(j->b, j->kmers + q * j->k, j->k, &j->out[q], &j->st);
+        int rc = orc_rle_count_kmer(j->b, j->kmers + q * j->k, j->k, &j->out[q], j->want_stats ? &j->st : NULL);
         if (rc) { j->rc = rc; j->out[q] = UINT64_MAX; }
     }
     return NULL;
@@ -456,7 +457,7 @@ int orc_rle_count_kmers(const orc_rle_bwt *b, const uint8_t *kmers, size_t k, si
     pthread_t *tid = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
     if (!jobs || !tid) { free(jobs); free(tid); return ORC_ERR_IO; }
     for (int t = 0; t < nthreads; ++t) {
-        jobs[t].b = b; jobs[t].kmers = kmers; jobs[t].k = k; jobs[t].out = out;
+        jobs[t].b = b; jobs[t].kmers = kmers; jobs[t].k = k; jobs[t].out = out; jobs[t].want_stats = st != NULL;
         jobs[t].lo = n * (size_t)t / (size_t)nthreads;
         jobs[t].hi = n * (size_t)(t + 1) / (size_t)nthreads;
     }

@@ -52,7 +52,15 @@ struct msbwt_rle {
     int wanted_filter = -1;         // -1 = keep it when it can reject something, 0 = off
     int wanted_table_depth = -1; // -1 = pick from the index size
     int search_kernel = kSearchAuto;
-    unsigned launch_seq = 0;
+    // Tile-ticket counter blocks of the lanes kernel (kernels.hpp, kTicketBytes each): a launch takes a block whose
+    // previous launch has COMPLETED (its event says so) or a new one, so two launches in flight on different
+    // streams never share counters however many there are.
+    struct TicketSlot {
+        void *counters = nullptr;
+        hipEvent_t done = nullptr;
+        bool used = false;  // `done` has been recorded at least once
+    };
+    std::vector<TicketSlot> tickets;
     // device status block (128 bytes): word 0 = flags of the host-pointer entry points (handle
     // stream), word 1 = flags of the *_device entry points (caller streams; read and cleared only by
     // msbwt_rle_device_status), bytes 64.. = 8 x u64 record of a failed device consistency check
@@ -72,9 +80,8 @@ struct msbwt_rle {
 namespace {
 
 constexpr int kMaxTableDepth = 16;  // 4^16 x 16 B = 64 GiB
-constexpr size_t kCounterOffset = 1024;  // flags + debug record first, then the tile-ticket counters of kCounterSets launches
-constexpr unsigned kCounterSets = 8;
-constexpr size_t kStatusBytes = kCounterOffset + kCounterSets * kTicketBytes;
+constexpr size_t kStatusBytes = 1024;  // flag words, debug record, the single-query mailbox's device half
+constexpr size_t kMaxTimedEvents = 256;  // start/stop pairs kept before timed_launch folds them into the running sum
 constexpr int kHostFlags = 0, kDeviceFlags = 1;  // words of the status block
 
 const char *kVersion = "rust-msbwt_amd 0.1.0 (gfx950 plane-block index)";
@@ -156,10 +163,38 @@ IndexView view_of(msbwt_rle *h) {
     v.pair_stride96 = h->d_pair_blocks && h->pair_stride == 96;
     v.search_kernel = h->search_kernel;
     v.debug = h->d_flags ? reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(h->d_flags) + 64) : nullptr;
-    // one set of ticket counters per launch, round robin over 8: launches on one stream are ordered anyway, and 8
-    // launches of one handle in flight on different streams at once is beyond any sensible use
-    if (h->d_flags) v.tile_counter = reinterpret_cast<char *>(h->d_flags) + kCounterOffset + kTicketBytes * (h->launch_seq++ % kCounterSets);
-    return v;
+    return v;  // tile_counter: with_tickets()
+}
+
+// Runs `launch(view)` with a ticket-counter block that no launch still in flight uses, and marks the block busy
+// until everything enqueued on `stream` so far -- the launch included -- has completed.  The caller holds h->mu.
+template <class Launch>
+hipError_t with_tickets(msbwt_rle *h, hipStream_t stream, Launch &&launch) {
+    msbwt_rle::TicketSlot *slot = nullptr;
+    for (auto &s : h->tickets)
+        if (!s.used || hipEventQuery(s.done) == hipSuccess) {
+            slot = &s;
+            break;
+        }
+    (void)hipGetLastError();  // hipErrorNotReady from a busy slot is not an error
+    if (!slot) {
+        msbwt_rle::TicketSlot fresh;
+        hipError_t e = hipMalloc(&fresh.counters, kTicketBytes);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&fresh.done, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            if (fresh.counters) (void)hipFree(fresh.counters);
+            return e;
+        }
+        h->tickets.push_back(fresh);
+        slot = &h->tickets.back();
+    }
+    IndexView v = view_of(h);
+    v.tile_counter = slot->counters;
+    hipError_t e = launch(v);
+    // recorded even after a failed launch: the memset of the counters may already be queued
+    const hipError_t r = hipEventRecord(slot->done, stream);
+    slot->used = true;
+    return e != hipSuccess ? e : r;
 }
 
 int ensure_runtime(msbwt_rle *h) {
@@ -222,54 +257,65 @@ int rebuild_table(msbwt_rle *h) {
     h->table_depth = 0;
     h->table_packed = false;
     h->table_bytes = 0;
+    // Automatic depths come from ONE decision (table_policy.hpp, pinned by a CPU test through
+    // msbwt_auto_table_depths): beside a pair index the flat table is built as deep as the packed one needs.
+    const bool automatic = h->wanted_table_depth < 0;
     int depth = h->wanted_table_depth;
-    if (depth < 0) {  // automatic (table_policy.hpp): beside a pair index the flat table is built as deep as the packed one needs
+    bool pack = h->d_pair_blocks != nullptr && h->wanted_table_packed > 0;  // an explicit depth is packed only on request
+    if (automatic) {
         size_t free_b = 0, total_b = 0;
         const bool know_free = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
-        depth = choose_table_depths(h->totals.total, h->nblocks * kBlockBytes, know_free ? uint64_t(free_b) : 0, h->d_pair_blocks != nullptr,
-                                    h->wanted_table_packed != 0).flat;
+        const TableChoice c = choose_table_depths(h->totals.total, h->nblocks * kBlockBytes, know_free ? uint64_t(free_b) : 0,
+                                                  h->d_pair_blocks != nullptr, h->wanted_table_packed != 0);
+        depth = c.flat;
+        pack = c.packed != 0 || (h->d_pair_blocks != nullptr && h->wanted_table_packed > 0);  // mode 1: whenever a pair index exists
     }
     if (depth <= 0) return MSBWT_OK;
-    const size_t bytes = (size_t(1) << (2 * depth)) * 16;
-    void *tab = nullptr;
-    HIP_TRY(h, hipMalloc(&tab, bytes));
-    IndexView v = view_of(h);
-    hipError_t e = launch_build_table(v, depth, tab, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (e != hipSuccess) {
-        (void)hipFree(tab);
-        if (e == hipErrorNotSupported) return MSBWT_OK;  // kernel set without a table
-        return hip_fail(h, e, "build suffix table");
-    }
-    h->d_table = tab;
-    h->table_depth = depth;
-    h->table_bytes = bytes;
-    int rc = rebuild_filter(h);  // from the flat table, before it may be packed away
-    if (rc) return rc;
+    if (depth + 2 > 18) pack = false;
+    auto build_flat = [&](int d) -> int {
+        const size_t bytes = (size_t(1) << (2 * d)) * 16;
+        void *tab = nullptr;
+        HIP_TRY(h, hipMalloc(&tab, bytes));
+        hipError_t e = launch_build_table(view_of(h), d, tab, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(tab);
+            if (e == hipErrorNotSupported) return MSBWT_OK;  // kernel set without a table
+            return hip_fail(h, e, "build suffix table");
+        }
+        h->d_table = tab;
+        h->table_depth = d;
+        h->table_bytes = bytes;
+        return rebuild_filter(h);  // from the flat table, before it may be packed away
+    };
+    int rc = build_flat(depth);
+    if (rc || !h->d_table || !pack) return rc;
     // Packed form, two levels deeper (kernels.hpp, launch_pack_table): every level removes a line fetch
     // per query, and the first step after a shallow table is the expensive one (wide ranges straddle
-    // blocks).  Needs the pair index; automatic when the data warrants the depth (4^(depth+2) <= 16 T:
-    // measured +3 % on C3, +10 % on C4, +18 % at human scale) and the packed lines take at most half
-    // of the HBM that is free once the flat table is gone.
-    if (!h->d_pair_blocks || h->wanted_table_packed == 0 || depth + 2 > 18) return MSBWT_OK;
+    // blocks).  Needs the pair index.
     const uint64_t pbytes = packed_table_bytes(depth + 2);
-    if (h->wanted_table_packed < 0) {
-        size_t free_b = 0, total_b = 0;
-        if (h->wanted_table_depth >= 0 ||  // an explicit depth is taken literally
-            (uint64_t(1) << (2 * (depth + 2))) > 16 * h->totals.total ||  // most entries would be empty
-            hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
-            2 * pbytes > uint64_t(free_b) + bytes)
-            return MSBWT_OK;
-    }
     void *packed = nullptr;
-    e = hipMalloc(&packed, pbytes);
+    hipError_t e = hipMalloc(&packed, pbytes);
     if (e == hipSuccess) e = launch_pack_table(view_of(h), depth, h->d_table, packed, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
         if (packed) (void)hipFree(packed);
         (void)hipGetLastError();
-        if (h->wanted_table_packed < 0) return MSBWT_OK;  // optional structure: keep the flat table
-        return hip_fail(h, e, "pack suffix table");
+        if (!automatic || h->wanted_table_packed > 0) return hip_fail(h, e, "pack suffix table");
+        // optional structure: the handle keeps a flat table -- within the flat table's OWN budget, not the
+        // deeper parent that was only meant to be packed away
+        const int own = auto_flat_table_depth(h->totals.total, h->nblocks * kBlockBytes);
+        if (own < depth) {
+            if (h->d_filter) (void)hipFree(h->d_filter);
+            h->d_filter = nullptr;
+            h->filter_depth = 0;
+            (void)hipFree(h->d_table);
+            h->d_table = nullptr;
+            h->table_depth = 0;
+            h->table_bytes = 0;
+            return own > 0 ? build_flat(own) : MSBWT_OK;
+        }
+        return MSBWT_OK;
     }
     (void)hipFree(h->d_table);
     h->d_table = packed;
@@ -480,6 +526,26 @@ int flags_to_code(msbwt_rle *h, uint32_t flags) {
     return MSBWT_OK;
 }
 
+// Folds the recorded start/stop pairs into the running sum (waits for the kernels they bracket).
+int drain_timing_events(msbwt_rle *h) {
+    int rc = MSBWT_OK;
+    for (size_t i = 0; i + 1 < h->events.size(); i += 2) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(h->events[i + 1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, h->events[i], h->events[i + 1]);
+        if (e == hipSuccess) {
+            h->timed_ms += ms;
+            h->timed_launches += 1;
+        } else if (!rc) {
+            rc = hip_fail(h, e, "kernel timing events");
+        }
+        (void)hipEventDestroy(h->events[i]);
+        (void)hipEventDestroy(h->events[i + 1]);
+    }
+    h->events.clear();
+    return rc;
+}
+
 // Runs `launch` (which enqueues the count kernel on `stream`); when kernel timing is on, brackets
 // it with HIP events on that same stream (read back by msbwt_rle_kernel_time_ms).
 template <class Launch>
@@ -501,13 +567,14 @@ int timed_launch(msbwt_rle *h, hipStream_t stream, Launch &&launch) {
     }
     h->events.push_back(start);
     h->events.push_back(stop);
+    if (h->events.size() >= 2 * kMaxTimedEvents) return drain_timing_events(h);  // a caller that never reads the timer must not grow this forever
     return MSBWT_OK;
 }
 
 int launch_count(msbwt_rle *h, const uint8_t *d_kmers, size_t k, size_t n, uint64_t *d_out, hipStream_t stream, int which) {
     if (k > 0xFFFFFFFFull) return fail(h, MSBWT_ERR_INVALID_ARG, "k does not fit 32 bits");
     return timed_launch(h, stream, [&] {
-        return launch_count_kmers(view_of(h), d_kmers, uint32_t(k), n, d_out, h->d_flags + which, stream);
+        return with_tickets(h, stream, [&](const IndexView &v) { return launch_count_kmers(v, d_kmers, uint32_t(k), n, d_out, h->d_flags + which, stream); });
     });
 }
 
@@ -523,7 +590,7 @@ msbwt_rle *msbwt_rle_new_on_device(uint8_t bin_power, int device) {
     h->bin_power = bin_power;
     if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;
     h->device = device;
-    if (const char *env = std::getenv("MSBWT_TABLE_DEPTH")) h->wanted_table_depth = std::atoi(env);
+    if (const char *env = std::getenv("MSBWT_TABLE_DEPTH")) h->wanted_table_depth = std::max(-1, std::min(std::atoi(env), kMaxTableDepth));
     if (const char *env = std::getenv("MSBWT_TABLE_PACKED")) h->wanted_table_packed = std::atoi(env) ? 1 : 0;
     if (const char *env = std::getenv("MSBWT_PAIR_INDEX")) h->wanted_pair = std::atoi(env) ? 1 : 0;
     if (const char *env = std::getenv("MSBWT_PAIR_STRIDE")) h->wanted_pair_stride = std::atoi(env);
@@ -542,6 +609,10 @@ void msbwt_rle_free(msbwt_rle *h) {
         DeviceScope scope(h->device);
         release_index(h);
         for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+        for (auto &t : h->tickets) {
+            if (t.done) (void)hipEventDestroy(t.done);
+            if (t.counters) (void)hipFree(t.counters);
+        }
         h->pipe.release();
         if (h->d_stage) (void)hipFree(h->d_stage);
         if (h->d_flags) (void)hipFree(h->d_flags);
@@ -610,9 +681,10 @@ int msbwt_rle_constrain_ranges_device(const msbwt_rle *ch, const void *d_syms, c
 static int launch_read_kmers_locked(msbwt_rle *h, const void *d_reads, size_t read_len, size_t n_reads, size_t k,
                                     int ascii, void *d_out_fwd, void *d_out_rc, hipStream_t stream, int which) {
     return timed_launch(h, stream, [&] {
-        return launch_count_read_kmers(view_of(h), static_cast<const uint8_t *>(d_reads), uint32_t(read_len), n_reads,
-                                       uint32_t(k), ascii != 0, static_cast<uint64_t *>(d_out_fwd),
-                                       static_cast<uint64_t *>(d_out_rc), h->d_flags + which, stream);
+        return with_tickets(h, stream, [&](const IndexView &v) {
+            return launch_count_read_kmers(v, static_cast<const uint8_t *>(d_reads), uint32_t(read_len), n_reads, uint32_t(k), ascii != 0,
+                                           static_cast<uint64_t *>(d_out_fwd), static_cast<uint64_t *>(d_out_rc), h->d_flags + which, stream);
+        });
     });
 }
 
@@ -708,8 +780,10 @@ int msbwt_rle_count_ragged_read_kmers(const msbwt_rle *ch, const uint8_t *reads,
             HIP_TRY(h, hipMemcpyAsync(d_roff, roff.data(), off_bytes, hipMemcpyHostToDevice, h->stream));
             HIP_TRY(h, hipMemcpyAsync(d_woff, woff.data(), off_bytes, hipMemcpyHostToDevice, h->stream));
             rc = timed_launch(h, h->stream, [&] {
-                return launch_count_ragged_read_kmers(view_of(h), d_r, d_roff, d_woff, m, nwin, uint32_t(k), ascii != 0,
-                                                      out_fwd ? d_f : nullptr, out_rc ? d_c : nullptr, h->d_flags, h->stream);
+                return with_tickets(h, h->stream, [&](const IndexView &v) {
+                    return launch_count_ragged_read_kmers(v, d_r, d_roff, d_woff, m, nwin, uint32_t(k), ascii != 0, out_fwd ? d_f : nullptr,
+                                                          out_rc ? d_c : nullptr, h->d_flags, h->stream);
+                });
             });
             if (rc) return rc;
             if (out_fwd) HIP_TRY(h, hipMemcpyAsync(out_fwd + win[r0], d_f, nwin * 8, hipMemcpyDeviceToHost, h->stream));
@@ -941,12 +1015,14 @@ int msbwt_rle_count_kmers_multi_device(const msbwt_rle *const *replicas, size_t 
     const int home = replicas[0]->device;
     const uint8_t *src = static_cast<const uint8_t *>(d_kmers);
     uint64_t *dst = static_cast<uint64_t *>(d_out_counts);
-    // enqueue every shard on its replica's stream: shard in by peer copy, kernel, counts back by peer copy
-    for (size_t r = 0; r < n_replicas; ++r) {
+    // enqueue every shard on its replica's stream: shard in by peer copy, kernel, counts back by peer copy.  An
+    // error ends the enqueueing but NOT the call: the replicas already at work are drained below before the
+    // first error is returned, so that nothing still writes into d_out_counts when the caller gets it back.
+    auto enqueue = [&](size_t r) -> int {
         msbwt_rle *h = const_cast<msbwt_rle *>(replicas[r]);
         size_t lo, hi;
         shard_of(n, n_replicas, r, &lo, &hi);
-        if (hi <= lo) continue;
+        if (hi <= lo) return MSBWT_OK;
         std::lock_guard<std::mutex> lock(h->mu);
         if (!h->loaded) return fail(h, MSBWT_ERR_NOT_LOADED, "no BWT loaded");
         DeviceScope scope(h->device);
@@ -954,23 +1030,21 @@ int msbwt_rle_count_kmers_multi_device(const msbwt_rle *const *replicas, size_t 
         const size_t m = hi - lo;
         // MSBWT_FORCE_PEER_COPIES=1: take the staging + peer-copy path even on the home device (tests on one GPU)
         static const bool force_peer = [] { const char *e = std::getenv("MSBWT_FORCE_PEER_COPIES"); return e && std::atoi(e) != 0; }();
-        if (h->device == home && !(force_peer && r > 0)) {
-            const int rc = launch_count(h, src + lo * k, k, m, dst + lo, h->stream, kHostFlags);
-            if (rc) return rc;
-        } else {
-            const size_t kmer_bytes = (m * k + 255) / 256 * 256;
-            int rc = ensure_stage(h, kmer_bytes + m * sizeof(uint64_t));
-            if (rc) return rc;
-            uint8_t *d_k = static_cast<uint8_t *>(h->d_stage);
-            uint64_t *d_c = reinterpret_cast<uint64_t *>(d_k + kmer_bytes);
-            if (k) HIP_TRY(h, hipMemcpyPeerAsync(d_k, h->device, src + lo * k, home, m * k, h->stream));
-            rc = launch_count(h, d_k, k, m, d_c, h->stream, kHostFlags);
-            if (rc) return rc;
-            HIP_TRY(h, hipMemcpyPeerAsync(dst + lo, home, d_c, h->device, m * sizeof(uint64_t), h->stream));
-        }
-    }
-    // the counts are complete when every replica's stream has drained
+        if (h->device == home && !(force_peer && r > 0)) return launch_count(h, src + lo * k, k, m, dst + lo, h->stream, kHostFlags);
+        const size_t kmer_bytes = (m * k + 255) / 256 * 256;
+        int rc = ensure_stage(h, kmer_bytes + m * sizeof(uint64_t));
+        if (rc) return rc;
+        uint8_t *d_k = static_cast<uint8_t *>(h->d_stage);
+        uint64_t *d_c = reinterpret_cast<uint64_t *>(d_k + kmer_bytes);
+        if (k) HIP_TRY(h, hipMemcpyPeerAsync(d_k, h->device, src + lo * k, home, m * k, h->stream));
+        rc = launch_count(h, d_k, k, m, d_c, h->stream, kHostFlags);
+        if (rc) return rc;
+        HIP_TRY(h, hipMemcpyPeerAsync(dst + lo, home, d_c, h->device, m * sizeof(uint64_t), h->stream));
+        return MSBWT_OK;
+    };
     int first = MSBWT_OK;
+    for (size_t r = 0; r < n_replicas && !first; ++r) first = enqueue(r);
+    // the counts are complete when every replica's stream has drained
     for (size_t r = 0; r < n_replicas; ++r) {
         msbwt_rle *h = const_cast<msbwt_rle *>(replicas[r]);
         std::lock_guard<std::mutex> lock(h->mu);
@@ -1099,16 +1173,8 @@ int msbwt_rle_kernel_time_ms(const msbwt_rle *ch, double *avg_ms, uint64_t *laun
     std::lock_guard<std::mutex> lock(h->mu);
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
-    for (size_t i = 0; i + 1 < h->events.size(); i += 2) {
-        float ms = 0.f;
-        HIP_TRY(h, hipEventSynchronize(h->events[i + 1]));
-        HIP_TRY(h, hipEventElapsedTime(&ms, h->events[i], h->events[i + 1]));
-        h->timed_ms += ms;
-        h->timed_launches += 1;
-        (void)hipEventDestroy(h->events[i]);
-        (void)hipEventDestroy(h->events[i + 1]);
-    }
-    h->events.clear();
+    const int rc = drain_timing_events(h);
+    if (rc) return rc;
     if (avg_ms) *avg_ms = h->timed_launches ? h->timed_ms / double(h->timed_launches) : 0.0;
     if (launches) *launches = h->timed_launches;
     h->timed_ms = 0.0;

@@ -69,7 +69,10 @@ class ShardedCounter:
         torch, dist = self.torch, self.dist
         n = kmers.shape[0]
         lo, hi = shard_bounds(n, self.world, self.rank)
-        mine = self._count_local(kmers[lo:hi])  # a row slice: contiguous, and 16-byte aligned when `kmers` is
+        # the C ABI takes a dense row-major n x k matrix: a strided view (a column slice, an unfold() window view, a
+        # transposed tensor) is copied; a row slice of a contiguous batch is contiguous already -- same storage, and
+        # 16-byte aligned when `kmers` is
+        mine = self._count_local(kmers[lo:hi].contiguous())
         if self.world == 1:
             return mine
         cap = shard_capacity(n, self.world)

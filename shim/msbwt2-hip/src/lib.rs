@@ -102,7 +102,7 @@ impl GpuRleBWT {
     /// Counts of every k-mer window of `n` equal-length ASCII reads, forward strand and reverse
     /// complement, prepared on the GPU (no n x k query matrix).
     pub fn count_read_kmers(&self, reads: &[u8], read_len: usize, k: usize) -> (Vec<u64>, Vec<u64>) {
-        assert!(read_len > 0 && reads.len() % read_len == 0 && k >= 1 && k <= read_len.min(32));
+        assert!(read_len > 0 && reads.len() % read_len == 0 && k >= 1 && k <= read_len.min(64)); // the library takes 1 <= k <= 64
         let n = reads.len() / read_len;
         let w = read_len - k + 1;
         let (mut fwd, mut rc) = (vec![0u64; n * w], vec![0u64; n * w]);
@@ -137,6 +137,7 @@ impl GpuRleBWTSet {
     }
 
     pub fn count_kmers(&self, kmers: &[u8], k: usize) -> Vec<u64> {
+        assert!(k == 0 || kmers.len() % k == 0);
         let n = if k == 0 { 0 } else { kmers.len() / k };
         let raws: Vec<*const MsbwtRle> = self.replicas.iter().map(|r| r.raw as *const MsbwtRle).collect();
         let mut out = vec![0u64; n];

@@ -608,6 +608,38 @@ def test_concurrent_queries_from_host_threads():
         assert np.array_equal(got[i], exp[i])
 
 
+def test_long_launch_on_one_stream_and_many_short_ones_on_another():
+    """Every launch gets tile-ticket counters that no launch still in flight uses: one long *_device
+    launch on stream A, then more short launches on stream B than any fixed pool would hold, all
+    before A has finished.  (A round-robin pool of 8 counter sets let the 9th short launch zero the
+    long launch's counters: tiles were lost silently.)"""
+    torch = pytest.importorskip("torch")
+    reads, rle = _real_bwt(31, 2000, 100)
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    dev = torch.device("cuda:0")
+    k = 31
+    present = np.array([orc.convert_stoi(r[i:i + k]) for r in reads for i in range(0, 70, 3)], dtype=np.uint8)
+    long_q = np.tile(present, (max(1, 4_000_000 // len(present)), 1))          # ~4e6 present 31-mers: a launch of several ms
+    short_q = [np.concatenate([present[j::17][:300], random_kmers(100 + j, 211, k)]) for j in range(24)]
+    d_long = torch.from_numpy(long_q).to(dev)
+    d_short = [torch.from_numpy(q).to(dev) for q in short_q]
+    out_long = torch.full((len(long_q),), -1, dtype=torch.int64, device=dev)
+    out_short = [torch.full((len(q),), -1, dtype=torch.int64, device=dev) for q in short_q]
+    sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    torch.cuda.synchronize(dev)
+    b.count_kmers_device(d_long.data_ptr(), k, len(long_q), out_long.data_ptr(), sa.cuda_stream)
+    for d_q, d_o in zip(d_short, out_short):
+        b.count_kmers_device(d_q.data_ptr(), k, d_q.shape[0], d_o.data_ptr(), sb.cuda_stream)
+    b.device_status(sb.cuda_stream)
+    b.device_status(sa.cuda_stream)
+    exp_present = o.count_kmers(present)
+    assert np.array_equal(out_long.cpu().numpy().astype(np.uint64), np.tile(exp_present, len(long_q) // len(present)))
+    for q, d_o in zip(short_q, out_short):
+        assert np.array_equal(d_o.cpu().numpy().astype(np.uint64), o.count_kmers(q))
+
+
 def test_introspection(search_kernel):
     needs_plane_blocks(search_kernel)
     rle = random_stream(2, 30000, "short")

@@ -53,6 +53,16 @@ def _worker(rank, world, port, n, k, ret):
         got = counter.count_kmers(torch.from_numpy(q))
         exp = ref.count_kmers(q)
         ok = np.array_equal(msbwt.sharded.as_u64(got), exp)
+        # a strided input (column slice of a wider matrix, a transposed matrix): the worker must see a dense copy
+        wide = torch.from_numpy(np.concatenate([q, q[:, ::-1]], axis=1))
+
+        def dense_worker(kmers):
+            assert kmers.is_contiguous()
+            return cpu_worker(kmers)
+
+        strided = ShardedCounter(count_local=dense_worker)
+        ok = ok and np.array_equal(msbwt.sharded.as_u64(strided.count_kmers(wide[:, :k])), exp)
+        ok = ok and np.array_equal(msbwt.sharded.as_u64(strided.count_kmers(torch.from_numpy(np.ascontiguousarray(q.T)).t())), exp)
         # counts that need the int32 and the int64 wire formats (1-mers of a 5000-run stream are large)
         big = np.array([[1], [2], [3], [5], [0]], dtype=np.uint8)
         wide_worker_calls = []
