@@ -185,11 +185,24 @@ int msbwt_rle_get_pair_index(const msbwt_rle *bwt);
 /* Spacing of the pair blocks: 128 = disjoint blocks (1 byte per symbol); 96 = overlapping blocks that
  * also hold the first 32 positions of their successor (1.33 bytes per symbol), so that a range up to
  * 32 wide is ranked from ONE line -- on real 30x data ranges stay ~25 wide to the last step and every
- * fifth step would otherwise fetch a second line.  0 = automatic (default: 96 when that takes at most a
- * quarter of the free HBM; MSBWT_PAIR_STRIDE=96|128 overrides).  get returns 0 without a pair index.
+ * fifth step would otherwise fetch a second line.  0 = automatic (default; MSBWT_PAIR_STRIDE=96|128
+ * overrides): 96 when that takes at most a quarter of the free HBM; otherwise the DATA decide -- the packed
+ * suffix table measures how wide the range of a present k-mer is when its search leaves the table
+ * (msbwt_rle_get_typical_range_width), and disjoint blocks are replaced by overlapping ones when that width
+ * is >= 8 and the bigger blocks fit with an eighth of the HBM to spare.  get returns 0 without a pair index.
  * Results never change. */
 int msbwt_rle_set_pair_stride(msbwt_rle *bwt, int stride);
 int msbwt_rle_get_pair_stride(const msbwt_rle *bwt);
+/* sum(w^2) / sum(w) over the widths w of the packed table's ranges: the width of the range a random PRESENT
+ * suffix finds itself in after `table depth` symbols (~ the coverage on a real read set, ~1-6 on a stream of
+ * independent symbols).  -1 without a packed table. */
+double msbwt_rle_get_typical_range_width(const msbwt_rle *bwt);
+/* The automatic spacing as a pure function (no device needed): for an index of `total_symbols` symbols with
+ * `free_hbm_bytes` free once the plane blocks are in place on a device of `hbm_total_bytes`, the stride the
+ * loader starts with and the one it ends with given the typical range width the packed table reports
+ * (negative = unknown). */
+int msbwt_auto_pair_stride(uint64_t total_symbols, uint64_t free_hbm_bytes, uint64_t hbm_total_bytes, double typical_width,
+                           int *provisional_stride, int *final_stride);
 /* Block format of the index, chosen BEFORE a load (MSBWT_BLOCKS=runs in the environment sets the
  * initial choice): 0 = bit-plane blocks (default: 0.5 byte per symbol, fastest, the only format the
  * pair index and the lane-per-query kernel work on), 1 = run blocks -- the layout of the reference's

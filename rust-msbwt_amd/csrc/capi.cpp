@@ -41,7 +41,8 @@ struct msbwt_rle {
     uint64_t pair_bytes = 0;
     int wanted_pair = -1;           // -1 = on when it fits comfortably, 0 = off, 1 = on
     int pair_stride = 128;          // spacing of the pair blocks in HBM: 128, or 96 (overlapping)
-    int wanted_pair_stride = 0;     // 0 = overlapping when that takes at most a quarter of the free HBM
+    int wanted_pair_stride = 0;     // 0 = automatic (table_policy.hpp: cheap -> 96; else 96 when the data keep ranges wide and it fits)
+    double typical_width = -1.0;    // width of the range a present k-mer leaves the packed table with (-1: no packed table)
     void *d_table = nullptr;
     int table_depth = 0;         // symbols a table entry stands for (of the table currently in HBM)
     bool table_packed = false;   // packed lines (two levels deeper than the flat table it was made from)
@@ -69,6 +70,11 @@ struct msbwt_rle {
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
     HostPipeline pipe;             // pinned, triple-buffered path of the host-pointer batch entry points
+    // Small host batches (the trait's single-query calls above all): queries and results travel through ONE
+    // mapped, coherent host buffer that the kernel reads and writes directly -- no copies, no memset, no flag
+    // read-back; one launch and one stream synchronisation per call.
+    uint8_t *mail = nullptr;       // host address
+    uint8_t *d_mail = nullptr;     // the same buffer as the device sees it
     bool timing = false;
     std::vector<hipEvent_t> events;  // start/stop pairs not yet read back
     double timed_ms = 0.0;
@@ -80,7 +86,8 @@ struct msbwt_rle {
 namespace {
 
 constexpr int kMaxTableDepth = 16;  // 4^16 x 16 B = 64 GiB
-constexpr size_t kStatusBytes = 1024;  // flag words, debug record, the single-query mailbox's device half
+constexpr size_t kStatusBytes = 1024;  // flag words, debug record (bytes 64..128), width statistics of the packed table
+constexpr size_t kWidthStatsOffset = 128;
 constexpr size_t kMaxTimedEvents = 256;  // start/stop pairs kept before timed_launch folds them into the running sum
 constexpr int kHostFlags = 0, kDeviceFlags = 1;  // words of the status block
 
@@ -142,6 +149,7 @@ void release_index(msbwt_rle *h) {
     h->table_depth = 0;
     h->table_packed = false;
     h->table_bytes = 0;
+    h->typical_width = -1.0;
     h->totals = Totals{};  // an unloaded handle reports 0 symbols, not the previous BWT's
     h->loaded = false;
 }
@@ -206,6 +214,27 @@ int ensure_runtime(msbwt_rle *h) {
     return MSBWT_OK;
 }
 
+// mailbox layout (bytes); kMailQueries queries of at most kMailKmerBytes in all
+constexpr size_t kMailQueries = 64, kMailKmerBytes = 4096;
+constexpr size_t kMailKmers = 64, kMailCounts = kMailKmers + kMailKmerBytes, kMailSyms = kMailCounts + 8 * kMailQueries,
+                 kMailL = kMailSyms + 64, kMailH = kMailL + 8 * kMailQueries, kMailOutL = kMailH + 8 * kMailQueries,
+                 kMailOutH = kMailOutL + 8 * kMailQueries, kMailBytes = kMailOutH + 8 * kMailQueries;
+
+int ensure_mail(msbwt_rle *h) {
+    if (h->mail) return MSBWT_OK;
+    void *host = nullptr, *dev = nullptr;
+    HIP_TRY(h, hipHostMalloc(&host, kMailBytes, hipHostMallocMapped));
+    const hipError_t e = hipHostGetDevicePointer(&dev, host, 0);
+    if (e != hipSuccess) {
+        (void)hipHostFree(host);
+        return hip_fail(h, e, "hipHostGetDevicePointer");
+    }
+    std::memset(host, 0, kMailBytes);
+    h->mail = static_cast<uint8_t *>(host);
+    h->d_mail = static_cast<uint8_t *>(dev);
+    return MSBWT_OK;
+}
+
 int ensure_stage(msbwt_rle *h, size_t bytes) {
     if (bytes <= h->stage_bytes) return MSBWT_OK;
     if (h->d_stage) (void)hipFree(h->d_stage);
@@ -257,6 +286,7 @@ int rebuild_table(msbwt_rle *h) {
     h->table_depth = 0;
     h->table_packed = false;
     h->table_bytes = 0;
+    h->typical_width = -1.0;
     // Automatic depths come from ONE decision (table_policy.hpp, pinned by a CPU test through
     // msbwt_auto_table_depths): beside a pair index the flat table is built as deep as the packed one needs.
     const bool automatic = h->wanted_table_depth < 0;
@@ -295,8 +325,11 @@ int rebuild_table(msbwt_rle *h) {
     // blocks).  Needs the pair index.
     const uint64_t pbytes = packed_table_bytes(depth + 2);
     void *packed = nullptr;
+    uint64_t *d_stats = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(h->d_flags) + kWidthStatsOffset), stats[2] = {0, 0};
     hipError_t e = hipMalloc(&packed, pbytes);
-    if (e == hipSuccess) e = launch_pack_table(view_of(h), depth, h->d_table, packed, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_stats, 0, sizeof stats, h->stream);
+    if (e == hipSuccess) e = launch_pack_table(view_of(h), depth, h->d_table, packed, d_stats, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(stats, d_stats, sizeof stats, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
         if (packed) (void)hipFree(packed);
@@ -322,30 +355,32 @@ int rebuild_table(msbwt_rle *h) {
     h->table_depth = depth + 2;
     h->table_packed = true;
     h->table_bytes = pbytes;
+    h->typical_width = typical_range_width(stats[0], stats[1]);
     return MSBWT_OK;
 }
 
 // Pair index (two symbols per step, rank_ops.hpp): 1 byte/symbol on top of the plane blocks,
 // built on the device from them.  Default policy: build it when it fits in half of what is
 // still free in HBM after the blocks (it is a pure speed-for-memory trade).
-int rebuild_pair_index(msbwt_rle *h) {
+int rebuild_pair_index(msbwt_rle *h, int forced_stride = 0) {
     if (h->d_pair_blocks) (void)hipFree(h->d_pair_blocks);
     if (h->d_pair_super) (void)hipFree(h->d_pair_super);
     h->d_pair_blocks = h->d_pair_super = nullptr;
     h->pair_bytes = 0;
     if (h->wanted_pair == 0 || h->totals.total == 0 || h->block_format != kBlocksPlanes) return MSBWT_OK;  // built from plane blocks
-    // Overlapping blocks (stride 96, 1.33 bytes per symbol) rank ranges up to 32 wide from one line:
-    // taken when they are cheap in HBM (a quarter of what is free), e.g. C3 / C4-sized indexes; a
-    // human-scale index keeps stride 128 (90 GB instead of 120 GB).
+    // Spacing (table_policy.hpp): an explicit wish is taken literally; otherwise overlapping blocks (stride 96,
+    // 1.33 bytes per symbol: ranges up to 32 wide from one line) when they are cheap in HBM, disjoint ones for
+    // now when they are not -- widen_pair_blocks_if_warranted() looks again once the packed table knows how
+    // wide the data keep their ranges.
     size_t free_b = 0, total_b = 0;
     const bool know_free = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
-    int stride = h->wanted_pair_stride;
+    int stride = forced_stride ? forced_stride : h->wanted_pair_stride;
     if (stride != 96 && stride != 128) {
         const PairIndexSizes wide = pair_index_sizes(h->nblocks, 96);
-        stride = (know_free && wide.pair_block_bytes + wide.scratch_bytes <= free_b / 4) ? 96 : 128;
+        stride = know_free ? provisional_pair_stride(wide.pair_block_bytes + wide.super_bytes + wide.scratch_bytes, free_b) : 128;
     }
     const PairIndexSizes sz = pair_index_sizes(h->nblocks, stride);
-    if (h->wanted_pair < 0) {
+    if (h->wanted_pair < 0 && !forced_stride) {  // (a forced stride comes from the policy, which has checked the fit)
         if (!know_free || sz.pair_block_bytes + sz.scratch_bytes > free_b / 2) return MSBWT_OK;
     }
     void *scratch = nullptr;
@@ -365,6 +400,24 @@ int rebuild_pair_index(msbwt_rle *h) {
     h->pair_stride = stride;
     h->pair_bytes = sz.pair_block_bytes + sz.super_bytes;
     return MSBWT_OK;
+}
+
+// The second look at the pair spacing (table_policy.hpp, final_pair_stride): the packed table has just measured
+// how wide a present k-mer's range is when it leaves the table.  Disjoint blocks chosen for lack of HBM are
+// replaced by overlapping ones when the data keep ranges wide and the bigger blocks fit next to the table.  The
+// table itself holds ranges, not block addresses: it stays.
+int widen_pair_blocks_if_warranted(msbwt_rle *h) {
+    if (!h->d_pair_blocks || h->wanted_pair_stride == 96 || h->wanted_pair_stride == 128 || h->pair_stride != 128) return MSBWT_OK;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return MSBWT_OK;
+    const PairIndexSizes wide = pair_index_sizes(h->nblocks, 96), now = pair_index_sizes(h->nblocks, 128);
+    const int stride = final_pair_stride(128, h->typical_width, wide.pair_block_bytes + wide.super_bytes + wide.scratch_bytes, free_b,
+                                         now.pair_block_bytes + now.super_bytes, uint64_t(total_b) / 8);
+    if (stride == 128) return MSBWT_OK;
+    const int rc = rebuild_pair_index(h, 96);
+    if (rc == MSBWT_OK && h->d_pair_blocks) return MSBWT_OK;
+    (void)hipGetLastError();
+    return rebuild_pair_index(h, 128);  // did not fit after all: back to what there was
 }
 
 // Index build on the host (kept for MSBWT_BUILD=host and for cross-checking the device
@@ -491,12 +544,18 @@ int install(msbwt_rle *h, const uint8_t *rle, size_t n) {
     if (!rc) stage(h->pair_stride == 96 ? "pair blocks, stride 96" : "pair blocks, stride 128", h->pair_bytes);
     if (!rc) rc = rebuild_table(h);
     if (!rc) stage(h->table_packed ? "suffix table, packed" : "suffix table, flat", h->table_bytes);
+    if (!rc) {
+        const int before = h->pair_stride;
+        rc = widen_pair_blocks_if_warranted(h);
+        if (!rc && h->pair_stride != before) stage("pair blocks -> stride 96", h->pair_bytes);
+    }
     if (rc) {
         release_index(h);
         return rc;
     }
     if (verbose)
-        std::fprintf(stderr, "[msbwt] load: %llu symbols, table depth %d, %.2f GB of HBM in all\n", (unsigned long long)t.total, h->table_depth,
+        std::fprintf(stderr, "[msbwt] load: %llu symbols, table depth %d, typical range width after the table %.1f, %.2f GB of HBM in all\n",
+                     (unsigned long long)t.total, h->table_depth, h->typical_width,
                      double(h->nblocks * kBlockBytes + h->overflow_bytes + h->pair_bytes + h->table_bytes) / 1e9);
     h->err.clear();
     return MSBWT_OK;
@@ -614,6 +673,7 @@ void msbwt_rle_free(msbwt_rle *h) {
             if (t.counters) (void)hipFree(t.counters);
         }
         h->pipe.release();
+        if (h->mail) (void)hipHostFree(h->mail);
         if (h->d_stage) (void)hipFree(h->d_stage);
         if (h->d_flags) (void)hipFree(h->d_flags);
         if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -818,6 +878,32 @@ int msbwt_rle_count_kmers(const msbwt_rle *ch, const uint8_t *kmers, size_t k, s
     if (n && (!out_counts || (!kmers && k))) return fail(h, MSBWT_ERR_INVALID_ARG, "null pointer");
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    if (n == 0) return MSBWT_OK;
+    if (n <= kMailQueries && n * k <= kMailKmerBytes) {
+        // the trait's single-query shape (msbwt_core.rs:124: one k-mer per call) and other tiny batches: through the
+        // mailbox.  Every error ends its query with u64::MAX -- no real count is that large -- so the status word is
+        // only read back when one shows up.
+        int rc = ensure_runtime(h);
+        if (!rc) rc = ensure_mail(h);
+        if (rc) return rc;
+        if (k) std::memcpy(h->mail + kMailKmers, kmers, n * k);
+        uint64_t *counts = reinterpret_cast<uint64_t *>(h->mail + kMailCounts);
+        rc = timed_launch(h, h->stream, [&] {
+            return launch_count_kmers(view_of(h), h->d_mail + kMailKmers, uint32_t(k), n, reinterpret_cast<uint64_t *>(h->d_mail + kMailCounts),
+                                      h->d_flags + kHostFlags, h->stream);  // no ticket counters: at most one tile
+        });
+        if (rc) return rc;
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        bool flagged = false;
+        for (size_t i = 0; i < n; ++i) {
+            out_counts[i] = counts[i];
+            flagged |= counts[i] == ~0ull;
+        }
+        if (!flagged) return MSBWT_OK;
+        uint32_t flags = 0;
+        rc = read_flags(h, h->stream, kHostFlags, &flags);
+        return rc ? rc : flags_to_code(h, flags);
+    }
     // pipelined: chunks of 2 Mi queries travel host -> pinned -> HBM -> pinned -> host, copies and
     // kernels overlapping on three streams (host_pipeline.hpp)
     std::vector<HostArray> ins(1), outs(1);
@@ -848,6 +934,30 @@ int msbwt_rle_constrain_ranges(const msbwt_rle *ch, const uint8_t *syms, const u
     if (n && (!syms || !l || !hh || !out_l || !out_h)) return fail(h, MSBWT_ERR_INVALID_ARG, "null pointer");
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    if (n == 0) return MSBWT_OK;
+    if (n <= kMailQueries) {  // BWT::constrain_range, one range per call (msbwt_core.rs:99): through the mailbox, as above
+        int rc = ensure_runtime(h);
+        if (!rc) rc = ensure_mail(h);
+        if (rc) return rc;
+        std::memcpy(h->mail + kMailSyms, syms, n);
+        std::memcpy(h->mail + kMailL, l, n * sizeof(uint64_t));
+        std::memcpy(h->mail + kMailH, hh, n * sizeof(uint64_t));
+        HIP_TRY(h, launch_constrain_ranges(view_of(h), h->d_mail + kMailSyms, reinterpret_cast<const uint64_t *>(h->d_mail + kMailL),
+                                           reinterpret_cast<const uint64_t *>(h->d_mail + kMailH), n, reinterpret_cast<uint64_t *>(h->d_mail + kMailOutL),
+                                           reinterpret_cast<uint64_t *>(h->d_mail + kMailOutH), h->d_flags + kHostFlags, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        const uint64_t *ol = reinterpret_cast<const uint64_t *>(h->mail + kMailOutL), *oh = reinterpret_cast<const uint64_t *>(h->mail + kMailOutH);
+        bool flagged = false;
+        for (size_t i = 0; i < n; ++i) {
+            out_l[i] = ol[i];
+            out_h[i] = oh[i];
+            flagged |= ol[i] == ~0ull;  // an invalid symbol or range ends as {u64::MAX, u64::MAX}
+        }
+        if (!flagged) return MSBWT_OK;
+        uint32_t flags = 0;
+        rc = read_flags(h, h->stream, kHostFlags, &flags);
+        return rc ? rc : flags_to_code(h, flags);
+    }
     std::vector<HostArray> ins(3), outs(2);
     ins[0].in = syms; ins[0].item_bytes = 1;
     ins[1].in = l; ins[1].item_bytes = sizeof(uint64_t);
@@ -941,6 +1051,7 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
     h->table_depth = src->table_depth;
     h->table_packed = src->table_packed;
     h->table_bytes = src->table_bytes;
+    h->typical_width = src->typical_width;
     h->filter_depth = src->filter_depth;
     h->pair_bytes = src->pair_bytes;
     h->loaded = true;
@@ -1077,8 +1188,9 @@ int msbwt_rle_set_pair_index(msbwt_rle *h, int mode) {
     if (!h->loaded) return MSBWT_OK;
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
-    const int rc = rebuild_pair_index(h);
-    return rc ? rc : rebuild_table(h);  // the table's packed form exists only beside a pair index
+    int rc = rebuild_pair_index(h);
+    if (!rc) rc = rebuild_table(h);  // the table's packed form exists only beside a pair index
+    return rc ? rc : widen_pair_blocks_if_warranted(h);
 }
 
 int msbwt_rle_get_pair_index(const msbwt_rle *h) { return (h && h->d_pair_blocks) ? 1 : 0; }
@@ -1090,8 +1202,9 @@ int msbwt_rle_set_pair_stride(msbwt_rle *h, int stride) {
     if (!h->loaded) return MSBWT_OK;
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
-    const int rc = rebuild_pair_index(h);
-    return rc ? rc : rebuild_table(h);
+    int rc = rebuild_pair_index(h);
+    if (!rc) rc = rebuild_table(h);
+    return rc ? rc : widen_pair_blocks_if_warranted(h);
 }
 
 int msbwt_rle_get_pair_stride(const msbwt_rle *h) { return (h && h->d_pair_blocks) ? h->pair_stride : 0; }
@@ -1136,6 +1249,25 @@ int msbwt_auto_table_depths(uint64_t total_symbols, uint64_t free_hbm_bytes, int
     *packed_depth = c.packed;
     return MSBWT_OK;
 }
+
+int msbwt_auto_pair_stride(uint64_t total_symbols, uint64_t free_hbm_bytes, uint64_t hbm_total_bytes, double typical_width,
+                           int *provisional_stride, int *final_stride) {
+    if (!provisional_stride || !final_stride) return MSBWT_ERR_INVALID_ARG;
+    const uint64_t nblocks = plane_block_count(total_symbols);
+    const PairIndexSizes wide = pair_index_sizes(nblocks, 96), narrow = pair_index_sizes(nblocks, 128);
+    const uint64_t bytes96 = wide.pair_block_bytes + wide.super_bytes + wide.scratch_bytes, bytes128 = narrow.pair_block_bytes + narrow.super_bytes;
+    *provisional_stride = *final_stride = provisional_pair_stride(bytes96, free_hbm_bytes);
+    if (*provisional_stride == 96) return MSBWT_OK;
+    // the same sequence the loader goes through: disjoint blocks, the table beside them, then the second look
+    const uint64_t free2 = free_hbm_bytes > bytes128 ? free_hbm_bytes - bytes128 : 0;
+    const TableChoice c = choose_table_depths(total_symbols, nblocks * kBlockBytes, free2, true, true);
+    const uint64_t table_bytes = c.packed ? packed_table_bytes(c.packed) : (c.flat ? uint64_t(16) << (2 * c.flat) : 0);
+    const uint64_t free3 = free2 > table_bytes ? free2 - table_bytes : 0;
+    *final_stride = final_pair_stride(128, c.packed ? typical_width : -1.0, bytes96, free3, bytes128, hbm_total_bytes / 8);
+    return MSBWT_OK;
+}
+
+double msbwt_rle_get_typical_range_width(const msbwt_rle *h) { return h ? h->typical_width : -1.0; }
 
 int msbwt_rle_set_search_kernel(msbwt_rle *h, int mode) {
     if (!h || mode < kSearchAuto || mode > kSearchLanes) return MSBWT_ERR_INVALID_ARG;

@@ -301,8 +301,12 @@ __device__ __forceinline__ uint64_t pair_bound_thread(const uint4 *__restrict__ 
 // (t mod 4^flat_depth) by the two symbols in t's top four bits, t = 30 line + i.
 __global__ __launch_bounds__(256) void k_table_pack(const uint4 *__restrict__ flat, uint32_t flat_depth,
                                                     const uint4 *__restrict__ pair_blocks, const uint64_t *__restrict__ pair_super,
-                                                    uint32_t stride96, uint32_t *__restrict__ packed, uint64_t nlines) {
+                                                    uint32_t stride96, uint32_t *__restrict__ packed, uint64_t nlines,
+                                                    unsigned long long *__restrict__ stats) {
     const uint32_t lane = threadIdx.x & 63u, i = lane & 31u, team_first = lane & 32u;
+    // stats[0] += sum of range widths w, stats[1] += sum of w x min(w, 65535): their quotient is the width of the
+    // range a random present suffix finds itself in once the table has been consumed (table_policy.hpp)
+    uint64_t sum_w = 0, sum_ww = 0;
     const uint64_t entries = 1ull << (2u * (flat_depth + 2u)), parent_mask = (1ull << (2u * flat_depth)) - 1ull;
     const uint64_t nteams = (uint64_t(gridDim.x) * blockDim.x) / 32;
     for (uint64_t line = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) / 32; line < nlines; line += nteams) {
@@ -320,6 +324,10 @@ __global__ __launch_bounds__(256) void k_table_pack(const uint4 *__restrict__ fl
             }
         }
         const bool nonempty = valid && l != h;
+        if (nonempty) {
+            sum_w += h - l;
+            sum_ww += (h - l) * min(h - l, uint64_t(65535));
+        }
         // base = the first non-empty range's l (ranges of consecutive indices are consecutive, so l is monotone)
         const uint64_t ne = __ballot(nonempty);
         const uint32_t mine32 = uint32_t(ne >> team_first);
@@ -335,6 +343,16 @@ __global__ __launch_bounds__(256) void k_table_pack(const uint4 *__restrict__ fl
             const uint64_t b = (mine32 ? base : 0ull) | (escape ? kPackedEscape : 0ull);
             out[0] = uint32_t(b);
             out[1] = uint32_t(b >> 32);
+        }
+    }
+    if (stats != nullptr) {  // one pair of atomics per wave, once
+        for (int d = 32; d >= 1; d >>= 1) {
+            sum_w += (uint64_t(uint32_t(__shfl_xor(int(uint32_t(sum_w >> 32)), d))) << 32) | uint32_t(__shfl_xor(int(uint32_t(sum_w)), d));
+            sum_ww += (uint64_t(uint32_t(__shfl_xor(int(uint32_t(sum_ww >> 32)), d))) << 32) | uint32_t(__shfl_xor(int(uint32_t(sum_ww)), d));
+        }
+        if (lane == 0u && sum_w != 0ull) {
+            atomicAdd(stats, sum_w);
+            atomicAdd(stats + 1, sum_ww);
         }
     }
 }
@@ -499,12 +517,12 @@ hipError_t launch_build_table(const IndexView &ix, int depth, void *entries, hip
 }
 
 hipError_t launch_pack_table(const IndexView &ix, int flat_depth, const void *flat_entries, void *packed_entries,
-                             hipStream_t stream) {
+                             uint64_t *d_width_stats, hipStream_t stream) {
     if (flat_depth < 1 || flat_depth > 16 || !ix.pair_blocks || !ix.pair_super) return hipErrorInvalidValue;
     const uint64_t nlines = packed_table_bytes(flat_depth + 2) / 128;
     hipLaunchKernelGGL(k_table_pack, dim3(grid_for(nlines * 32)), dim3(256), 0, stream, static_cast<const uint4 *>(flat_entries),
                        uint32_t(flat_depth), static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, ix.pair_stride96 ? 1u : 0u,
-                       static_cast<uint32_t *>(packed_entries), nlines);
+                       static_cast<uint32_t *>(packed_entries), nlines, reinterpret_cast<unsigned long long *>(d_width_stats));
     return hipGetLastError();
 }
 

@@ -83,8 +83,10 @@ hipError_t launch_build_table(const IndexView &ix, int depth, void *entries, hip
 // Packs a finished FLAT table of `flat_depth` levels into a PACKED table two levels deeper
 // (`packed_entries`: ceil(4^(flat_depth+2) / 30) lines of 128 bytes): every entry is extended by
 // one two-symbol step of the pair index (required).  Returns the packed size through the helper.
+// d_width_stats (optional, 2 x u64, zeroed by the caller): += sum of the packed ranges' widths w, += sum of
+// w x min(w, 65535) -- what the pair-stride policy reads (table_policy.hpp, typical_range_width).
 hipError_t launch_pack_table(const IndexView &ix, int flat_depth, const void *flat_entries, void *packed_entries,
-                             hipStream_t stream);
+                             uint64_t *d_width_stats, hipStream_t stream);
 inline uint64_t packed_table_bytes(int depth) { return ((uint64_t(1) << (2 * depth)) + 29) / 30 * 128; }
 // filter (zero-filled, 4^filter_depth bits) from a finished table of `depth` levels
 hipError_t launch_build_filter(const void *entries, int depth, int filter_depth, uint32_t *filter, hipStream_t stream);

@@ -23,8 +23,11 @@
 // table entries ride along with the next search step's lines; while lanes are idle and a tile is on
 // its way, its survivors are fetched before a search step is spent.  Tiles are dealt out by atomic
 // tickets (sharded counters), so slow waves simply take fewer.  Counts go straight to the caller's
-// buffer.  Block layouts: plane_index.hpp, rank_ops.hpp.  One wave per workgroup, 13.25 KiB of LDS
-// each and 12 waves per CU for k <= 32 (18.4 KiB and 8 for k > 32; kRegionsFor, resident_waves).
+// buffer.  Block layouts: plane_index.hpp, rank_ops.hpp.  One wave per workgroup, 12.1 KiB of LDS
+// (k <= 32) or 12.9 KiB (k <= 64) each: 12 waves per CU either way (kRegionsFor, resident_waves).
+// Fused query preparation (kReads): the bytes a tile of consecutive read windows spans are converted
+// to symbol codes ONCE per read symbol and staged in LDS, forward and reverse-complemented, so that a
+// window is packed exactly like a row of a query matrix (stage_read_span).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -47,15 +50,25 @@ constexpr int kRing = 64;        // undecided queries waiting for a lane: one ti
 // throughput follows: measured at human scale (tools/sweep_variants.sh), 14 regions / 8 waves per CU
 // 5.05, 12 / 10 4.88 (uneven SIMDs), 10 / 8 4.77, 10 / 12 5.32 x 10^9 q/s -- sixteen second-line slots
 // cost 7 % (the queries of a tile take their first, widest step together), four more waves bring 13 %.
-// Searches of k > 32 carry 3 KiB of ring: they keep 14 regions and 8 waves.
+// Round 3: ring entries shrank to 24 / 36 bytes (RingItemT) and the line list moved INTO the line area,
+// so searches of k > 32 fit the same 10 regions and 12 waves (they had 14 regions and 8 waves).
 #ifdef MSBWT_LANES_REGIONS  // experiments
 template <int kWords> constexpr int kRegionsFor = MSBWT_LANES_REGIONS;
 #else
-template <int kWords> constexpr int kRegionsFor = kWords == 3 ? 10 : 14;
+template <int kWords> constexpr int kRegionsFor = 10;
 #endif
 #ifndef MSBWT_LANES_WAVE_CAP
 #define MSBWT_LANES_WAVE_CAP 12
 #endif
+
+// One undecided query waiting in the ring: 24 bytes (k <= 32) or 36 (k <= 64).  The ring only ever holds
+// queries of ONE tile (it is refilled when empty), so the tile index is a wave-uniform register, not a field.
+template <int kWords>
+struct RingItemT {
+    uint32_t l_lo, h_lo;
+    uint32_t meta;        // l >> 32 (8 bits) | h >> 32 (8 bits) << 8 | remaining steps << 16 | lane in the tile << 24
+    uint32_t w[kWords];   // remaining symbols, 3 bits each, next step in the low bits
+};
 
 template <int kWords>
 struct LaneScratchT {
@@ -68,11 +81,13 @@ struct LaneScratchT {
     // region_base(i): every odd region is pushed 128 bytes further, so that the 64 lanes'
     // read-back of "chunk j of my line" touches every bank exactly once per 16 lanes (lanes 16 m ..
     // 16 m + 15 own the lines of regions 2 m and 2 m + 1, whose bank phases differ by 128 bytes).
-    // During phase 1 the same memory stages the tile's query bytes (2 or 4 KiB).
-    uint4 lines[(kRegions / 2) * 136];   // 10.6 or 14.9 KiB
-    uint64_t list[kLineSlots];        // this step's line addresses (640 or 896 B)
-    WorkItemT<kWords> ring[kRing];    // 2 or 3 KiB
+    // Between two steps the same memory stages the tile's query bytes (2 or 4 KiB; reads mode: 512 B of
+    // symbol codes), and at the start of a step its first 640 bytes hold the step's line addresses: they
+    // are in registers (s_waitcnt lgkmcnt(0)) before the first LDS-DMA load is issued.
+    uint4 lines[(kRegions / 2) * 136];   // 10.6 KiB
+    RingItemT<kWords> ring[kRing];       // 1.5 or 2.25 KiB
 };
+static_assert(sizeof(LaneScratchT<6>) <= 160 * 1024 / 12, "12 one-wave workgroups per CU");
 
 // uint4 index of the first of region i's 64 sixteen-byte pieces: pairs of regions take 136 pieces,
 // the odd one starting 72 in (64 + 8 of padding)
@@ -161,7 +176,7 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
                                                           uint32_t *__restrict__ flags, uint64_t *__restrict__ debug,
                                                           unsigned long long *__restrict__ tile_counter, uint32_t grain) {
     using Scratch = LaneScratchT<kWords>;
-    using WorkItem = WorkItemT<kWords>;
+    using RingItem = RingItemT<kWords>;
     constexpr int kPieces = Scratch::kMaxK / 16;  // 16-byte pieces of a tile per lane: 2 or 4
     constexpr int kRegions = Scratch::kRegions, kLineSlots = Scratch::kLineSlots;
     constexpr uint32_t kMaxSecond = Scratch::kMaxSecond;
@@ -185,7 +200,13 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
     // which would be most of a SHORT launch's time), taken one segment ahead so that nobody waits for them.
     const uint32_t ncounters = min(uint32_t(kTicketCounters), max(1u, gridDim.x >> 3));  // every counter in use has waves drawing from it
     const uint32_t my_counter = (blockIdx.x >> 3) % ncounters;  // consecutive workgroups sit on different XCDs
+    uint64_t static_next = (uint64_t(blockIdx.x) + gridDim.x) * grain;  // tile_counter == nullptr (small launches: no memset, no atomics): static striding
     auto take_ticket = [&]() -> uint64_t {  // first tile of this wave's next `grain` tiles (>= ntiles: there are none)
+        if (tile_counter == nullptr) {
+            const uint64_t t = static_next;
+            static_next += uint64_t(gridDim.x) * grain;
+            return t;
+        }
         unsigned long long t = 0;
         if (lane == 0) t = atomicAdd(tile_counter + my_counter * 16u, 1ull);
         const uint64_t drawn = (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(t >> 32))))) << 32) |
@@ -204,6 +225,7 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
         }
     };
     uint32_t ring_head = 0, ring_count = 0;  // wave-uniform
+    uint64_t ring_tile = 0;                  // the tile whose queries are in the ring
     uint32_t filter_pause = 0;           // as in the tiled kernel: the filter rests while nearly everything passes
 
     // the lane's running query
@@ -224,12 +246,40 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
     uint4 staged_next[kPieces];
 #pragma unroll
     for (int i = 0; i < kPieces; ++i) staged_next[i] = make_uint4(0, 0, 0, 0);
+    // Reads mode, fixed read length, at least a tile's worth of windows per read (launch-uniform): a tile of
+    // consecutive windows lies in at most two reads, so the bytes it spans -- its windows + k - 1, twice
+    // that tail across a read border: at most 64 + 2 x 63 = 190 -- are ONE dword per lane.  staged_n0 =
+    // how many of the tile's windows still belong to the first of the two reads.
+    const uint32_t wshift = (kReads && src.strands == 3u) ? 1u : 0u;  // both strands: two queries per window
+    const uint32_t tile_windows = uint32_t(kTile) >> wshift;
+    const bool reads_fast = kReads && src.win_off == nullptr && src.windows >= tile_windows;
+    const double inv_windows = kReads ? 1.0 / double(src.windows) : 0.0;
+    uint32_t staged_n0 = 0;  // wave-uniform
     auto fetch_tile_bytes = [&](uint64_t tile) {
-        if (!kReads && tile < ntiles) {
+        if (tile >= ntiles) return;
+        if (!kReads) {
             const uint64_t q0 = tile * kTile;
             const uint32_t nbytes = uint32_t(min(uint64_t(kTile), n - q0)) * k;
 #pragma unroll
             for (int i = 0; i < kPieces; ++i) staged_next[i] = load_piece(kmers + q0 * k, nbytes, lane + 64u * i);
+        } else if (reads_fast) {
+            // first window of the tile -> (read, offset): one division per TILE, by way of a double
+            // reciprocal (window indices stay below 2^38) with an exact fix-up
+            const uint64_t g0 = (tile * kTile) >> wshift;
+            uint64_t r0 = uint64_t(double(g0) * inv_windows);
+            int64_t w0 = int64_t(g0 - r0 * src.windows);
+            if (w0 < 0) { --r0; w0 += src.windows; }
+            if (w0 >= int64_t(src.windows)) { ++r0; w0 -= src.windows; }
+            staged_n0 = min(tile_windows, src.windows - uint32_t(w0));
+            const uint64_t at = r0 * src.read_len + uint64_t(w0) + 4u * lane, data_len = src.n_reads * src.read_len;
+            uint32_t d = 0;
+            if (at + 4u <= data_len) {
+                __builtin_memcpy(&d, kmers + at, 4);  // unaligned dword load
+            } else {  // the batch's last bytes: nothing beyond the caller's buffer is touched
+                for (uint32_t b = 0; b < 4u; ++b)
+                    if (at + b < data_len) d |= uint32_t(kmers[at + b]) << (8u * b);
+            }
+            staged_next[0].x = d;
         }
     };
     fetch_tile_bytes(next_tile);
@@ -259,15 +309,15 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
             const uint64_t pend_mask = __ballot(pending);
             if (pending) {
                 const uint32_t at = __builtin_amdgcn_mbcnt_hi(uint32_t(pend_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(pend_mask), 0u));
-                WorkItem it;
-                // l, h < 2^40: the hi words have 24 spare bits each -- they carry the 32-bit tile index
-                it.l_lo = uint32_t(pl); it.l_hi = uint32_t(pl >> 32) | (uint32_t(prep_tile) << 8);
-                it.h_lo = uint32_t(ph); it.h_hi = uint32_t(ph >> 32) | ((uint32_t(prep_tile) >> 24) << 8);
+                RingItem it;
+                it.l_lo = uint32_t(pl);
+                it.h_lo = uint32_t(ph);
+                it.meta = uint32_t(pl >> 32) | (uint32_t(ph >> 32) << 8) | (prep_rem << 16) | (lane << 24);  // l, h < 2^40; rem <= 64
 #pragma unroll
                 for (int i = 0; i < kWords; ++i) it.w[i] = prep_w[i];
-                it.rem_slot = prep_rem | (lane << 8);
                 ws.ring[(ring_head + ring_count + at) & (kRing - 1)] = it;
             }
+            ring_tile = prep_tile;  // the ring was empty: everything in it belongs to this tile
             ring_count += uint32_t(__popcll(pend_mask));
             prepared = false;
             wave_lds_sync();
@@ -278,22 +328,13 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
             const uint64_t idle = ~busy;
             const uint32_t my = __builtin_amdgcn_mbcnt_hi(uint32_t(idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle), 0u));
             if (!have && my < ring_count) {
-                const uint4 *it = reinterpret_cast<const uint4 *>(&ws.ring[(ring_head + my) & (kRing - 1)]);
-                const uint4 a = it[0], b = it[1];
-                l = (uint64_t(a.y & 0xFFu) << 32) | a.x;
-                h = (uint64_t(a.w & 0xFFu) << 32) | a.z;
-                const uint32_t item_tile = (a.y >> 8) | ((a.w >> 8) << 24);
-                uint32_t rem_slot;
-                if constexpr (kWords == 3) {
-                    w[0] = b.x; w[1] = b.y; w[2] = b.z;
-                    rem_slot = b.w;
-                } else {
-                    const uint4 c = it[2];
-                    w[0] = b.x; w[1] = b.y; w[2] = b.z; w[3] = b.w; w[4] = c.x; w[5] = c.y;
-                    rem_slot = c.z;
-                }
-                rem = rem_slot & 0xFFu;
-                qid = uint64_t(item_tile) * kTile + (rem_slot >> 8);
+                const RingItem it = ws.ring[(ring_head + my) & (kRing - 1)];
+                l = (uint64_t(it.meta & 0xFFu) << 32) | it.l_lo;
+                h = (uint64_t((it.meta >> 8) & 0xFFu) << 32) | it.h_lo;
+#pragma unroll
+                for (int i = 0; i < kWords; ++i) w[i] = it.w[i];
+                rem = (it.meta >> 16) & 0xFFu;
+                qid = ring_tile * kTile + (it.meta >> 24);
                 have = true;
             }
             const uint32_t taken = min(ring_count, uint32_t(__popcll(idle)));
@@ -325,16 +366,43 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
             const uint32_t in_tile = uint32_t(min(uint64_t(kTile), n - q0));
             const bool filter_now = filter != nullptr && filter_pause == 0;
             bool looked_up = false, passed = false;
+            const uint32_t tile_n0 = staged_n0;  // (fetch_tile_bytes below replaces it with the next tile's)
             if (!kReads) {  // the tile's bytes go through LDS (the line area is free between two steps)
 #pragma unroll
                 for (int i = 0; i < kPieces; ++i) ws.lines[kStageLead / 16 + lane + 64u * i] = staged_next[i];
+            } else if (reads_fast) {
+                // every read symbol becomes a code ONCE: forward codes at stage_bytes[0..256), the reverse
+                // complement of the whole span at stage_bytes[256..512) (byte j = comp(span byte 255 - j))
+                const uint32_t d = staged_next[0].x;
+                uint32_t f = 0, c = 0;
+#pragma unroll
+                for (uint32_t b = 0; b < 4u; ++b) {
+                    uint32_t sym = (d >> (8u * b)) & 0xFFu;
+                    if (src.ascii) sym = ascii_to_code(sym);
+                    f |= sym << (8u * b);
+                    c |= complement_code(sym) << (8u * (3u - b));
+                }
+                uint32_t *codes = reinterpret_cast<uint32_t *>(ws.lines) + kStageLead / 4;
+                codes[lane] = f;
+                codes[64u + (63u - lane)] = c;
             }
             wave_lds_sync();
             prep_kind = 0;
             prep_tile = tile;
             if (lane < in_tile) {
                 PackedQuery<kWords> pq;
-                pack_query<kReads, kWords>(src, depth, stage_bytes + lane * k, q0 + lane, pq);
+                if (!kReads) {
+                    pack_query<false, kWords>(src, depth, stage_bytes + lane * k, q0 + lane, pq);
+                } else if (reads_fast) {
+                    // window j of the tile starts o bytes into the span (k - 1 more once the read border is
+                    // crossed); forward: the row at F + o; reverse complement: the row at C + 256 - o - k --
+                    // either way a k-byte row packed exactly like a row of a query matrix
+                    const uint32_t j = lane >> wshift, o = j + (j >= tile_n0 ? k - 1u : 0u);
+                    const bool rc = src.strands == 3u ? (lane & 1u) != 0u : src.strands == 2u;
+                    pack_query<false, kWords>(src, depth, stage_bytes + (rc ? 512u - o - k : o), q0 + lane, pq);
+                } else {
+                    pack_query<true, kWords>(src, depth, stage_bytes, q0 + lane, pq);
+                }
                 if (pq.bad) {  // the reference asserts (msbwt_core.rs:127)
                     store_count<kReads>(src, q0 + lane, ~0ull);
                     atomicOr(flags, kFlagInvalidSymbol);
@@ -403,9 +471,10 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
         // an idle slot names the index's first block (an L2 hit) instead of masking its eight DMA lanes
         // off: one branch-free load instruction per region is cheaper than the exec-mask dance
         const uint64_t dummy = reinterpret_cast<uint64_t>(blocks);
-        ws.list[lane] = act ? base + bl * 128u : dummy;
-        if (second && act) ws.list[slot_h] = base + bh * 128u;
-        if (lane < 8u && 64u + nsecond + lane < uint32_t(kLineSlots)) ws.list[64u + nsecond + lane] = dummy;  // the ragged end of the last second-bound region
+        uint64_t *list = reinterpret_cast<uint64_t *>(ws.lines);  // this step's line addresses: read back before the first line lands
+        list[lane] = act ? base + bl * 128u : dummy;
+        if (second && act) list[slot_h] = base + bh * 128u;
+        if (lane < 8u && 64u + nsecond + lane < uint32_t(kLineSlots)) list[64u + nsecond + lane] = dummy;  // the ragged end of the last second-bound region
         // pair steps: K[a][b] + occ2 at the superblock start (L2-resident table).  One 8-byte load per lane
         // is a separate L2 request each (64 per wave): the second bound's base is fetched only in the rare
         // case that it lies in another superblock -- into a register of its own, so that nothing here waits
@@ -423,7 +492,10 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
         {   // all line addresses first (one LDS round trip), then the LDS-DMA loads back to back
             uint64_t addr[kRegions];
 #pragma unroll
-            for (int i = 0; i < kRegions; ++i) addr[i] = ws.list[8u * i + dma_group] + dma_chunk_bytes;
+            for (int i = 0; i < kRegions; ++i) addr[i] = list[8u * i + dma_group] + dma_chunk_bytes;
+            // the list lives in the line area: every address must be in registers before a line may land on it
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
+            wave_lds_sync();
 #pragma unroll
             for (int i = 0; i < kRegions; ++i) {
                 const bool wanted = i < 8 ? ((busy >> (8 * i)) & 0xFFull) != 0ull : nsecond > uint32_t(8 * (i - 8));  // wave-uniform
@@ -477,7 +549,7 @@ uint32_t resident_waves() {
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_count_kmers_lanes<kReads, kPair, kWords, kStride96>, 64, 0) != hipSuccess ||
             cus <= 0 || per_cu <= 0)
             return 7u * 256u;
-        // LDS decides (13.25 KiB -> 12 waves, 18.4 KiB -> 8); whole multiples of the four SIMDs only: with
+        // LDS decides (12.1 / 12.9 KiB -> 12 waves); whole multiples of the four SIMDs only: with
         // 10 waves the two three-wave SIMDs run slower and throughput FELL (tools/sweep_variants.sh)
         per_cu = std::min(per_cu, MSBWT_LANES_WAVE_CAP);
         if (per_cu > 4) per_cu -= per_cu % 4;
@@ -498,15 +570,20 @@ hipError_t launch_variant(hipStream_t stream, const IndexView &ix, const QuerySo
     const uint32_t filter_mask = filter ? uint32_t((1ull << (2 * ix.table.filter_depth)) - 1ull) : 0u;
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
     const uint64_t waves = std::min<uint64_t>(tiles, resident_waves<kReads, kPair, kWords, kStride96>());
-    if (tiles > kMaxTiles || !ix.tile_counter) return hipErrorInvalidValue;
-    const hipError_t zeroed = hipMemsetAsync(ix.tile_counter, 0, kTicketBytes, stream);
-    if (zeroed != hipSuccess) return zeroed;
+    if (tiles > kMaxTiles) return hipErrorInvalidValue;
+    // Ticket counters are only needed when there are more tiles than waves; without them (small batches, the
+    // single-query path: no memset, no atomics) the kernel strides statically.
+    const bool tickets = ix.tile_counter != nullptr && tiles > waves;
+    if (tickets) {
+        const hipError_t zeroed = hipMemsetAsync(ix.tile_counter, 0, kTicketBytes, stream);
+        if (zeroed != hipSuccess) return zeroed;
+    }
     // tiles per ticket: about eight tickets per wave at least, sixteen tiles at most
     const uint32_t grain = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(16, tiles / (waves * 8))));
     hipLaunchKernelGGL((k_count_kmers_lanes<kReads, kPair, kWords, kStride96>), dim3(uint32_t(waves)), dim3(64), 0, stream,
                        static_cast<const uint4 *>(ix.blocks), ix.total, table, uint32_t(ix.table.depth), ix.table.packed ? 1u : 0u, filter, filter_mask,
                        static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags, ix.debug,
-                       static_cast<unsigned long long *>(ix.tile_counter), grain);
+                       tickets ? static_cast<unsigned long long *>(ix.tile_counter) : nullptr, grain);
     return hipGetLastError();
 }
 

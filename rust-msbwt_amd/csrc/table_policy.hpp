@@ -45,4 +45,30 @@ inline TableChoice choose_table_depths(uint64_t total, uint64_t block_bytes, uin
     return c;
 }
 
+// ---- spacing of the pair blocks (rank_ops.hpp): 128 = disjoint, 96 = overlapping (1.33 bytes per symbol) --------
+// Overlapping blocks rank a range up to 32 wide from ONE line.  Whether that pays is a property of the DATA: on
+// a real 30x read set the range of a present k-mer stays about as wide as the coverage down to the last step
+// (every fifth pair step would fetch a second line from disjoint blocks), on a stream of independent symbols
+// it collapses to width 1 within a few steps and the overlap buys nothing.  The packed table knows which: it
+// holds the width of every range that survives `depth` symbols.
+//   typical width = sum(w x w) / sum(w) over the table's ranges = the width of the range that a random PRESENT
+//   suffix -- a k-mer drawn from the reads -- finds itself in when its search leaves the table.
+inline double typical_range_width(uint64_t sum_w, uint64_t sum_w_times_w) { return sum_w ? double(sum_w_times_w) / double(sum_w) : -1.0; }
+
+constexpr double kWideRangeThreshold = 8.0;  // from here on a second line per pair step is common enough to pay 0.33 bytes per symbol
+
+// First decision, before any table exists: overlapping blocks when they are cheap (their blocks and build scratch
+// take at most a quarter of the free HBM: C3 / C4-sized indexes), disjoint otherwise.
+inline int provisional_pair_stride(uint64_t bytes_stride96, uint64_t free_bytes) { return bytes_stride96 <= free_bytes / 4 ? 96 : 128; }
+
+// Second decision, once the packed table has been built beside disjoint blocks: switch to overlapping ones when
+// the data keep ranges wide AND the bigger blocks fit -- `free_bytes` is what is free NOW (table and disjoint pair
+// blocks in place), `held_bytes` what freeing the disjoint blocks gives back, and `reserve_bytes` stays free for
+// the caller's batches.  typical_width < 0 = unknown (no packed table): keep what there is.
+inline int final_pair_stride(int current, double typical_width, uint64_t bytes_stride96, uint64_t free_bytes, uint64_t held_bytes,
+                             uint64_t reserve_bytes) {
+    if (current != 128 || typical_width < kWideRangeThreshold) return current;
+    return bytes_stride96 + reserve_bytes <= free_bytes + held_bytes ? 96 : 128;
+}
+
 }  // namespace msbwt

@@ -251,6 +251,10 @@ class RleBWT(BWT):
     def get_pair_stride(self):
         return int(_lib.lib().msbwt_rle_get_pair_stride(self._h))
 
+    def get_typical_range_width(self):
+        """Width of the range a present k-mer leaves the packed suffix table with (-1.0 without one)."""
+        return float(_lib.lib().msbwt_rle_get_typical_range_width(self._h))
+
     BLOCK_FORMATS = {"planes": 0, "runs": 1}
 
     def set_block_format(self, fmt):

@@ -39,6 +39,10 @@ def lib():
         L.synth_rle_encode.restype = u64
         L.synth_rle_stream.argtypes = [u64, C.c_double, u64, C.c_int, C.POINTER(u64), C.POINTER(u64)]
         L.synth_rle_stream.restype = vp
+        L.synth_run_histogram.argtypes = [vp, u64, vp, u64]
+        L.synth_rle_stream_hist.argtypes = [u64, vp, vp, C.c_double, u64, C.c_int, C.c_int, C.POINTER(u64), C.POINTER(u64)]
+        L.synth_rle_stream_hist.restype = vp
+        L.synth_set_threads.argtypes = [C.c_int]
         L.synth_free.argtypes = [vp]
         _lib = L
     return _lib
@@ -107,13 +111,61 @@ def rle_encode(symbols):
     return out
 
 
-def rle_stream(target_symbols, mean_run, seed, chunks=0):
+def set_threads(threads):
+    """Host threads the generators use (0 = default: min(16, hardware)); bench.py bounds them per rank."""
+    lib().synth_set_threads(int(threads))
+
+
+HISTOGRAM_FILE = os.path.join(HERE, "c4_run_histogram.json")
+RUN_HIST_CAP = 65536
+
+
+def run_histogram(rle_bytes, cap=RUN_HIST_CAP):
+    """Per-symbol run-length histogram of an RLE stream: (6, cap) uint64, lengths >= cap in the last bin."""
+    a = np.ascontiguousarray(rle_bytes, dtype=np.uint8)
+    hist = np.zeros((6, cap), dtype=np.uint64)
+    lib().synth_run_histogram(_p(a), a.size, _p(hist), cap)
+    return hist
+
+
+def load_histogram(path=HISTOGRAM_FILE):
+    """The committed measurement (tools/measure_run_histogram.py): {"lengths": {symbol: {run length: runs}}} ->
+    (len_table uint16[6, 65536], sym_cdf uint32[6], mean run)."""
+    import json
+    with open(path) as f:
+        data = json.load(f)
+    table = np.ones((6, 65536), dtype=np.uint16)
+    runs_of = np.zeros(6, dtype=np.float64)
+    symbols = 0.0
+    for s in range(6):
+        items = sorted((int(l), int(c)) for l, c in data["lengths"].get(str(s), {}).items())
+        if not items:
+            continue
+        lens = np.array([l for l, _ in items], dtype=np.int64)
+        cnts = np.array([c for _, c in items], dtype=np.float64)
+        runs_of[s] = cnts.sum()
+        symbols += float((lens * cnts).sum())
+        cdf = np.cumsum(cnts) / cnts.sum()
+        # inverse CDF at (u + 0.5) / 65536
+        table[s] = np.minimum(lens[np.searchsorted(cdf, (np.arange(65536) + 0.5) / 65536.0, side="left").clip(0, len(lens) - 1)], 65535).astype(np.uint16)
+    cdf = np.cumsum(runs_of) / runs_of.sum()
+    sym_cdf = np.minimum(np.floor(cdf * 4294967296.0), 4294967295.0).astype(np.uint32)
+    sym_cdf[5] = 4294967295
+    return np.ascontiguousarray(table), sym_cdf, symbols / runs_of.sum()
+
+
+def rle_stream(target_symbols, mean_run, seed, chunks=0, histogram=None):
     """Structure-equivalent synthetic RLE stream (NOT a real BWT). Returns (bytes, total).
-    Deterministic for a given (target, mean_run, seed, chunks)."""
+    Deterministic for a given (target, mean_run, seed, chunks).  histogram = path of a measured run-length
+    histogram (load_histogram): run lengths and symbols are drawn from it instead of a geometric law."""
     if chunks <= 0:  # ~64 Mi symbols per chunk, at least 64 chunks (fixed rule => reproducible)
         chunks = max(64, int(target_symbols) >> 26)
     nbytes, total = C.c_uint64(), C.c_uint64()
-    ptr = lib().synth_rle_stream(target_symbols, mean_run, seed, chunks, C.byref(nbytes), C.byref(total))
+    if histogram is not None:
+        table, sym_cdf, mean = load_histogram(histogram)
+        ptr = lib().synth_rle_stream_hist(target_symbols, _p(table), _p(sym_cdf), mean, seed, chunks, 0, C.byref(nbytes), C.byref(total))
+    else:
+        ptr = lib().synth_rle_stream(target_symbols, mean_run, seed, chunks, C.byref(nbytes), C.byref(total))
     if not ptr:
         raise MemoryError("synth_rle_stream")
     # wrap the malloc'ed buffer without copying it (it is 15 GB at human scale)

@@ -35,8 +35,11 @@ inline uint64_t splitmix64_at(uint64_t seed, uint64_t i) {
 
 const uint8_t kBase[4] = {1, 2, 3, 5};  // A C G T
 
+int g_default_threads = 0;  // synth_set_threads: bench.py bounds the host threads of a rank (nproc / world)
+
 int pick_threads(int threads) {
     if (threads > 0) return threads;
+    if (g_default_threads > 0) return g_default_threads;
     unsigned hw = std::thread::hardware_concurrency();
     return int(std::max(1u, std::min(hw, 16u)));
 }
@@ -333,6 +336,8 @@ static void gen_chunk(uint64_t target, const GeomTable &geom, double mean_run, u
     enc->resize(w);
 }
 
+void synth_set_threads(int threads) { g_default_threads = threads; }
+
 uint8_t *synth_rle_stream(uint64_t target_symbols, double mean_run, uint64_t seed, int chunks,
                           uint64_t *out_bytes, uint64_t *out_total) {
     if (chunks < 1) chunks = 1;
@@ -361,6 +366,98 @@ uint8_t *synth_rle_stream(uint64_t target_symbols, double mean_run, uint64_t see
     uint8_t *out = static_cast<uint8_t *>(std::malloc(bytes ? bytes : 1));
     if (!out) return nullptr;
     parallel_for(pick_threads(0), size_t(chunks), [&](int, size_t b, size_t e) {
+        for (size_t c = b; c < e; ++c)
+            if (!enc[c].empty()) std::memcpy(out + off[c], enc[c].data(), enc[c].size());
+    });
+    if (out_bytes) *out_bytes = bytes;
+    if (out_total) *out_total = target_symbols;
+    return out;
+}
+
+// Run-length histogram of an RLE stream, per symbol: hist[s * cap + min(len, cap - 1)] += 1 for every run
+// (consecutive same-symbol bytes are the base-32 digits of ONE run, least significant first).
+void synth_run_histogram(const uint8_t *rle, uint64_t n, uint64_t *hist, uint64_t cap) {
+    uint64_t i = 0;
+    while (i < n) {
+        const uint8_t s = rle[i] & 7u;
+        uint64_t len = 0, weight = 1;
+        while (i < n && (rle[i] & 7u) == s) {
+            len += uint64_t(rle[i] >> 3) * weight;
+            weight <<= 5;
+            ++i;
+        }
+        if (s < 6) ++hist[uint64_t(s) * cap + std::min(len, cap - 1)];
+    }
+}
+
+// The same kind of stream as synth_rle_stream, with (symbol, run length) drawn from a MEASURED histogram
+// ("run-length histogram taken from C4's BWT"): len_table[s * 65536 + u] is the inverse CDF
+// of symbol s's run lengths at u / 65536, sym_cdf[s] the cumulative share of runs with symbol <= s scaled to
+// 2^32.  Symbols stay independent of their neighbours (except that two neighbouring runs differ), so this is
+// still not a BWT: ranges of present k-mers collapse to width 1 as before.
+static void gen_chunk_hist(uint64_t target, const uint16_t *len_table, const uint32_t *sym_cdf, double mean_run, uint64_t seed,
+                           std::vector<uint8_t> *enc) {
+    uint64_t st = seed, total = 0;
+    uint8_t prev = 255;
+    enc->resize(size_t(double(target) / mean_run * 1.3) + 4096);
+    size_t w = 0;
+    bool first = true;
+    auto pick = [&](uint32_t u) -> uint8_t {
+        for (uint8_t s = 0; s < 5; ++s)
+            if (u < sym_cdf[s]) return s;
+        return 5;
+    };
+    while (total < target) {
+        if (w + 8 > enc->size()) enc->resize(enc->size() + enc->size() / 4 + 4096);
+        uint8_t *out = enc->data();
+        uint64_t x = splitmix64(st);
+        uint8_t sym = pick(uint32_t(x));
+        while (sym == prev) sym = pick(uint32_t(splitmix64(st)));
+        // chunk borders can never merge two runs: a chunk starts with G or T and ends with A or C
+        if (first) sym = (x >> 40) & 1u ? 3 : 5;
+        uint64_t len = len_table[size_t(sym) * 65536 + ((x >> 44) & 0xFFFFu)];
+        if (len == 0) len = 1;
+        if (len >= target - total) {  // the chunk's last run
+            len = target - total;
+            if (!first) {
+                sym = (x >> 41) & 1u ? 1 : 2;
+                if (sym == prev) sym = uint8_t(prev == 1 ? 2 : 1);
+            }
+        }
+        for (uint64_t l = len; l > 0; l >>= 5) out[w++] = uint8_t(sym | ((l & 31u) << 3));
+        total += len;
+        prev = sym;
+        first = false;
+    }
+    enc->resize(w);
+}
+
+uint8_t *synth_rle_stream_hist(uint64_t target_symbols, const uint16_t *len_table, const uint32_t *sym_cdf, double mean_run, uint64_t seed,
+                               int chunks, int threads, uint64_t *out_bytes, uint64_t *out_total) {
+    if (chunks < 1) chunks = 1;
+    if (uint64_t(chunks) * 4 > target_symbols) chunks = 1;
+    std::vector<std::vector<uint8_t>> enc(static_cast<size_t>(chunks));
+    {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> pool;
+        for (int t = 0; t < pick_threads(threads); ++t)
+            pool.emplace_back([&] {
+                for (;;) {
+                    const size_t c = next.fetch_add(1);
+                    if (c >= size_t(chunks)) break;
+                    const uint64_t lo = uint64_t((unsigned __int128)target_symbols * c / uint64_t(chunks));
+                    const uint64_t hi = uint64_t((unsigned __int128)target_symbols * (c + 1) / uint64_t(chunks));
+                    gen_chunk_hist(hi - lo, len_table, sym_cdf, mean_run < 1.0 ? 1.0 : mean_run, seed + 0x632BE59BD9B4E019ull * (c + 1), &enc[c]);
+                }
+            });
+        for (auto &th : pool) th.join();
+    }
+    uint64_t bytes = 0;
+    std::vector<uint64_t> off(static_cast<size_t>(chunks) + 1, 0);
+    for (size_t c = 0; c < size_t(chunks); ++c) { off[c] = bytes; bytes += enc[c].size(); }
+    uint8_t *out = static_cast<uint8_t *>(std::malloc(bytes ? bytes : 1));
+    if (!out) return nullptr;
+    parallel_for(pick_threads(threads), size_t(chunks), [&](int, size_t b, size_t e) {
         for (size_t c = b; c < e; ++c)
             if (!enc[c].empty()) std::memcpy(out + off[c], enc[c].data(), enc[c].size());
     });

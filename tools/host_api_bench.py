@@ -30,3 +30,12 @@ w = reads.shape[1] - k + 1
 win = np.ascontiguousarray(reads[(ids // w)[:, None], (ids % w)[:, None] + np.arange(k)[None, :]])
 assert np.array_equal(f.reshape(-1)[ids], ref.count_kmers(win, nthreads=8)), "fused host path differs from the oracle"
 print("parity ok")
+# single-call latency through the trait-shaped entry points (a C host: examples/call_latency.c) next to the CPU restatement
+import os, subprocess
+exe = "/tmp/call_latency"
+subprocess.check_call(["gcc", "-O2", "-Iinclude", "examples/call_latency.c", "-Lrust-msbwt_amd", "-lmsbwt_hip",
+                       "-Wl,-rpath," + os.path.abspath("rust-msbwt_amd"), "-o", exe])
+print(subprocess.run([exe, npy, "21"], capture_output=True, text=True).stdout, flush=True)
+qs = q[:200_000]
+t = time.time(); ref.count_kmers(qs, nthreads=1); dt = time.time() - t
+print("CPU restatement (oracle, 1 thread), same index: %.2f us per 21-mer query" % (dt / len(qs) * 1e6))

@@ -16,12 +16,19 @@ export TMPDIR=/tmp
 cd /tmp
 LEAN="--no-cpu-baseline --no-c5 --parity-sample 20000 --stats-sample 200000"
 
+# PROF_PASSES (optional): which passes to run, by first word -- default "stats FETCH_SIZE WRITE_SIZE TCC_HIT_sum SQ_WAVE_CYCLES"
+PASSES=${PROF_PASSES:-stats FETCH_SIZE WRITE_SIZE TCC_HIT_sum SQ_WAVE_CYCLES}
+wanted() { case " $PASSES " in *" $1 "*) return 0;; *) return 1;; esac; }
+
+if wanted stats; then
 echo "[profile] kernel-trace + stats" >&2
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 "$ROOT/bench.py" "$@" $LEAN --steps 10 --warmup 2 \
     > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+fi
 
 for group in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS"; do
     first=${group%% *}
+    wanted "$first" || continue
     echo "[profile] pmc $group" >&2
     rocprofv3 --pmc $group --kernel-include-regex "k_count_kmers" --kernel-trace --output-format csv -d "$OUT/pmc_$first" -o run -- python3 "$ROOT/bench.py" "$@" $LEAN --no-oracle --steps 3 --warmup 1 \
         > "$OUT/bench_pmc_$first.json" 2> "$OUT/pmc_$first.err"
