@@ -5,16 +5,23 @@ One "step" = one pass of the hot path (msbwt_rle_count_kmers_device) over one ba
 queries that is already resident in HBM.
 
 Default workload ("human") = the configuration BASELINE.json quotes its metric on, on ONE GPU:
-k = 31 on a 30x-human-scale index (9e10 symbols; a structure-equivalent synthetic RLE stream,
-see DESIGN.md), 3e8 PRESENT 31-mers per step (LF-walk; every query runs all 31 steps -- the
-read-corrector case).  The literal configs[4] line (1e9 random 31-mers generated in HBM) is
-carried in the extra key `c5_random_1e9`.  Other workloads: c2, c3 (--fused = configs[2]), c4, big.
+k = 31 on a 30x-human-scale index (9e10 symbols; a structure-equivalent synthetic RLE stream whose
+runs are drawn from the run-length histogram of config C4's real MSBWT), 3e8 PRESENT
+31-mers per step (LF-walk; every query runs all 31 steps -- the read-corrector case).  Extra keys of the
+default run:
+  c5_random_1e9  the literal configs[4] line: 1e9 random 31-mers generated in HBM, sharded over the ranks
+                 and gathered when N > 1;
+  c4_real_reads  (N = 1) the REAL multi-string BWT of config C4 (12.9 M reads, 1.95e9 symbols, built on the
+                 host in this run): 1e8 read-derived 31-mers -- what searches look like on real 30x data
+                 (ranges stay ~ coverage wide), with its own roofline and parity.
+Other workloads: c2, c3 (--fused = configs[2]), c4, big.
 
---gpus N: one rank per GPU.  Launched plainly (no torchrun) the script starts
-torch.distributed.run itself as a child process and relays its JSON line.  The index is
-replicated; ONE fixed batch is sharded across the ranks (strong scaling, BASELINE configs[3]'s
-shape) and every rank ends each step holding all counts after one RCCL all_gather.  The
-weak-scaling figure (every rank the whole batch) is reported in the extra key `weak_scaling`.
+--gpus N: one rank per GPU.  Launched plainly (no torchrun) the script starts torch.distributed.run
+itself as a child process and relays its JSON line.  The index is replicated; ONE fixed batch is
+sharded across the ranks (strong scaling, BASELINE configs[3]'s shape) and every rank ends each step
+holding all counts after one RCCL all_gather.  The weak-scaling figure (every rank the whole batch) is
+reported in the extra key `weak_scaling`; `ranks` carries per-rank kernel and exchange times;
+`native_gather` repeats the measurement with the library's own RCCL call (msbwt_rle_allgather_counts).
 
 Prints ONE JSON line (rank 0).  DESIGN.md section 5 defines the roofline figures.
 """
@@ -37,7 +44,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is 
 RANDOM_LINE_PEAK = 4.86e10  # random 128-byte lines/s, measured: independent gathers over 8-250 GiB (tools/ubench_granule.hip; 64-, 32- and 16-byte
 # granules are served at the same rate), dependent LDS-DMA gathers over 100 GB 4.8e10 (tools/ubench_lds_gather.hip)
 HUMAN_SYMBOLS = 9e10
-KERNEL_SOURCES = ["kernels.hip", "lanes.hip", "search_common.hpp", "rank_ops.hpp", "kernels.hpp", "plane_index.hpp"]
+# everything that decides which bytes a query makes the kernel move: the kernels, the block layouts and their
+# builders, and the policies that pick table depth and pair spacing
+KERNEL_SOURCES = ["kernels.hip", "lanes.hip", "search_common.hpp", "rank_ops.hpp", "kernels.hpp", "plane_index.hpp",
+                  "pair_index.hip", "device_build.hip", "table_policy.hpp"]
+NARROW_MAX = 32767
 
 
 def log(msg):
@@ -86,6 +97,8 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="human", choices=["human", "c2", "c3", "c4", "big"])
     ap.add_argument("--big-symbols", type=float, default=2.0**33, help="workload big: BWT length")
     ap.add_argument("--big-mean-run", type=float, default=6.0)
+    ap.add_argument("--stream", default="histogram", choices=["histogram", "geometric"],
+                    help="human / big: run lengths of the stand-in stream from C4's measured histogram (default) or geometric")
     ap.add_argument("--stats-sample", type=int, default=2_000_000, help="queries used for the algorithmic-byte counters (0 = all)")
     ap.add_argument("--queries", type=int, default=0, help="queries per step, whole job (0 = the config's)")
     ap.add_argument("--k", type=int, default=0, help="override k")
@@ -110,7 +123,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-oracle", action="store_true",
                     help="profiling passes only: skip parity, algorithmic-byte counters and the CPU baseline (prints a lean line)")
     ap.add_argument("--no-c5", action="store_true", help="skip the extra 1e9-random-31-mer line of the default workload")
+    ap.add_argument("--no-c4", action="store_true", help="skip the extra real-MSBWT (config C4, read-derived 31-mers) line of the default workload")
+    ap.add_argument("--c4-scale", type=float, default=0.0, help="tests: run the extra C4 line on a shrunk C4 (0 = full size, only with --scale 1)")
+    ap.add_argument("--c4-queries", type=int, default=100_000_000)
     ap.add_argument("--no-weak", action="store_true", help="N>1: skip the extra weak-scaling measurement")
+    ap.add_argument("--no-native-gather", action="store_true", help="N>1: skip the extra measurement with the library's own RCCL all-gather")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 code path (process group, all_gather of the counts, barriers) even with one rank: "
                          "a one-GPU rehearsal of the RCCL calls themselves")
@@ -184,18 +201,78 @@ def walk_kmers(torch, np, bwt, dev, total, n, k, seed, chunk=40_000_000):
     return out
 
 
-def device_random_kmers(torch, dev, n, k, seed, chunk=50_000_000):
-    """uniform ACGT k-mers generated in HBM (BASELINE configs[4] asks for 1e9 queries: 31 GB that
-    never need to exist on the host)"""
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(seed)
-    d_q = torch.empty((n, k), dtype=torch.uint8, device=dev)
-    for lo_q in range(0, n, chunk):
-        part = d_q[lo_q:lo_q + chunk]
+def device_random_kmers(torch, dev, lo, hi, k, seed, chunk=50_000_000):
+    """Rows [lo, hi) of a batch of uniform ACGT k-mers, generated in HBM (BASELINE configs[4] asks for 1e9
+    queries: 31 GB that never need to exist on the host).  The batch is defined chunk by chunk (chunk c =
+    rows [c * chunk, (c + 1) * chunk), its own generator seeded seed + c), so a rank that owns a shard
+    generates only the chunks its shard touches and every rank agrees on every row."""
+    d_q = torch.empty((hi - lo, k), dtype=torch.uint8, device=dev)
+    for c in range(lo // chunk, (max(hi, lo + 1) - 1) // chunk + 1):
+        c_lo, c_hi = c * chunk, (c + 1) * chunk
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed * 1_000_003 + c)
+        a, b = max(lo, c_lo), min(hi, c_hi)
+        if b <= a:
+            continue
+        whole = a == c_lo and b == c_hi
+        part = d_q[a - lo:b - lo] if whole else torch.empty((chunk, k), dtype=torch.uint8, device=dev)
         part.random_(0, 4, generator=gen)      # 0..3
         part.add_(1)                           # A C G -> 1 2 3
         part.masked_fill_(part == 4, 5)        # T -> 5
+        if not whole:
+            d_q[a - lo:b - lo] = part[a - c_lo:b - c_lo]
+            del part
     return d_q
+
+
+def lookup_traffic(workload, k, bwt, kind, total, fused, full_size):
+    """HBM traffic per query of one launch of this configuration: PMC counters from separate rocprofv3 passes
+    (FETCH_SIZE x2 on gfx950, WRITE_SIZE), committed under profiles/ and keyed by configuration AND kernel sources.
+    Returns (bytes per query | None, source, note, stamp)."""
+    per_query, src, note = None, None, "no PMC summary for this configuration under profiles/"
+    stamp = kernel_stamp()
+    try:
+        for ent in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["entries"]:
+            same = (ent["workload"] == workload and ent["k"] == k and ent["table_depth"] == bwt.get_table_depth()
+                    and ent.get("pair_index", False) == bwt.get_pair_index() and ent.get("pair_stride", bwt.get_pair_stride()) == bwt.get_pair_stride()
+                    and ent.get("query_kind") == kind and ent.get("bwt_symbols", total) == total and full_size
+                    and bool(ent.get("fused", False)) == bool(fused))
+            if same and ent.get("kernel_stamp") != stamp:
+                note = "stale: %s was taken with kernel sources %s, the tree has %s" % (ent["source"], ent.get("kernel_stamp"), stamp)
+            elif same:
+                per_query, src, note = ent["traffic_bytes_per_query"], ent["source"], None
+    except (OSError, KeyError, ValueError):
+        pass
+    return per_query, src, note, stamp
+
+
+def roofline_block(orc, ref, queries, k, ncpu, per_launch_q, kern_s, kernel_ms, launches, traffic_per_query, traffic_src, traffic_note,
+                   stamp, label, stats_sample):
+    """roofline object of one measured line: counter traffic / kernel time / 8 TB/s, next to the
+    algorithmic bytes of the REFERENCE algorithm for this query set (exact counters from the instrumented oracle)."""
+    st = orc.Stats()
+    nst = min(len(queries), stats_sample) if stats_sample else len(queries)
+    ref.count_kmers(queries[:nst], nthreads=ncpu, stats=st)
+    alg_bytes = st.algorithmic_bytes(k) / nst * per_launch_q  # exact when nst == nq, else scaled from the sample
+    traffic = None if traffic_per_query is None else traffic_per_query * per_launch_q
+    achieved = None if traffic is None else traffic / kern_s / 1e9
+    return {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": None if achieved is None else achieved / HBM_PEAK_GBS,
+        "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note, "kernel_stamp": stamp,
+        "kernel": label, "kernel_ms": kernel_ms, "kernel_launches": launches,
+        "algorithmic": {
+            "bytes_per_launch": int(alg_bytes), "bytes_per_query": alg_bytes / per_launch_q,
+            "GBps": alg_bytes / kern_s / 1e9, "x_hbm_peak": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
+            "mean_steps_per_query": st.steps / nst, "mean_bin_visits_per_query": st.visits / nst, "stats_queries": int(nst),
+            "note": "bytes the REFERENCE algorithm touches for this query set (SURVEY 8d: 56 B of samples + scanned RLE bytes per "
+                    "bin visit, + k + 8 per query) / kernel time.  The suffix table and pair steps make this kernel move fewer "
+                    "bytes than that, so it is a speed-up measure, not a bandwidth fraction"},
+        "note": "achieved/frac = measured HBM-side traffic of one launch (rocprofv3 PMC, committed summary) / kernel time measured "
+                "live with HIP events on the launch stream / 8 TB/s",
+        "random_lines": None if traffic is None else {
+            "per_s": traffic / 128.0 / kern_s, "peak_per_s": RANDOM_LINE_PEAK, "frac": traffic / 128.0 / kern_s / RANDOM_LINE_PEAK},
+    }
 
 
 def main():
@@ -240,6 +317,11 @@ def main():
     msbwt = importlib.import_module("rust-msbwt_amd")
     import synth
 
+    # host threads of this rank: the ranks of one node share its cores (generators, oracle)
+    nproc = os.cpu_count() or 1
+    host_threads = max(1, min(16, nproc // max(1, world)))
+    synth.set_threads(host_threads)
+
     human = args.workload == "human"
     big = human or args.workload == "big"
     cfg = dict(synth.CONFIGS["c3" if big else args.workload])
@@ -249,6 +331,7 @@ def main():
     if args.scale < 1.0 and not args.queries:
         nq = max(1000, int(nq * min(1.0, args.scale * (4 if not human else 40))))
     symbols = int((HUMAN_SYMBOLS if human else args.big_symbols) * (args.scale if human else 1.0))
+    hist_file = synth.HISTOGRAM_FILE if (args.stream == "histogram" and os.path.exists(synth.HISTOGRAM_FILE)) else None
 
     bwt = msbwt.RleBWT(device=local_rank)
     bwt.set_block_format(args.blocks)
@@ -259,8 +342,8 @@ def main():
     if big:
         # structure-equivalent synthetic RLE stream (NOT a real BWT): sizes that cannot be
         # suffix-sorted here.  Same seed on every rank => identical replicas.
-        rle, _ = synth.rle_stream(symbols, args.big_mean_run, 77)
-        log("rank %d: synthetic RLE stream of %d bytes in %.1fs" % (rank, len(rle), time.time() - t0))
+        rle, _ = synth.rle_stream(symbols, args.big_mean_run, 77, histogram=hist_file)
+        log("rank %d: synthetic RLE stream of %d bytes in %.1fs (%d host threads)" % (rank, len(rle), time.time() - t0, host_threads))
         t0 = time.time()
         bwt.load_vector(rle)
         if rank != 0:
@@ -277,13 +360,15 @@ def main():
         t0 = time.time()
         bwt.load_numpy_file(npy)
     total = bwt.get_total_size()
-    log("rank %d: %d symbols on the GPU (%.1f MB index, table depth %d, pair index %s) in %.1fs"
-        % (rank, total, bwt.device_bytes() / 1e6, bwt.get_table_depth(), bwt.get_pair_index(), time.time() - t0))
+    log("rank %d: %d symbols on the GPU (%.1f MB index, table depth %d, pair index %s stride %d, typical range width %.1f) in %.1fs"
+        % (rank, total, bwt.device_bytes() / 1e6, bwt.get_table_depth(), bwt.get_pair_index(), bwt.get_pair_stride(),
+           bwt.get_typical_range_width(), time.time() - t0))
 
     # ---- the batch: identical on every rank (same seeds); d_q holds ALL nq queries in HBM ---------
     fused = args.fused and not big
     t0 = time.time()
     d_reads = None
+    nread = rlen = wins = 0
     if fused:
         kind = "reads"
         nread, rlen = reads.shape
@@ -294,7 +379,7 @@ def main():
     elif kind == "walk":
         d_q = walk_kmers(torch, np, bwt, dev, total, nq, k, 4242)
     elif kind == "random" and (args.device_queries or big):
-        d_q = device_random_kmers(torch, dev, nq, k, 4242)
+        d_q = device_random_kmers(torch, dev, 0, nq, k, 4242)
     elif kind == "random":
         d_q = torch.from_numpy(synth.random_kmers(nq, k, cfg["qseed"])).to(dev)
     else:
@@ -305,23 +390,20 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     strong = multi and args.scaling == "strong" and not fused
-    if strong:
-        lo, hi = msbwt.sharded.shard_bounds(nq, world, rank)  # 16-query aligned: every shard keeps the tiled kernel
-        cap = msbwt.sharded.shard_capacity(nq, world)
-    else:
-        lo, hi, cap = 0, nq, nq
-    mine_n = hi - lo
-
-    def count_into(out, a=lo, b=hi):
-        if fused:
-            bwt.count_read_kmers_device(d_reads.data_ptr(), rlen, nread, k, False, out.data_ptr(), 0, stream)
-        elif b > a:
-            bwt.count_kmers_device(d_q.data_ptr() + a * k, k, b - a, out.data_ptr(), stream)
 
     def fence():
         if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
+
+    def gather_floats(values):
+        """[values of rank 0, values of rank 1, ...] on every rank"""
+        if not multi:
+            return [list(values)]
+        t = torch.tensor(values, dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        out = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [o.tolist() for o in out]
 
     # ---- the exchange step (N > 1): every rank ends each step holding ALL counts ------------------
     # 8 bytes per query over xGMI can cost more than the search itself, so the counts travel as
@@ -329,15 +411,31 @@ def main():
     # the loop; any overflow re-runs the whole measurement with 64-bit payloads), the all_gather
     # runs asynchronously on RCCL's stream and overlaps the next step's kernel (two buffers in
     # flight), and each rank widens what it received back to u64 -- inside the timed region.
-    NARROW_MAX = 32767
+    class Batch:
+        """One batch in HBM and how a step counts this rank's part of it."""
 
-    def run_steps(nsteps, narrow, a, b, per_rank):
+        def __init__(self, the_bwt, q=None, row0=0, fused_reads=None, kk=k):
+            self.bwt, self.q, self.row0, self.reads, self.k = the_bwt, q, row0, fused_reads, kk
+
+        def count_into(self, out, a, b):
+            if self.reads is not None:
+                self.bwt.count_read_kmers_device(self.reads.data_ptr(), rlen, nread, self.k, False, out.data_ptr(), 0, stream)
+            elif b > a:  # self.q holds the batch's rows from row0 on
+                self.bwt.count_kmers_device(self.q.data_ptr() + (a - self.row0) * self.k, self.k, b - a, out.data_ptr(), stream)
+
+    def run_steps(batch, nsteps, narrow, a, b, per_rank, native=None, exchange=True):
         """nsteps passes over queries [a, b) of the batch; N > 1: + all_gather of `per_rank` counts per rank"""
         outs = [torch.zeros(per_rank, dtype=torch.int64, device=dev) for _ in range(2)]
         if not multi:
             for _ in range(nsteps):
-                count_into(outs[0], a, b)
+                batch.count_into(outs[0], a, b)
             return outs[0], None, False
+        if native is not None:  # the library's own RCCL call: narrow, ncclAllGather, widen -- all on this stream
+            d_all = torch.empty(per_rank * world, dtype=torch.int64, device=dev)
+            for i in range(nsteps):
+                batch.count_into(outs[i & 1], a, b)
+                batch.bwt.allgather_counts(native, outs[i & 1].data_ptr(), per_rank, d_all.data_ptr(), 16 if narrow else 64, stream)
+            return outs[(nsteps - 1) & 1], d_all, False  # (an overflow shows up in device_status)
         pay_dtype = torch.int16 if narrow else torch.int64
         sends = [torch.zeros(per_rank, dtype=pay_dtype, device=dev) for _ in range(2)]
         recvs = [torch.empty(per_rank * world, dtype=pay_dtype, device=dev) for _ in range(2)]
@@ -354,7 +452,8 @@ def main():
         for i in range(nsteps):
             j = i & 1
             finish(j)
-            count_into(outs[j], a, b)
+            if exchange is not None:
+                batch.count_into(outs[j], a, b)
             if narrow and outs[j].numel():  # one reduction pass for both ends (u64 counts >= 2^63 look negative)
                 mn, mx = torch.aminmax(outs[j])
                 overflow |= (mx > NARROW_MAX) | (mn < 0)
@@ -372,54 +471,84 @@ def main():
         finish((nsteps - 1) & 1)
         return outs[(nsteps - 1) & 1], d_all, overflow
 
-    def timed(narrow, a, b, per_rank):
-        run_steps(args.warmup, narrow, a, b, per_rank)
+    def timed(batch, narrow, a, b, per_rank, native=None, exchange=True):
+        run_steps(batch, args.warmup, narrow, a, b, per_rank, native, exchange)
         fence()
-        bwt.device_status(stream)
-        bwt.set_kernel_timing(True)
+        batch.bwt.device_status(stream)
+        batch.bwt.set_kernel_timing(True)
         t_start = time.perf_counter()
-        d_mine, d_everything, ovf = run_steps(args.steps, narrow, a, b, per_rank)
+        d_mine, d_everything, ovf = run_steps(batch, args.steps, narrow, a, b, per_rank, native, exchange)
         fence()
         dt = time.perf_counter() - t_start
-        bwt.set_kernel_timing(False)
-        k_ms, n_launch = bwt.kernel_time_ms()
-        bwt.device_status(stream)
+        batch.bwt.set_kernel_timing(False)
+        k_ms, n_launch = batch.bwt.kernel_time_ms()
+        overflowed = bool(ovf) if native is None else False
+        try:
+            batch.bwt.device_status(stream)
+        except msbwt.MsbwtError as e:
+            if native is None or e.code != msbwt._lib.ERR_OVERFLOW:
+                raise
+            overflowed = True
         if multi:
-            flag = torch.tensor([1.0 if bool(ovf) else 0.0, dt], dtype=torch.float64,
+            flag = torch.tensor([1.0 if overflowed else 0.0, dt], dtype=torch.float64,
                                 device=dev if args.dist_backend == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             return d_mine, d_everything, float(flag[1].item()), k_ms, n_launch, flag[0].item() > 0
         return d_mine, d_everything, dt, k_ms, n_launch, False
 
-    def measure(a, b, per_rank):
+    def measure(batch, a, b, per_rank, native=None, exchange=True):
         narrow = multi and args.payload == "auto"
-        res = timed(narrow, a, b, per_rank)
+        res = timed(batch, narrow, a, b, per_rank, native, exchange)
         if res[5]:  # some count did not fit int16: measure again with u64 payloads (always exact)
             log("counts exceed int16: re-running with 64-bit payloads")
             narrow = False
-            res = timed(False, a, b, per_rank)
+            res = timed(batch, False, a, b, per_rank, native, exchange)
         return res[:5] + (narrow,)
 
-    d_out, d_all, elapsed, kernel_ms, launches, narrow = measure(lo, hi, cap)
+    def shard(n_all):
+        if strong:
+            a, b = msbwt.sharded.shard_bounds(n_all, world, rank)  # 16-query aligned: every shard keeps the fast kernels
+            return a, b, msbwt.sharded.shard_capacity(n_all, world)
+        return 0, n_all, n_all
+
+    def stitch(d_all, d_out, n_all, cap):
+        """the whole batch's counts as one vector (strong: stitched from the gathered shards)"""
+        if not strong:
+            return d_out
+        spans = [msbwt.sharded.shard_bounds(n_all, world, r) for r in range(world)]
+        return torch.cat([d_all[r * cap:r * cap + (b - a)] for r, (a, b) in enumerate(spans)])
+
+    main_batch = Batch(bwt, d_q, 0, d_reads)
+    lo, hi, cap = shard(nq)
+    mine_n = hi - lo
+    d_out, d_all, elapsed, kernel_ms, launches, narrow = measure(main_batch, lo, hi, cap)
     if multi:  # the gathered vector must contain this rank's own counts where they belong
         assert torch.equal(d_all[rank * cap:rank * cap + mine_n], d_out[:mine_n]), "gathered counts differ from the local ones"
     ms_per_step = elapsed / args.steps * 1e3
     job_queries = nq if (strong or not multi) else nq * world
     value = job_queries * args.steps / elapsed
+    d_counts = stitch(d_all, d_out, nq, cap)
 
-    # the whole batch's counts as one vector (strong: stitched from the gathered shards)
-    if strong:
-        spans = [msbwt.sharded.shard_bounds(nq, world, r) for r in range(world)]
-        d_counts = torch.cat([d_all[r * cap:r * cap + (b - a)] for r, (a, b) in enumerate(spans)])
-    else:
-        d_counts = d_out
+    # per-rank view of the timed region: the count kernel alone (HIP events on the launch stream), and the exchange
+    # step alone (the same all_gather + widening, timed without kernels) -- so that a sub-linear curve can be read
+    ranks_info = None
+    if multi:
+        _, _, ex_elapsed, _, _, _ = measure(main_batch, lo, hi, cap, exchange=None)
+        per = gather_floats([kernel_ms, ex_elapsed / args.steps * 1e3])
+        ranks_info = {"kernel_ms": [p[0] for p in per], "kernel_ms_min": min(p[0] for p in per), "kernel_ms_max": max(p[0] for p in per),
+                      "exchange_ms_alone": max(p[1] for p in per), "step_ms": ms_per_step,
+                      "step_minus_slowest_kernel_ms": ms_per_step - max(p[0] for p in per),
+                      "note": "kernel_ms: average count-kernel duration per rank; exchange_ms_alone: narrow + all_gather + widen of one step "
+                              "with no kernel running (max over ranks); inside a step the exchange overlaps the next step's kernel"}
 
     weak = None
     if strong and not args.no_weak:
         # every rank the same (whole or 1e8-query) batch, all N x n counts gathered each step; bounded so that
         # the N x n gathered vectors fit next to a 200 GB index at N = 8
         nw = min(nq, 100_000_000)
-        w_out, w_all, w_elapsed, _, _, w_narrow = measure(0, nw, nw)
+        was_strong, strong = strong, False
+        w_out, w_all, w_elapsed, _, _, w_narrow = measure(main_batch, 0, nw, nw)
+        strong = was_strong
         assert torch.equal(w_all[rank * nw:(rank + 1) * nw], w_out)
         assert torch.equal(w_out, d_counts[:nw]), "sharded counts differ from one GPU's counts of the same queries"
         weak = {"value": nw * world * args.steps / w_elapsed, "unit": "queries/s", "ms_per_step": w_elapsed / args.steps * 1e3,
@@ -427,10 +556,34 @@ def main():
                 "note": "every rank runs the same %d queries and all N x n counts are all_gathered each step" % nw}
         del w_out, w_all
 
+    # the same strong-scaling step with the LIBRARY's own RCCL call site (msbwt_rle_allgather_counts over a
+    # communicator made through msbwt_comm_*; the id travels through torch.distributed) -- what a Rust host with one
+    # process per GPU would run.  Extra, fenced: a failure here never costs the main line.
+    native = None
+    if multi and strong and args.dist_backend == "nccl" and not args.no_native_gather:
+        try:
+            id_t = torch.zeros(msbwt._lib.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                id_t.copy_(torch.frombuffer(bytearray(msbwt.RankComm.unique_id()), dtype=torch.uint8))
+            dist.broadcast(id_t, 0)
+            comm = msbwt.RankComm(world, bytes(id_t.cpu().numpy().tobytes()), rank)
+            n_out, n_all, n_elapsed, n_kms, _, n_narrow = measure(main_batch, lo, hi, cap, native=comm)
+            same = bool(torch.equal(n_all, d_all))
+            native = {"value": nq * args.steps / n_elapsed, "unit": "queries/s", "ms_per_step": n_elapsed / args.steps * 1e3,
+                      "kernel_ms": n_kms, "payload": "uint16" if n_narrow else "uint64", "equals_torch_path": same,
+                      "note": "msbwt_rle_allgather_counts (ncclAllGather bound at run time inside libmsbwt_hip.so), in stream order "
+                              "after the kernel -- no overlap with the next step"}
+            comm.close()
+            del n_out, n_all
+        except Exception as e:  # noqa: BLE001
+            native = {"error": repr(e)}
+            log("native gather failed: %r" % (e,))
+
     kind_text = {"walk": "present (LF-walk)", "random": "random", "reads": "read-derived"}[kind]
     if big:
-        wl = ("%s: structure-equivalent synthetic RLE stream (NOT a real BWT; 30x-human-scale stand-in), %d symbols, mean run %.1f; "
-              "%d %s %d-mers per step" % (args.workload, total, args.big_mean_run, nq, kind_text, k))
+        wl = ("%s: structure-equivalent synthetic RLE stream (NOT a real BWT; 30x-human-scale stand-in), %d symbols, run lengths %s; "
+              "%d %s %d-mers per step" % (args.workload, total, "drawn from the run-length histogram of config C4's real MSBWT (synth/c4_run_histogram.json)"
+                                          if hist_file else "geometric, mean %.1f" % args.big_mean_run, nq, kind_text, k))
     else:
         wl = ("%s: %d synthetic %d-bp reads (%.0fx of a %d-bp random genome, %.1f%% subst.) -> MSBWT of %d symbols; %d %s %d-mers per step"
               % (args.workload, len(reads), reads.shape[1], len(reads) * reads.shape[1] / max(1, int(cfg["genome"] * args.scale)),
@@ -445,14 +598,15 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "strong" if strong else "weak",
+        "scaling": "strong" if (strong or not multi) else "weak",
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
         "config": {
             "workload": wl, "k": k, "queries_per_step": job_queries, "queries_per_gpu": mine_n if strong else nq,
             "bwt_symbols": total, "index_bytes": bwt.device_bytes(),
-            "table_depth": bwt.get_table_depth(), "pair_index": bwt.get_pair_index(), "block_format": bwt.get_block_format(),
+            "table_depth": bwt.get_table_depth(), "pair_index": bwt.get_pair_index(), "pair_stride": bwt.get_pair_stride(),
+            "typical_range_width": bwt.get_typical_range_width(), "block_format": bwt.get_block_format(),
             "parallelism": ("index replicated x%d; %s; per step one %s all_gather of all counts (%s payload, widened to u64 on "
                             "arrival), overlapped with the next step's kernel"
                             % (world, "ONE fixed batch sharded over the ranks" if strong else "every rank its own whole batch",
@@ -462,9 +616,13 @@ def main():
     }
     if weak is not None:
         result["weak_scaling"] = weak
+    if ranks_info is not None:
+        result["ranks"] = ranks_info
+    if native is not None:
+        result["native_gather"] = native
 
-    # the rows the oracle will check travel to the host now; then the batch leaves HBM (the extra line
-    # below needs 39 GB next to a 200 GB index)
+    # the rows the oracle will check travel to the host now; then the batch leaves HBM (the extra lines
+    # below need up to 39 GB next to a 200 GB index)
     queries = got = None
     if rank == 0 and not args.no_oracle:
         rng = np.random.default_rng(5)
@@ -475,39 +633,41 @@ def main():
         else:
             queries = d_q[torch.from_numpy(sample_ids).to(dev)].cpu().numpy()
         got = d_counts[torch.from_numpy(sample_ids).to(dev)].cpu().numpy().astype(np.uint64)
-    del d_counts, d_out, d_all, d_q
+    del d_counts, d_out, d_all, d_q, main_batch
     torch.cuda.empty_cache()
 
-    # ---- BASELINE configs[4] in its literal shape on this GPU: 1e9 random 31-mers generated in HBM ----
+    # ---- BASELINE configs[4] in its literal shape: 1e9 random 31-mers generated in HBM, sharded over the ranks ----
     c5 = None
-    if human and world == 1 and not args.no_c5 and args.scale == 1.0:
+    if human and not args.no_c5 and args.scale == 1.0:
         t0 = time.time()
         n5 = args.c5_queries
-        d_q5 = device_random_kmers(torch, dev, n5, k, 99)
-        out5 = torch.empty(n5, dtype=torch.int64, device=dev)
-        bwt.count_kmers_device(d_q5.data_ptr(), k, n5, out5.data_ptr(), stream)  # warm-up pass
-        torch.cuda.synchronize(dev)
-        passes = 3
-        t1 = time.perf_counter()
-        for _ in range(passes):
-            bwt.count_kmers_device(d_q5.data_ptr(), k, n5, out5.data_ptr(), stream)
-        torch.cuda.synchronize(dev)
-        dt5 = (time.perf_counter() - t1) / passes
-        bwt.device_status(stream)
-        ids5 = torch.from_numpy(np.sort(np.random.default_rng(5).choice(n5, size=min(n5, args.parity_sample), replace=False))).to(dev)
-        c5 = {"queries": n5, "ms_per_pass": dt5 * 1e3, "value": n5 / dt5, "unit": "queries/s",
-              "kind": "uniform random ACGT 31-mers generated in HBM (BASELINE configs[4]'s query shape, one GPU)",
-              "_q": d_q5[ids5].cpu().numpy(), "_got": out5[ids5].cpu().numpy().astype(np.uint64)}
-        del d_q5, out5
+        lo5, hi5, cap5 = shard(n5)
+        d_q5 = device_random_kmers(torch, dev, lo5, hi5, k, 99)
+        b5 = Batch(bwt, d_q5, lo5)
+        saved_steps, saved_warm = args.steps, args.warmup
+        args.steps, args.warmup = 3, 1
+        o5, all5, el5, kms5, _, narrow5 = measure(b5, lo5, hi5, cap5)
+        args.steps, args.warmup = saved_steps, saved_warm
+        dt5 = el5 / 3
+        c5 = {"queries": n5, "queries_per_gpu": hi5 - lo5, "ms_per_pass": dt5 * 1e3, "kernel_ms": kms5, "value": n5 / dt5, "unit": "queries/s",
+              "kind": "uniform random ACGT 31-mers generated in HBM (BASELINE configs[4]'s query shape)%s"
+                      % ("; sharded over %d ranks, all counts all_gathered (%s payload) each pass" % (world, "int16" if narrow5 else "int64") if multi else ", one GPU")}
+        if rank == 0:  # parity on a sample of THIS rank's rows (rank 0 holds the first shard)
+            ids5 = torch.from_numpy(np.sort(np.random.default_rng(5).choice(hi5 - lo5, size=min(hi5 - lo5, args.parity_sample), replace=False))).to(dev)
+            c5["_q"] = d_q5[ids5].cpu().numpy()
+            c5["_got"] = o5[ids5].cpu().numpy().astype(np.uint64)
+        del d_q5, o5, all5, b5
+        torch.cuda.empty_cache()
         log("c5 line: %d random %d-mers in %.1f ms per pass (%.1fs incl. generation)" % (n5, k, dt5 * 1e3, time.time() - t0))
 
     rc = 0
+    ncpu = host_threads
+    ref = orc = None
     if rank == 0 and args.no_oracle:
         result["roofline"] = {"kernel_ms": kernel_ms, "kernel_launches": launches, "note": "--no-oracle: lean line of a profiling pass"}
         if c5 is not None:
-            del c5["_q"], c5["_got"]
+            c5.pop("_q", None), c5.pop("_got", None)
             result["c5_random_1e9"] = c5
-        emit(result)
     elif rank == 0:
         # ---- parity + algorithmic bytes (the oracle is the checker, never the thing timed as `value`) ----
         from oracle import oracle as orc
@@ -520,7 +680,6 @@ def main():
         log("oracle loaded in %.1fs" % (time.time() - t0))
         ns = min(len(queries), args.parity_sample)
         sel = np.linspace(0, len(queries) - 1, ns).astype(np.int64)
-        ncpu = min(os.cpu_count() or 1, 16)
         exp = ref.count_kmers(queries[sel], nthreads=ncpu)
         mism = int((exp != got[sel]).sum())
         result["parity"] = {"checked": int(ns), "mismatches": mism, "vs": "CPU oracle (restated RleBWT::count_kmer)",
@@ -536,61 +695,87 @@ def main():
             log("PARITY FAILURE: %d sampled counts differ from the oracle" % mism)
             result["value"] = None
             rc = 1
-        # algorithmic bytes of the reference algorithm for THIS query set: exact counters
-        st = orc.Stats()
-        nst = min(len(queries), args.stats_sample) if args.stats_sample else len(queries)
-        t0 = time.time()
-        ref.count_kmers(queries[:nst], nthreads=ncpu, stats=st)
-        t_all = time.time() - t0
         per_launch_q = mine_n if strong else nq
-        alg_bytes = st.algorithmic_bytes(k) / nst * per_launch_q  # exact when nst == nq, else scaled from the sample
         kern_s = kernel_ms / 1e3 if launches else elapsed / args.steps
-        # HBM traffic of one launch: PMC counters from separate rocprofv3 passes (FETCH_SIZE x2 on gfx950,
-        # WRITE_SIZE), committed under profiles/ and keyed by configuration AND kernel sources
-        traffic, traffic_src, traffic_note = None, None, "no PMC summary for this configuration under profiles/"
-        stamp = kernel_stamp()
-        try:
-            for ent in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["entries"]:
-                same = (ent["workload"] == args.workload and ent["k"] == k and ent["table_depth"] == bwt.get_table_depth()
-                        and ent.get("pair_index", False) == bwt.get_pair_index() and ent.get("query_kind", cfg["queries"]) == kind
-                        and ent.get("bwt_symbols", total) == total and args.scale == 1.0 and bool(ent.get("fused", False)) == bool(fused))
-                if same and ent.get("kernel_stamp") != stamp:
-                    traffic_note = "stale: %s was taken with kernel sources %s, the tree has %s" % (ent["source"], ent.get("kernel_stamp"), stamp)
-                elif same:
-                    traffic = ent["traffic_bytes_per_query"] * per_launch_q
-                    traffic_src, traffic_note = ent["source"], None
-        except (OSError, KeyError, ValueError):
-            pass
-        achieved = None if traffic is None else traffic / kern_s / 1e9
-        result["roofline"] = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": None if achieved is None else achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note, "kernel_stamp": stamp,
-            "kernel": kernel_label(bwt, k, fused),
-            "kernel_ms": kernel_ms, "kernel_launches": launches,
-            "algorithmic": {
-                "bytes_per_launch": int(alg_bytes), "bytes_per_query": alg_bytes / per_launch_q,
-                "GBps": alg_bytes / kern_s / 1e9, "x_hbm_peak": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
-                "mean_steps_per_query": st.steps / nst, "mean_bin_visits_per_query": st.visits / nst, "stats_queries": int(nst),
-                "note": "bytes the REFERENCE algorithm touches for this query set (SURVEY 8d: 56 B of samples + scanned RLE bytes per "
-                        "bin visit, + k + 8 per query) / kernel time.  The suffix table and pair steps make this kernel move fewer "
-                        "bytes than that, so it is a speed-up measure, not a bandwidth fraction"},
-            "note": "achieved/frac = measured HBM-side traffic of one launch (rocprofv3 PMC, committed summary) / kernel time measured "
-                    "live with HIP events on the launch stream / 8 TB/s",
-            "random_lines": None if traffic is None else {
-                "per_s": traffic / 128.0 / kern_s, "peak_per_s": RANDOM_LINE_PEAK, "frac": traffic / 128.0 / kern_s / RANDOM_LINE_PEAK},
-        }
+        tq, tsrc, tnote, stamp = lookup_traffic(args.workload, k, bwt, kind, total, fused, args.scale == 1.0)
+        result["roofline"] = roofline_block(orc, ref, queries, k, ncpu, per_launch_q, kern_s, kernel_ms, launches, tq, tsrc, tnote, stamp,
+                                            kernel_label(bwt, k, fused), args.stats_sample)
         if world == 1 and not args.no_cpu_baseline:
             ncs = min(len(queries), args.cpu_sample)
             t0 = time.time()
             ref.count_kmers(queries[:ncs], nthreads=1)
             t1 = time.time() - t0
+            t0 = time.time()
+            ref.count_kmers(queries, nthreads=nproc)   # no byte counters: the plain loop on every hardware thread
+            t_all = time.time() - t0
             result["cpu_baseline"] = {
                 "value": ncs / t1, "unit": "queries/s", "cores": 1, "kind": "port",
-                "cpu_model": cpu_model(), "nproc": os.cpu_count(),
+                "cpu_model": cpu_model(), "nproc": nproc,
                 "sample": "%d queries sampled from the same batch, same RLE stream / comp_msbwt.npy, 1 thread (the reference is single-threaded), -O3 C restatement" % ncs,
-                "all_cores": {"value": nst / t_all, "cores": ncpu, "note": "same sample, static partition, instrumented build"},
+                "all_cores": {"value": len(queries) / t_all, "cores": nproc,
+                              "note": "%d sampled queries, static partition over all %d hardware threads of this box's share, same un-instrumented build" % (len(queries), nproc)},
             }
+
+    # ---- the REAL 30x MSBWT (config C4: 12.9 M reads, 1.95e9 symbols), read-derived 31-mers, one GPU ----------------
+    # The human-scale stand-in stream has independent symbols: a present k-mer's range collapses to width 1, searches
+    # are easier than on real data.  This line carries the real thing into the same record: ranges stay ~ coverage wide.
+    c4_scale = args.c4_scale if args.c4_scale > 0 else (1.0 if args.scale == 1.0 else 0.0)
+    if human and world == 1 and not multi and not args.no_c4 and c4_scale > 0 and rank == 0:
+        del bwt, ref, rle, queries, got
+        torch.cuda.empty_cache()
+        t0 = time.time()
+        cfg4 = synth.CONFIGS["c4"]
+        npy4, reads4 = synth.workload_index("c4", c4_scale)
+        log("c4 line: real MSBWT %s ready in %.1fs" % (os.path.basename(npy4), time.time() - t0))
+        t0 = time.time()
+        bwt4 = msbwt.RleBWT(device=local_rank)
+        bwt4.load_numpy_file(npy4)
+        total4 = bwt4.get_total_size()
+        n4 = max(1000, int(args.c4_queries * min(1.0, c4_scale * 4))) if c4_scale < 1.0 else args.c4_queries
+        q4 = synth.read_kmers(reads4, 31, limit=n4, seed=cfg4["qseed"])
+        n4 = len(q4)
+        d_q4 = torch.from_numpy(q4).to(dev)
+        log("c4 line: %d symbols on the GPU (%.1f MB, table depth %d, pair stride %d, typical range width %.1f), %d read-derived 31-mers in HBM in %.1fs"
+            % (total4, bwt4.device_bytes() / 1e6, bwt4.get_table_depth(), bwt4.get_pair_stride(), bwt4.get_typical_range_width(), n4, time.time() - t0))
+        b4 = Batch(bwt4, d_q4, 0, None, 31)
+        o4, _, el4, kms4, launches4, _ = measure(b4, 0, n4, n4)
+        c4 = {"value": n4 * args.steps / el4, "unit": "queries/s", "ms_per_step": el4 / args.steps * 1e3, "steps": args.steps,
+              "config": {"workload": "c4: the REAL multi-string BWT of %d synthetic %d-bp reads (%.0fx of a %d-bp random genome, %.1f%% substitutions), "
+                                     "%d symbols, built on the host in this run; %d read-derived 31-mers per step"
+                                     % (len(reads4), reads4.shape[1], len(reads4) * reads4.shape[1] / max(1, int(cfg4["genome"] * c4_scale)),
+                                        int(cfg4["genome"] * c4_scale), cfg4["err"] * 100, total4, n4),
+                         "k": 31, "queries_per_step": n4, "bwt_symbols": total4, "index_bytes": bwt4.device_bytes(), "table_depth": bwt4.get_table_depth(),
+                         "pair_stride": bwt4.get_pair_stride(), "typical_range_width": bwt4.get_typical_range_width()}}
+        if not args.no_oracle:
+            from oracle import oracle as orc
+            ref4 = orc.OracleRleBWT(8)
+            ref4.load_numpy_file(npy4)
+            ids4 = np.sort(np.random.default_rng(6).choice(n4, size=min(n4, max(args.parity_sample, args.stats_sample)), replace=False))
+            got4 = o4[torch.from_numpy(ids4).to(dev)].cpu().numpy().astype(np.uint64)
+            qs4 = q4[ids4]
+            ns4 = min(len(qs4), args.parity_sample)
+            exp4 = ref4.count_kmers(qs4[:ns4], nthreads=ncpu)
+            m4 = int((exp4 != got4[:ns4]).sum())
+            c4["parity"] = {"checked": int(ns4), "mismatches": m4, "nonzero_counts_in_sample": int((got4 > 0).sum()),
+                            "mean_count_in_sample": float(got4.mean())}
+            if m4:
+                log("PARITY FAILURE on the c4 line: %d sampled counts differ from the oracle" % m4)
+                result["value"] = None
+                rc = 1
+            tq, tsrc, tnote, stamp = lookup_traffic("c4", 31, bwt4, "reads", total4, False, c4_scale == 1.0)
+            c4["roofline"] = roofline_block(orc, ref4, qs4, 31, ncpu, n4, kms4 / 1e3 if launches4 else el4 / args.steps, kms4, launches4, tq, tsrc,
+                                            tnote, stamp, kernel_label(bwt4, 31, False), args.stats_sample)
+            if not args.no_cpu_baseline:
+                ncs4 = min(len(qs4), args.cpu_sample // 4)
+                t0 = time.time()
+                ref4.count_kmers(qs4[:ncs4], nthreads=1)
+                c4["cpu_baseline"] = {"value": ncs4 / (time.time() - t0), "unit": "queries/s", "cores": 1, "kind": "port",
+                                      "sample": "%d of the same queries, 1 thread" % ncs4}
+        else:
+            c4["roofline"] = {"kernel_ms": kms4, "kernel_launches": launches4}
+        result["c4_real_reads"] = c4
+        log("c4 line: %.3e q/s, %.2f ms per step" % (c4["value"], c4["ms_per_step"]))
+    if rank == 0:
         emit(result)
     if multi:
         dist.barrier()

@@ -46,6 +46,8 @@ extern "C" {
 #define MSBWT_ERR_TOO_LARGE (-8)       /* total symbols >= 2^40 (device block counts are 40-bit) */
 #define MSBWT_ERR_INVALID_ARG (-9)
 #define MSBWT_ERR_INTERNAL (-10)       /* a device-side consistency check failed (a bug, not bad input) */
+#define MSBWT_ERR_OVERFLOW (-11)       /* a count did not fit the wire width of msbwt_rle_allgather_counts */
+#define MSBWT_ERR_RCCL (-12)           /* RCCL missing (librccl.so is bound at run time) or an RCCL call failed */
 
 typedef struct msbwt_rle msbwt_rle; /* opaque; replaces `struct RleBWT` (src/rle_bwt.rs:14-24) */
 
@@ -142,6 +144,29 @@ int msbwt_rle_count_read_kmers_multi(const msbwt_rle *const *replicas, size_t n_
 int msbwt_rle_count_kmers_multi_device(const msbwt_rle *const *replicas, size_t n_replicas, const void *d_kmers,
                                        size_t k, size_t n, void *d_out_counts);
 
+/* ---- one process per GPU (the shape `bench.py --gpus N` and an MPI-style Rust host use): every rank holds its
+ * own handle with a full index, counts its shard of the batch with msbwt_rle_count_kmers_device, and ONE
+ * collective leaves every rank with all counts -- ncclAllGather over RCCL / xGMI, the only exchange step of this
+ * path (queries are `&self`, src/msbwt_core.rs:125: no rank needs anything from another one before that).
+ * librccl.so is bound at run time (an RCCL already mapped into the process, e.g. PyTorch's, is shared);
+ * without it these calls return MSBWT_ERR_RCCL.
+ *
+ * Communicator bootstrap, for hosts that do not link RCCL themselves: rank 0 obtains an id
+ * (MSBWT_COMM_ID_BYTES opaque bytes), hands it to the other ranks by whatever channel the host has (a file, MPI,
+ * an environment variable), and every rank calls msbwt_comm_init_rank with its GPU current.  A communicator the
+ * host created itself (ncclComm_t) is accepted just as well. */
+#define MSBWT_COMM_ID_BYTES 128
+int msbwt_comm_get_unique_id(void *out_id);
+int msbwt_comm_init_rank(void **out_comm, int nranks, const void *id, int rank);
+int msbwt_comm_destroy(void *comm);
+/* d_all[r * n_mine + i] = rank r's d_mine[i] (u64 counts, device pointers on the handle's device; every rank
+ * passes the same n_mine -- pad the last shard), asynchronous on `hip_stream`.  wire_bits = 64, or 32 / 16: the
+ * counts travel narrowed and are widened on arrival (8 bytes per count over xGMI can cost more than the search
+ * itself); a count that does not fit makes msbwt_rle_device_status return MSBWT_ERR_OVERFLOW -- repeat the
+ * gather with 64.  Calls on one handle must be ordered by the caller (one stream): they share scratch memory. */
+int msbwt_rle_allgather_counts(const msbwt_rle *bwt, void *comm, const void *d_mine, size_t n_mine, void *d_all, int wire_bits,
+                               void *hip_stream);
+
 /* ---- tuning / introspection (no reference counterpart) ---- */
 /* Depth of the precomputed suffix table (the reference's stubbed kmer_cache,
  * src/msbwt_core.rs:133-146): ranges for every ACGT suffix of length `depth` are computed
@@ -186,23 +211,20 @@ int msbwt_rle_get_pair_index(const msbwt_rle *bwt);
  * also hold the first 32 positions of their successor (1.33 bytes per symbol), so that a range up to
  * 32 wide is ranked from ONE line -- on real 30x data ranges stay ~25 wide to the last step and every
  * fifth step would otherwise fetch a second line.  0 = automatic (default; MSBWT_PAIR_STRIDE=96|128
- * overrides): 96 when that takes at most a quarter of the free HBM; otherwise the DATA decide -- the packed
- * suffix table measures how wide the range of a present k-mer is when its search leaves the table
- * (msbwt_rle_get_typical_range_width), and disjoint blocks are replaced by overlapping ones when that width
- * is >= 8 and the bigger blocks fit with an eighth of the HBM to spare.  get returns 0 without a pair index.
- * Results never change. */
+ * overrides): 96 when that takes at most a quarter of the free HBM; otherwise the DATA decide -- at load time a
+ * few thousand present 24-mers are read off the index by LF walks and counted, and overlapping blocks are built
+ * when their median count (msbwt_rle_get_typical_range_width) is >= 8 and the bigger blocks fit beside the
+ * suffix table with an eighth of the HBM to spare.  get returns 0 without a pair index.  Results never change. */
 int msbwt_rle_set_pair_stride(msbwt_rle *bwt, int stride);
 int msbwt_rle_get_pair_stride(const msbwt_rle *bwt);
-/* sum(w^2) / sum(w) over the widths w of the packed table's ranges: the width of the range a random PRESENT
- * suffix finds itself in after `table depth` symbols (~ the coverage on a real read set, ~1-6 on a stream of
- * independent symbols).  -1 without a packed table. */
+/* Median number of occurrences of a 24-mer that is present in the index (4096 LF walks from pseudo-random rows,
+ * probed once per load): about the coverage on a real read set, 1 on a stream of independent symbols; the width
+ * the ranges of surviving queries keep through the search.  -1 = not probed (run blocks, empty index). */
 double msbwt_rle_get_typical_range_width(const msbwt_rle *bwt);
 /* The automatic spacing as a pure function (no device needed): for an index of `total_symbols` symbols with
- * `free_hbm_bytes` free once the plane blocks are in place on a device of `hbm_total_bytes`, the stride the
- * loader starts with and the one it ends with given the typical range width the packed table reports
- * (negative = unknown). */
-int msbwt_auto_pair_stride(uint64_t total_symbols, uint64_t free_hbm_bytes, uint64_t hbm_total_bytes, double typical_width,
-                           int *provisional_stride, int *final_stride);
+ * `free_hbm_bytes` free once the plane blocks are in place on a device of `hbm_total_bytes`, given the typical
+ * range width the probe reports (negative = unknown). */
+int msbwt_auto_pair_stride(uint64_t total_symbols, uint64_t free_hbm_bytes, uint64_t hbm_total_bytes, double typical_width, int *stride);
 /* Block format of the index, chosen BEFORE a load (MSBWT_BLOCKS=runs in the environment sets the
  * initial choice): 0 = bit-plane blocks (default: 0.5 byte per symbol, fastest, the only format the
  * pair index and the lane-per-query kernel work on), 1 = run blocks -- the layout of the reference's

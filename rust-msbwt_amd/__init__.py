@@ -11,10 +11,10 @@ string_util, bwt_converter.  Everything that computes runs in libmsbwt_hip.so.
 """
 from . import _lib
 from .msbwt_core import BWT, BWTRange, VC_LEN, LETTER_BITS, NUMBER_BITS, NUM_POWER, MASK, COUNT_MASK
-from .rle_bwt import RleBWT, MsbwtError
+from .rle_bwt import RleBWT, MsbwtError, RankComm
 from . import string_util, bwt_converter, msbwt_core, rle_bwt, sharded
 
-__all__ = ["BWT", "BWTRange", "RleBWT", "MsbwtError", "string_util", "bwt_converter", "msbwt_core",
+__all__ = ["BWT", "BWTRange", "RleBWT", "MsbwtError", "RankComm", "string_util", "bwt_converter", "msbwt_core",
            "rle_bwt", "sharded", "VC_LEN", "LETTER_BITS", "NUMBER_BITS", "NUM_POWER", "MASK", "COUNT_MASK"]
 
 
@@ -32,3 +32,15 @@ def auto_table_depths(total_symbols, free_hbm_bytes, pair_index=True):
     if rc:
         raise MsbwtError(rc, "msbwt_auto_table_depths")
     return flat.value, packed.value
+
+
+def auto_pair_stride(total_symbols, free_hbm_bytes, hbm_total_bytes, typical_width=-1.0):
+    """Spacing of the pair blocks (96 or 128) the loader picks for an index of that size: `free_hbm_bytes` free once
+    the plane blocks are in place, `typical_width` what the load-time probe reports about the data
+    (RleBWT.get_typical_range_width; negative = unknown).  Pure host logic (csrc/table_policy.hpp)."""
+    import ctypes
+    stride = ctypes.c_int(0)
+    rc = _lib.lib().msbwt_auto_pair_stride(int(total_symbols), int(free_hbm_bytes), int(hbm_total_bytes), float(typical_width), ctypes.byref(stride))
+    if rc:
+        raise MsbwtError(rc, "msbwt_auto_pair_stride")
+    return stride.value

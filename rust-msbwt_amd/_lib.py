@@ -9,6 +9,8 @@ LIB_PATH = os.path.join(HERE, "libmsbwt_hip.so")
 OK = 0
 ERR_IO, ERR_UNEXPECTED_EOF, ERR_BAD_HEADER, ERR_INVALID_SYMBOL = -1, -2, -3, -4
 ERR_INVALID_RANGE, ERR_HIP, ERR_NOT_LOADED, ERR_TOO_LARGE, ERR_INVALID_ARG, ERR_INTERNAL = -5, -6, -7, -8, -9, -10
+ERR_OVERFLOW, ERR_RCCL = -11, -12
+COMM_ID_BYTES = 128
 
 SIZE_MAX = C.c_size_t(-1).value
 
@@ -37,6 +39,10 @@ SIGNATURES = {
     "msbwt_rle_count_kmers_multi": (_int, [_vp, _sz, _vp, _sz, _sz, _vp]),
     "msbwt_rle_count_read_kmers_multi": (_int, [_vp, _sz, _vp, _sz, _sz, _sz, _int, _vp, _vp]),
     "msbwt_rle_count_kmers_multi_device": (_int, [_vp, _sz, _vp, _sz, _sz, _vp]),
+    "msbwt_comm_get_unique_id": (_int, [_vp]),
+    "msbwt_comm_init_rank": (_int, [C.POINTER(C.c_void_p), _int, _vp, _int]),
+    "msbwt_comm_destroy": (_int, [_vp]),
+    "msbwt_rle_allgather_counts": (_int, [_vp, _vp, _vp, _sz, _vp, _int, _vp]),
     "msbwt_rle_set_table_depth": (_int, [_vp, _int]),
     "msbwt_rle_get_table_depth": (_int, [_vp]),
     "msbwt_rle_set_table_packed": (_int, [_vp, _int]),
@@ -53,7 +59,7 @@ SIGNATURES = {
     "msbwt_rle_set_pair_stride": (_int, [_vp, _int]),
     "msbwt_rle_get_pair_stride": (_int, [_vp]),
     "msbwt_rle_get_typical_range_width": (C.c_double, [_vp]),
-    "msbwt_auto_pair_stride": (_int, [_u64, _u64, _u64, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "msbwt_auto_pair_stride": (_int, [_u64, _u64, _u64, C.c_double, C.POINTER(C.c_int)]),
     "msbwt_rle_device_bytes": (_u64, [_vp]),
     "msbwt_rle_kernel_time_ms": (_int, [_vp, C.POINTER(C.c_double), _pu64]),
     "msbwt_rle_set_kernel_timing": (_int, [_vp, _int]),

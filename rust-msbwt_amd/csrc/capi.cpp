@@ -14,6 +14,7 @@
 
 #include "../../include/msbwt_hip.h"
 #include "device_build.hpp"
+#include "gather.hpp"
 #include "host_pipeline.hpp"
 #include "kernels.hpp"
 #include "table_policy.hpp"
@@ -39,10 +40,11 @@ struct msbwt_rle {
     void *d_pair_blocks = nullptr;  // optional pair index (two symbols per step)
     void *d_pair_super = nullptr;
     uint64_t pair_bytes = 0;
+    uint64_t pair_overlap_bytes = 0;  // what overlapping pair blocks take beyond disjoint ones (0 unless the data-driven policy chose them)
     int wanted_pair = -1;           // -1 = on when it fits comfortably, 0 = off, 1 = on
     int pair_stride = 128;          // spacing of the pair blocks in HBM: 128, or 96 (overlapping)
     int wanted_pair_stride = 0;     // 0 = automatic (table_policy.hpp: cheap -> 96; else 96 when the data keep ranges wide and it fits)
-    double typical_width = -1.0;    // width of the range a present k-mer leaves the packed table with (-1: no packed table)
+    double typical_width = -1.0;    // median occurrence count of a present 24-mer, probed at load time (-1: not probed)
     void *d_table = nullptr;
     int table_depth = 0;         // symbols a table entry stands for (of the table currently in HBM)
     bool table_packed = false;   // packed lines (two levels deeper than the flat table it was made from)
@@ -73,6 +75,8 @@ struct msbwt_rle {
     // Small host batches (the trait's single-query calls above all): queries and results travel through ONE
     // mapped, coherent host buffer that the kernel reads and writes directly -- no copies, no memset, no flag
     // read-back; one launch and one stream synchronisation per call.
+    void *d_gather = nullptr;      // scratch of msbwt_rle_allgather_counts (narrow wire widths)
+    size_t gather_bytes = 0;
     uint8_t *mail = nullptr;       // host address
     uint8_t *d_mail = nullptr;     // the same buffer as the device sees it
     bool timing = false;
@@ -86,8 +90,7 @@ struct msbwt_rle {
 namespace {
 
 constexpr int kMaxTableDepth = 16;  // 4^16 x 16 B = 64 GiB
-constexpr size_t kStatusBytes = 1024;  // flag words, debug record (bytes 64..128), width statistics of the packed table
-constexpr size_t kWidthStatsOffset = 128;
+constexpr size_t kStatusBytes = 1024;  // flag words, debug record (bytes 64..128)
 constexpr size_t kMaxTimedEvents = 256;  // start/stop pairs kept before timed_launch folds them into the running sum
 constexpr int kHostFlags = 0, kDeviceFlags = 1;  // words of the status block
 
@@ -286,7 +289,6 @@ int rebuild_table(msbwt_rle *h) {
     h->table_depth = 0;
     h->table_packed = false;
     h->table_bytes = 0;
-    h->typical_width = -1.0;
     // Automatic depths come from ONE decision (table_policy.hpp, pinned by a CPU test through
     // msbwt_auto_table_depths): beside a pair index the flat table is built as deep as the packed one needs.
     const bool automatic = h->wanted_table_depth < 0;
@@ -295,7 +297,9 @@ int rebuild_table(msbwt_rle *h) {
     if (automatic) {
         size_t free_b = 0, total_b = 0;
         const bool know_free = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
-        const TableChoice c = choose_table_depths(h->totals.total, h->nblocks * kBlockBytes, know_free ? uint64_t(free_b) : 0,
+        // the table budgets against DISJOINT pair blocks: what overlapping ones take on top was checked against the
+        // reserve when they were chosen (choose_pair_stride)
+        const TableChoice c = choose_table_depths(h->totals.total, h->nblocks * kBlockBytes, know_free ? uint64_t(free_b) + h->pair_overlap_bytes : 0,
                                                   h->d_pair_blocks != nullptr, h->wanted_table_packed != 0);
         depth = c.flat;
         pack = c.packed != 0 || (h->d_pair_blocks != nullptr && h->wanted_table_packed > 0);  // mode 1: whenever a pair index exists
@@ -325,11 +329,8 @@ int rebuild_table(msbwt_rle *h) {
     // blocks).  Needs the pair index.
     const uint64_t pbytes = packed_table_bytes(depth + 2);
     void *packed = nullptr;
-    uint64_t *d_stats = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(h->d_flags) + kWidthStatsOffset), stats[2] = {0, 0};
     hipError_t e = hipMalloc(&packed, pbytes);
-    if (e == hipSuccess) e = hipMemsetAsync(d_stats, 0, sizeof stats, h->stream);
-    if (e == hipSuccess) e = launch_pack_table(view_of(h), depth, h->d_table, packed, d_stats, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(stats, d_stats, sizeof stats, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = launch_pack_table(view_of(h), depth, h->d_table, packed, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
         if (packed) (void)hipFree(packed);
@@ -355,32 +356,62 @@ int rebuild_table(msbwt_rle *h) {
     h->table_depth = depth + 2;
     h->table_packed = true;
     h->table_bytes = pbytes;
-    h->typical_width = typical_range_width(stats[0], stats[1]);
     return MSBWT_OK;
 }
 
 // Pair index (two symbols per step, rank_ops.hpp): 1 byte/symbol on top of the plane blocks,
 // built on the device from them.  Default policy: build it when it fits in half of what is
 // still free in HBM after the blocks (it is a pure speed-for-memory trade).
-int rebuild_pair_index(msbwt_rle *h, int forced_stride = 0) {
+// How wide is the range of a k-mer that occurs?  (kernels.hpp, launch_probe_widths: the median over a few thousand
+// sampled 24-mers; -1 when it cannot be told.)  Cheap: microseconds of kernel time, one 32 KiB read-back.
+double probe_typical_width(msbwt_rle *h) {
+    if (h->block_format != kBlocksPlanes || h->totals.total == 0) return -1.0;
+    uint64_t *d_out = nullptr;
+    std::vector<uint64_t> widths(kProbeSamples);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_out), widths.size() * sizeof(uint64_t));
+    if (e == hipSuccess) e = launch_probe_widths(view_of(h), kProbeSamples, kProbeSteps, 0x6D73627774ull, d_out, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(widths.data(), d_out, widths.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return -1.0;
+    }
+    widths.erase(std::remove(widths.begin(), widths.end(), uint64_t(0)), widths.end());  // walks that met '$' / 'N'
+    if (widths.size() < 64) return -1.0;
+    std::nth_element(widths.begin(), widths.begin() + widths.size() / 2, widths.end());
+    return double(widths[widths.size() / 2]);
+}
+
+// Pair index (two symbols per step, rank_ops.hpp): 1 byte/symbol on top of the plane blocks,
+// built on the device from them.  Default policy: build it when it fits in half of what is
+// still free in HBM after the blocks (it is a pure speed-for-memory trade).
+int rebuild_pair_index(msbwt_rle *h) {
     if (h->d_pair_blocks) (void)hipFree(h->d_pair_blocks);
     if (h->d_pair_super) (void)hipFree(h->d_pair_super);
     h->d_pair_blocks = h->d_pair_super = nullptr;
     h->pair_bytes = 0;
+    h->pair_overlap_bytes = 0;
     if (h->wanted_pair == 0 || h->totals.total == 0 || h->block_format != kBlocksPlanes) return MSBWT_OK;  // built from plane blocks
-    // Spacing (table_policy.hpp): an explicit wish is taken literally; otherwise overlapping blocks (stride 96,
-    // 1.33 bytes per symbol: ranges up to 32 wide from one line) when they are cheap in HBM, disjoint ones for
-    // now when they are not -- widen_pair_blocks_if_warranted() looks again once the packed table knows how
-    // wide the data keep their ranges.
+    // Spacing (table_policy.hpp, choose_pair_stride): an explicit wish is taken literally; otherwise overlapping
+    // blocks (stride 96, 1.33 bytes per symbol: ranges up to 32 wide from one line) when they are cheap in HBM, and
+    // when they are not, when the DATA keep the ranges of present k-mers wide (probed above) and the bigger blocks
+    // fit beside the table that is about to be built.
     size_t free_b = 0, total_b = 0;
     const bool know_free = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
-    int stride = forced_stride ? forced_stride : h->wanted_pair_stride;
+    int stride = h->wanted_pair_stride;
+    bool by_data = false;
     if (stride != 96 && stride != 128) {
-        const PairIndexSizes wide = pair_index_sizes(h->nblocks, 96);
-        stride = know_free ? provisional_pair_stride(wide.pair_block_bytes + wide.super_bytes + wide.scratch_bytes, free_b) : 128;
+        const PairIndexSizes wide = pair_index_sizes(h->nblocks, 96), narrow = pair_index_sizes(h->nblocks, 128);
+        const uint64_t bytes96 = wide.pair_block_bytes + wide.super_bytes + wide.scratch_bytes, bytes128 = narrow.pair_block_bytes + narrow.super_bytes;
+        const uint64_t after128 = uint64_t(free_b) > bytes128 ? uint64_t(free_b) - bytes128 : 0;
+        const uint64_t table_b = expected_table_bytes(h->totals.total, h->nblocks * kBlockBytes, after128, true, h->wanted_table_packed != 0);
+        stride = know_free ? choose_pair_stride(bytes96, table_b, free_b, total_b, h->typical_width) : 128;
+        by_data = stride == 96 && bytes96 > uint64_t(free_b) / 4;
+        if (by_data) h->pair_overlap_bytes = wide.pair_block_bytes + wide.super_bytes - bytes128;
     }
     const PairIndexSizes sz = pair_index_sizes(h->nblocks, stride);
-    if (h->wanted_pair < 0 && !forced_stride) {  // (a forced stride comes from the policy, which has checked the fit)
+    if (h->wanted_pair < 0 && !by_data) {  // (the data-driven choice has checked its own fit)
         if (!know_free || sz.pair_block_bytes + sz.scratch_bytes > free_b / 2) return MSBWT_OK;
     }
     void *scratch = nullptr;
@@ -394,30 +425,13 @@ int rebuild_pair_index(msbwt_rle *h, int forced_stride = 0) {
         if (h->d_pair_blocks) (void)hipFree(h->d_pair_blocks);
         if (h->d_pair_super) (void)hipFree(h->d_pair_super);
         h->d_pair_blocks = h->d_pair_super = nullptr;
+        h->pair_overlap_bytes = 0;
         if (h->wanted_pair < 0 && e == hipErrorOutOfMemory) return MSBWT_OK;  // optional structure
         return hip_fail(h, e, "build pair index");
     }
     h->pair_stride = stride;
     h->pair_bytes = sz.pair_block_bytes + sz.super_bytes;
     return MSBWT_OK;
-}
-
-// The second look at the pair spacing (table_policy.hpp, final_pair_stride): the packed table has just measured
-// how wide a present k-mer's range is when it leaves the table.  Disjoint blocks chosen for lack of HBM are
-// replaced by overlapping ones when the data keep ranges wide and the bigger blocks fit next to the table.  The
-// table itself holds ranges, not block addresses: it stays.
-int widen_pair_blocks_if_warranted(msbwt_rle *h) {
-    if (!h->d_pair_blocks || h->wanted_pair_stride == 96 || h->wanted_pair_stride == 128 || h->pair_stride != 128) return MSBWT_OK;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return MSBWT_OK;
-    const PairIndexSizes wide = pair_index_sizes(h->nblocks, 96), now = pair_index_sizes(h->nblocks, 128);
-    const int stride = final_pair_stride(128, h->typical_width, wide.pair_block_bytes + wide.super_bytes + wide.scratch_bytes, free_b,
-                                         now.pair_block_bytes + now.super_bytes, uint64_t(total_b) / 8);
-    if (stride == 128) return MSBWT_OK;
-    const int rc = rebuild_pair_index(h, 96);
-    if (rc == MSBWT_OK && h->d_pair_blocks) return MSBWT_OK;
-    (void)hipGetLastError();
-    return rebuild_pair_index(h, 128);  // did not fit after all: back to what there was
 }
 
 // Index build on the host (kept for MSBWT_BUILD=host and for cross-checking the device
@@ -540,22 +554,18 @@ int install(msbwt_rle *h, const uint8_t *rle, size_t n) {
     h->nblocks = h->block_format == kBlocksRuns ? run_block_count(t.total) : plane_block_count(t.total);
     h->loaded = true;
     stage(h->block_format == kBlocksRuns ? "run blocks (host build)" : "plane blocks", h->nblocks * kBlockBytes + h->overflow_bytes);
+    h->typical_width = probe_typical_width(h);
     rc = rebuild_pair_index(h);  // first: the table may be packed with its help
     if (!rc) stage(h->pair_stride == 96 ? "pair blocks, stride 96" : "pair blocks, stride 128", h->pair_bytes);
     if (!rc) rc = rebuild_table(h);
     if (!rc) stage(h->table_packed ? "suffix table, packed" : "suffix table, flat", h->table_bytes);
-    if (!rc) {
-        const int before = h->pair_stride;
-        rc = widen_pair_blocks_if_warranted(h);
-        if (!rc && h->pair_stride != before) stage("pair blocks -> stride 96", h->pair_bytes);
-    }
     if (rc) {
         release_index(h);
         return rc;
     }
     if (verbose)
-        std::fprintf(stderr, "[msbwt] load: %llu symbols, table depth %d, typical range width after the table %.1f, %.2f GB of HBM in all\n",
-                     (unsigned long long)t.total, h->table_depth, h->typical_width,
+        std::fprintf(stderr, "[msbwt] load: %llu symbols, table depth %d, a present %u-mer occurs %.0f times (median), %.2f GB of HBM in all\n",
+                     (unsigned long long)t.total, h->table_depth, kProbeSteps, h->typical_width,
                      double(h->nblocks * kBlockBytes + h->overflow_bytes + h->pair_bytes + h->table_bytes) / 1e9);
     h->err.clear();
     return MSBWT_OK;
@@ -582,6 +592,7 @@ int flags_to_code(msbwt_rle *h, uint32_t flags) {
     }
     if (flags & kFlagInvalidSymbol) return fail(h, MSBWT_ERR_INVALID_SYMBOL, "a query holds a symbol code >= 6");
     if (flags & kFlagInvalidRange) return fail(h, MSBWT_ERR_INVALID_RANGE, "a range has l > h or h > total size");
+    if (flags & kFlagNarrowOverflow) return fail(h, MSBWT_ERR_OVERFLOW, "a count does not fit the wire width of the all-gather: repeat it with 64 bits");
     return MSBWT_OK;
 }
 
@@ -674,6 +685,7 @@ void msbwt_rle_free(msbwt_rle *h) {
         }
         h->pipe.release();
         if (h->mail) (void)hipHostFree(h->mail);
+        if (h->d_gather) (void)hipFree(h->d_gather);
         if (h->d_stage) (void)hipFree(h->d_stage);
         if (h->d_flags) (void)hipFree(h->d_flags);
         if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1052,6 +1064,7 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
     h->table_packed = src->table_packed;
     h->table_bytes = src->table_bytes;
     h->typical_width = src->typical_width;
+    h->pair_overlap_bytes = src->pair_overlap_bytes;
     h->filter_depth = src->filter_depth;
     h->pair_bytes = src->pair_bytes;
     h->loaded = true;
@@ -1169,6 +1182,57 @@ int msbwt_rle_count_kmers_multi_device(const msbwt_rle *const *replicas, size_t 
     return first;
 }
 
+// ---- one process per GPU: the final count gather over RCCL ------------------------------------------------
+int msbwt_comm_get_unique_id(void *out_id) {
+    std::string why;
+    if (!out_id) return MSBWT_ERR_INVALID_ARG;
+    return comm_unique_id(out_id, &why) ? MSBWT_OK : MSBWT_ERR_RCCL;
+}
+
+int msbwt_comm_init_rank(void **out_comm, int nranks, const void *id, int rank) {
+    std::string why;
+    if (!out_comm || !id || nranks < 1 || rank < 0 || rank >= nranks) return MSBWT_ERR_INVALID_ARG;
+    if (!comm_init_rank(out_comm, nranks, id, rank, &why)) {
+        std::fprintf(stderr, "[msbwt] msbwt_comm_init_rank: %s\n", why.c_str());
+        return MSBWT_ERR_RCCL;
+    }
+    return MSBWT_OK;
+}
+
+int msbwt_comm_destroy(void *comm) {
+    std::string why;
+    if (!comm) return MSBWT_ERR_INVALID_ARG;
+    return comm_destroy(comm, &why) ? MSBWT_OK : MSBWT_ERR_RCCL;
+}
+
+int msbwt_rle_allgather_counts(const msbwt_rle *ch, void *comm, const void *d_mine, size_t n_mine, void *d_all, int wire_bits,
+                               void *hip_stream) {
+    msbwt_rle *h = const_cast<msbwt_rle *>(ch);
+    if (!h) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!comm || (wire_bits != 64 && wire_bits != 32 && wire_bits != 16) || (n_mine && (!d_mine || !d_all)))
+        return fail(h, MSBWT_ERR_INVALID_ARG, "allgather_counts needs a communicator, buffers and a wire width of 64, 32 or 16 bits");
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    int rc = ensure_runtime(h);
+    if (rc) return rc;
+    std::string why;
+    const int nranks = comm_ranks(comm, &why);
+    if (nranks < 1) return fail(h, MSBWT_ERR_RCCL, why);
+    const size_t need = allgather_scratch_bytes(n_mine, nranks, wire_bits);
+    if (need > h->gather_bytes) {  // (hipFree waits for the device: no gather still reads the old buffer)
+        if (h->d_gather) (void)hipFree(h->d_gather);
+        h->d_gather = nullptr;
+        h->gather_bytes = 0;
+        HIP_TRY(h, hipMalloc(&h->d_gather, need));
+        h->gather_bytes = need;
+    }
+    const hipError_t e = allgather_counts(comm, nranks, static_cast<const uint64_t *>(d_mine), n_mine, static_cast<uint64_t *>(d_all), wire_bits,
+                                          h->d_gather, h->d_flags + kDeviceFlags, static_cast<hipStream_t>(hip_stream), &why);
+    if (e == hipSuccess) return MSBWT_OK;
+    return why.empty() ? hip_fail(h, e, "all-gather of the counts") : fail(h, MSBWT_ERR_RCCL, why);
+}
+
 int msbwt_rle_set_table_depth(msbwt_rle *h, int depth) {
     if (!h || depth > kMaxTableDepth) return MSBWT_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
@@ -1188,9 +1252,8 @@ int msbwt_rle_set_pair_index(msbwt_rle *h, int mode) {
     if (!h->loaded) return MSBWT_OK;
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
-    int rc = rebuild_pair_index(h);
-    if (!rc) rc = rebuild_table(h);  // the table's packed form exists only beside a pair index
-    return rc ? rc : widen_pair_blocks_if_warranted(h);
+    const int rc = rebuild_pair_index(h);
+    return rc ? rc : rebuild_table(h);  // the table's packed form exists only beside a pair index
 }
 
 int msbwt_rle_get_pair_index(const msbwt_rle *h) { return (h && h->d_pair_blocks) ? 1 : 0; }
@@ -1202,9 +1265,8 @@ int msbwt_rle_set_pair_stride(msbwt_rle *h, int stride) {
     if (!h->loaded) return MSBWT_OK;
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
-    int rc = rebuild_pair_index(h);
-    if (!rc) rc = rebuild_table(h);
-    return rc ? rc : widen_pair_blocks_if_warranted(h);
+    const int rc = rebuild_pair_index(h);
+    return rc ? rc : rebuild_table(h);
 }
 
 int msbwt_rle_get_pair_stride(const msbwt_rle *h) { return (h && h->d_pair_blocks) ? h->pair_stride : 0; }
@@ -1250,20 +1312,14 @@ int msbwt_auto_table_depths(uint64_t total_symbols, uint64_t free_hbm_bytes, int
     return MSBWT_OK;
 }
 
-int msbwt_auto_pair_stride(uint64_t total_symbols, uint64_t free_hbm_bytes, uint64_t hbm_total_bytes, double typical_width,
-                           int *provisional_stride, int *final_stride) {
-    if (!provisional_stride || !final_stride) return MSBWT_ERR_INVALID_ARG;
+int msbwt_auto_pair_stride(uint64_t total_symbols, uint64_t free_hbm_bytes, uint64_t hbm_total_bytes, double typical_width, int *stride) {
+    if (!stride) return MSBWT_ERR_INVALID_ARG;
     const uint64_t nblocks = plane_block_count(total_symbols);
     const PairIndexSizes wide = pair_index_sizes(nblocks, 96), narrow = pair_index_sizes(nblocks, 128);
     const uint64_t bytes96 = wide.pair_block_bytes + wide.super_bytes + wide.scratch_bytes, bytes128 = narrow.pair_block_bytes + narrow.super_bytes;
-    *provisional_stride = *final_stride = provisional_pair_stride(bytes96, free_hbm_bytes);
-    if (*provisional_stride == 96) return MSBWT_OK;
-    // the same sequence the loader goes through: disjoint blocks, the table beside them, then the second look
-    const uint64_t free2 = free_hbm_bytes > bytes128 ? free_hbm_bytes - bytes128 : 0;
-    const TableChoice c = choose_table_depths(total_symbols, nblocks * kBlockBytes, free2, true, true);
-    const uint64_t table_bytes = c.packed ? packed_table_bytes(c.packed) : (c.flat ? uint64_t(16) << (2 * c.flat) : 0);
-    const uint64_t free3 = free2 > table_bytes ? free2 - table_bytes : 0;
-    *final_stride = final_pair_stride(128, c.packed ? typical_width : -1.0, bytes96, free3, bytes128, hbm_total_bytes / 8);
+    const uint64_t after128 = free_hbm_bytes > bytes128 ? free_hbm_bytes - bytes128 : 0;
+    *stride = choose_pair_stride(bytes96, expected_table_bytes(total_symbols, nblocks * kBlockBytes, after128, true, true), free_hbm_bytes,
+                                 hbm_total_bytes, typical_width);
     return MSBWT_OK;
 }
 

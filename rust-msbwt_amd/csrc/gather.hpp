@@ -1,0 +1,26 @@
+// The RCCL all-gather of the counts (gather.hip): the one exchange step of the one-process-per-GPU form.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+namespace msbwt {
+
+constexpr size_t kCommIdBytes = 128;  // sizeof(ncclUniqueId)
+
+bool rccl_available(std::string *why);
+bool comm_unique_id(void *out_id, std::string *why);
+bool comm_init_rank(void **out_comm, int nranks, const void *id, int rank, std::string *why);
+bool comm_destroy(void *comm, std::string *why);
+int comm_ranks(void *comm, std::string *why);  // -1 on error
+
+// d_all[r * n_mine + i] = rank r's d_mine[i], on every rank; wire_bits 64, 32 or 16 (narrower widths need
+// allgather_scratch_bytes of device scratch; a count that does not fit sets kFlagNarrowOverflow in *flags).
+// Asynchronous on `stream`.
+hipError_t allgather_counts(void *comm, int nranks, const uint64_t *d_mine, size_t n_mine, uint64_t *d_all, int wire_bits, void *d_scratch,
+                            uint32_t *flags, hipStream_t stream, std::string *why);
+size_t allgather_scratch_bytes(size_t n_mine, int nranks, int wire_bits);
+
+}  // namespace msbwt

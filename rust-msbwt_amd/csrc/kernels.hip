@@ -301,12 +301,8 @@ __device__ __forceinline__ uint64_t pair_bound_thread(const uint4 *__restrict__ 
 // (t mod 4^flat_depth) by the two symbols in t's top four bits, t = 30 line + i.
 __global__ __launch_bounds__(256) void k_table_pack(const uint4 *__restrict__ flat, uint32_t flat_depth,
                                                     const uint4 *__restrict__ pair_blocks, const uint64_t *__restrict__ pair_super,
-                                                    uint32_t stride96, uint32_t *__restrict__ packed, uint64_t nlines,
-                                                    unsigned long long *__restrict__ stats) {
+                                                    uint32_t stride96, uint32_t *__restrict__ packed, uint64_t nlines) {
     const uint32_t lane = threadIdx.x & 63u, i = lane & 31u, team_first = lane & 32u;
-    // stats[0] += sum of range widths w, stats[1] += sum of w x min(w, 65535): their quotient is the width of the
-    // range a random present suffix finds itself in once the table has been consumed (table_policy.hpp)
-    uint64_t sum_w = 0, sum_ww = 0;
     const uint64_t entries = 1ull << (2u * (flat_depth + 2u)), parent_mask = (1ull << (2u * flat_depth)) - 1ull;
     const uint64_t nteams = (uint64_t(gridDim.x) * blockDim.x) / 32;
     for (uint64_t line = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) / 32; line < nlines; line += nteams) {
@@ -324,10 +320,6 @@ __global__ __launch_bounds__(256) void k_table_pack(const uint4 *__restrict__ fl
             }
         }
         const bool nonempty = valid && l != h;
-        if (nonempty) {
-            sum_w += h - l;
-            sum_ww += (h - l) * min(h - l, uint64_t(65535));
-        }
         // base = the first non-empty range's l (ranges of consecutive indices are consecutive, so l is monotone)
         const uint64_t ne = __ballot(nonempty);
         const uint32_t mine32 = uint32_t(ne >> team_first);
@@ -345,16 +337,37 @@ __global__ __launch_bounds__(256) void k_table_pack(const uint4 *__restrict__ fl
             out[1] = uint32_t(b >> 32);
         }
     }
-    if (stats != nullptr) {  // one pair of atomics per wave, once
-        for (int d = 32; d >= 1; d >>= 1) {
-            sum_w += (uint64_t(uint32_t(__shfl_xor(int(uint32_t(sum_w >> 32)), d))) << 32) | uint32_t(__shfl_xor(int(uint32_t(sum_w)), d));
-            sum_ww += (uint64_t(uint32_t(__shfl_xor(int(uint32_t(sum_ww >> 32)), d))) << 32) | uint32_t(__shfl_xor(int(uint32_t(sum_ww)), d));
-        }
-        if (lane == 0u && sum_w != 0ull) {
-            atomicAdd(stats, sum_w);
-            atomicAdd(stats + 1, sum_ww);
-        }
+}
+
+// ---- what the DATA look like: how wide is the range of a k-mer that is present? -------------------------------
+// Sample g starts at a pseudo-random row r and walks backwards: the symbol stored at row r (the one that precedes
+// suffix r in the text) is prepended to the pattern -- one step of the backward search [l, h) -> constrain(s, [l, h))
+// -- and r moves on to LF(r), which lies inside the new range by construction.  After `steps` symbols h - l is the
+// number of occurrences of a `steps`-mer that is known to occur: about the coverage on a real read set, 1 on a
+// stream of independent symbols.  out[g] = 0 for walks that met '$' / 'N'.  Plane blocks only.
+__global__ __launch_bounds__(256) void k_probe_widths(const uint4 *__restrict__ blocks, uint64_t total, uint32_t nsamples, uint32_t steps,
+                                                      uint64_t seed, uint64_t *__restrict__ out) {
+    const uint32_t sub = threadIdx.x & (kGroup - 1), lane = threadIdx.x & 63u;
+    const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
+    if (g >= nsamples || total == 0) return;
+    uint64_t z = seed + uint64_t(g + 1u) * 0x9E3779B97F4A7C15ull;  // splitmix64
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    uint64_t r = z % total, l = 0, h = total;
+    bool ok = true;
+    for (uint32_t t = 0; t < steps && ok; ++t) {
+        const uint4 c = blocks[(r >> 8) * kGroup + sub];
+        const uint32_t bit = uint32_t(r) & 31u;
+        const uint32_t mine = ((c.x >> bit) & 1u) | (((c.y >> bit) & 1u) << 1) | (((c.z >> bit) & 1u) << 2);
+        const uint32_t s = uint32_t(__shfl(int(mine), int((lane & ~7u) + ((uint32_t(r) & 255u) >> 5))));
+        if (!is_acgt(s)) { ok = false; break; }  // group-uniform
+        r = constrain(blocks, s, r, r + 1, sub).l;
+        const Range q = constrain(blocks, s, l, h, sub);
+        l = q.l;
+        h = q.h;
     }
+    if (sub == 0u) out[g] = ok ? h - l : 0ull;
 }
 
 __global__ void k_table_root(uint4 *table, uint64_t total) {
@@ -517,12 +530,19 @@ hipError_t launch_build_table(const IndexView &ix, int depth, void *entries, hip
 }
 
 hipError_t launch_pack_table(const IndexView &ix, int flat_depth, const void *flat_entries, void *packed_entries,
-                             uint64_t *d_width_stats, hipStream_t stream) {
+                             hipStream_t stream) {
     if (flat_depth < 1 || flat_depth > 16 || !ix.pair_blocks || !ix.pair_super) return hipErrorInvalidValue;
     const uint64_t nlines = packed_table_bytes(flat_depth + 2) / 128;
     hipLaunchKernelGGL(k_table_pack, dim3(grid_for(nlines * 32)), dim3(256), 0, stream, static_cast<const uint4 *>(flat_entries),
                        uint32_t(flat_depth), static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, ix.pair_stride96 ? 1u : 0u,
-                       static_cast<uint32_t *>(packed_entries), nlines, reinterpret_cast<unsigned long long *>(d_width_stats));
+                       static_cast<uint32_t *>(packed_entries), nlines);
+    return hipGetLastError();
+}
+
+hipError_t launch_probe_widths(const IndexView &ix, uint32_t nsamples, uint32_t steps, uint64_t seed, uint64_t *d_out, hipStream_t stream) {
+    if (ix.block_format != kBlocksPlanes || nsamples == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_probe_widths, dim3((nsamples * kGroup + 255) / 256), dim3(256), 0, stream, static_cast<const uint4 *>(ix.blocks), ix.total,
+                       nsamples, steps, seed, d_out);
     return hipGetLastError();
 }
 

@@ -10,6 +10,7 @@ namespace msbwt {
 constexpr uint32_t kFlagInvalidSymbol = 1u;
 constexpr uint32_t kFlagInvalidRange = 2u;
 constexpr uint32_t kFlagInternal = 4u;  // a device-side consistency check failed (never on a well-formed index)
+constexpr uint32_t kFlagNarrowOverflow = 8u;  // a count did not fit the wire width of msbwt_rle_allgather_counts
 
 // One entry of the suffix table: the range after the last `depth` symbols of a k-mer.
 struct TableView {
@@ -83,10 +84,12 @@ hipError_t launch_build_table(const IndexView &ix, int depth, void *entries, hip
 // Packs a finished FLAT table of `flat_depth` levels into a PACKED table two levels deeper
 // (`packed_entries`: ceil(4^(flat_depth+2) / 30) lines of 128 bytes): every entry is extended by
 // one two-symbol step of the pair index (required).  Returns the packed size through the helper.
-// d_width_stats (optional, 2 x u64, zeroed by the caller): += sum of the packed ranges' widths w, += sum of
-// w x min(w, 65535) -- what the pair-stride policy reads (table_policy.hpp, typical_range_width).
 hipError_t launch_pack_table(const IndexView &ix, int flat_depth, const void *flat_entries, void *packed_entries,
-                             uint64_t *d_width_stats, hipStream_t stream);
+                             hipStream_t stream);
+// d_out[g] (g < nsamples) = number of occurrences of a `steps`-mer that is PRESENT in the index (an LF walk from a
+// pseudo-random row, searched as it is read off; 0 = the walk met '$' / 'N').  What the pair-stride policy reads
+// (table_policy.hpp).  Plane blocks only.
+hipError_t launch_probe_widths(const IndexView &ix, uint32_t nsamples, uint32_t steps, uint64_t seed, uint64_t *d_out, hipStream_t stream);
 inline uint64_t packed_table_bytes(int depth) { return ((uint64_t(1) << (2 * depth)) + 29) / 30 * 128; }
 // filter (zero-filled, 4^filter_depth bits) from a finished table of `depth` levels
 hipError_t launch_build_filter(const void *entries, int depth, int filter_depth, uint32_t *filter, hipStream_t stream);

@@ -52,10 +52,17 @@ constexpr int kRing = 64;        // undecided queries waiting for a lane: one ti
 // cost 7 % (the queries of a tile take their first, widest step together), four more waves bring 13 %.
 // Round 3: ring entries shrank to 24 / 36 bytes (RingItemT) and the line list moved INTO the line area,
 // so searches of k > 32 fit the same 10 regions and 12 waves (they had 14 regions and 8 waves).
+// MSBWT_LANES_SPLIT (default): a range that straddles two lines takes TWO iterations -- first the line of l,
+// then the line of h -- instead of a second-line slot in the same iteration: exactly one line per lane and
+// iteration, 8 regions, no compaction of second lines, no lane ever sits a step out, and the wave no longer
+// runs the second-line rank code whenever ANY of its 64 lanes straddles (which was nearly always).
+#ifndef MSBWT_LANES_SPLIT
+#define MSBWT_LANES_SPLIT 1
+#endif
 #ifdef MSBWT_LANES_REGIONS  // experiments
 template <int kWords> constexpr int kRegionsFor = MSBWT_LANES_REGIONS;
 #else
-template <int kWords> constexpr int kRegionsFor = 10;
+template <int kWords> constexpr int kRegionsFor = MSBWT_LANES_SPLIT ? 8 : 10;
 #endif
 #ifndef MSBWT_LANES_WAVE_CAP
 #define MSBWT_LANES_WAVE_CAP 12
@@ -76,7 +83,7 @@ struct LaneScratchT {
     static constexpr int kRegions = kRegionsFor<kWords>;
     static constexpr int kLineSlots = kRegions * 8;
     static constexpr uint32_t kMaxSecond = uint32_t(kLineSlots) - 64u;  // lanes beyond that with a second line sit the step out
-    static_assert(kRegions >= 10 && kRegions % 2 == 0, "first-bound lines take 8 regions; regions come in padded pairs");
+    static_assert(kRegions >= 8 && kRegions % 2 == 0, "first-bound lines take 8 regions; regions come in padded pairs");
     // Region i (one LDS-DMA instruction: lane j writes 16 bytes at 16 j) starts at uint4 index
     // region_base(i): every odd region is pushed 128 bytes further, so that the 64 lanes'
     // read-back of "chunk j of my line" touches every bank exactly once per 16 lanes (lanes 16 m ..
@@ -233,6 +240,10 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
     uint64_t l = 0, h = 0;
     uint32_t w[kWords], rem = 0;
     uint64_t qid = 0;  // global index of the lane's query
+#if MSBWT_LANES_SPLIT
+    bool half = false;     // l has taken this step already (its new value waits in new_l); h's line comes next
+    uint64_t new_l = 0;
+#endif
 #pragma unroll
     for (int i = 0; i < kWords; ++i) w[i] = 0;
 
@@ -336,6 +347,9 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
                 rem = (it.meta >> 16) & 0xFFu;
                 qid = ring_tile * kTile + (it.meta >> 24);
                 have = true;
+#if MSBWT_LANES_SPLIT
+                half = false;
+#endif
             }
             const uint32_t taken = min(ring_count, uint32_t(__popcll(idle)));
             ring_head = (ring_head + taken) & (kRing - 1);
@@ -453,6 +467,73 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
         const uint32_t a2 = acgt_code(s1) & 3u, b2 = acgt_code(s2) & 3u;
         constexpr bool s96 = kStride96;  // compile-time: the stride-128 kernel carries no division
         const uint64_t base = pair ? reinterpret_cast<uint64_t>(pair_blocks) : reinterpret_cast<uint64_t>(blocks);
+        // an idle slot names the index's first block (an L2 hit) instead of masking its eight DMA lanes
+        // off: one branch-free load instruction per region is cheaper than the exec-mask dance
+        const uint64_t dummy = reinterpret_cast<uint64_t>(blocks);
+        uint64_t *list = reinterpret_cast<uint64_t *>(ws.lines);  // this step's line addresses: read back before the first line lands
+#if MSBWT_LANES_SPLIT
+        // ONE line per lane: that of l -- which also serves h when h fits the same line (overlapping pair
+        // blocks hold 32 positions beyond their own 96) -- or, when the lane took l's line in the previous
+        // iteration and h did not fit (`half`), that of h.
+        const uint64_t cur = half ? h : l;
+        const uint64_t bc = pair ? pair_block_of(cur, s96) : cur >> 8;
+        const uint64_t start_c = pair ? pair_block_start(bc, s96) : bc << 8;
+        const bool same = !half && (pair ? (h - start_c) < 128u : (h >> 8) == bc);
+        const uint32_t r_c = uint32_t(cur - start_c), r_h = uint32_t(h - start_c);  // (r_h: only when `same`)
+        list[lane] = have ? base + bc * 128u : dummy;
+        // pair steps: K[a][b] + occ2 at the superblock start (L2-resident table), one 8-byte load per lane
+        uint64_t super_c = 0;
+        if (pair) super_c = pair_super[(bc >> kPairSuperBlocks) * 16u + a2 * 4u + b2];
+        wave_lds_sync();
+        {   // all line addresses first (one LDS round trip), then the LDS-DMA loads back to back
+            uint64_t addr[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) addr[i] = list[8u * i + dma_group] + dma_chunk_bytes;
+            // the list lives in the line area: every address must be in registers before a line may land on it
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
+            wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool wanted = ((busy >> (8 * i)) & 0xFFull) != 0ull;  // wave-uniform
+                if (wanted) __builtin_amdgcn_global_load_lds((global_void *)addr[i], (lds_void *)&ws.lines[region_base(i)], 16, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): every line has landed in LDS (and the table entries of step C are here)
+        wave_lds_sync();
+        if (have) {
+            uint64_t v_c, v_h;  // the new bound of `cur`, and of h when it shares the line
+            if (pair) {
+                PairLine L;
+                read_pair_line(ws.lines, lane, a2, b2, L);
+                v_c = pair_line_bound(L, super_c, r_c);
+                v_h = pair_line_bound(L, super_c, r_h);
+            } else {
+                PlaneLine L;
+                read_plane_line(ws.lines, lane, s1, L);
+                v_c = plane_line_bound(L, s1, cur);
+                v_h = plane_line_bound(L, s1, h);
+            }
+            if (!half && !same) {  // l is done; h's own line comes next iteration (the symbols stay)
+                new_l = v_c;
+                half = true;
+            } else {
+                l = half ? new_l : v_c;
+                h = half ? v_c : v_h;
+                half = false;
+                if (pair) {
+                    consume_symbols<kWords>(w, 6);
+                    rem -= 2u;
+                } else {
+                    consume_symbols<kWords>(w, 3);
+                    --rem;
+                }
+                if (rem == 0u || l == h) {
+                    store_count<kReads>(src, qid, h - l);
+                    have = false;
+                }
+            }
+        }
+#else
         // the block of l -- and h's own block only when h does not fit the same line (overlapping pair
         // blocks hold 32 positions beyond their own 96)
         const uint64_t bl = pair ? pair_block_of(l, s96) : l >> 8;
@@ -468,10 +549,6 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
         // takes the step in the next iteration)
         const bool act = have && !(second && second_rank >= kMaxSecond);
         const uint32_t slot_l = lane, slot_h = second ? 64u + second_rank : lane;
-        // an idle slot names the index's first block (an L2 hit) instead of masking its eight DMA lanes
-        // off: one branch-free load instruction per region is cheaper than the exec-mask dance
-        const uint64_t dummy = reinterpret_cast<uint64_t>(blocks);
-        uint64_t *list = reinterpret_cast<uint64_t *>(ws.lines);  // this step's line addresses: read back before the first line lands
         list[lane] = act ? base + bl * 128u : dummy;
         if (second && act) list[slot_h] = base + bh * 128u;
         if (lane < 8u && 64u + nsecond + lane < uint32_t(kLineSlots)) list[64u + nsecond + lane] = dummy;  // the ragged end of the last second-bound region
@@ -531,6 +608,7 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
                 have = false;
             }
         }
+#endif
         wave_lds_sync();  // the next iteration overwrites the lines
     }
 }

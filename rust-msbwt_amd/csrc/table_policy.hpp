@@ -48,27 +48,28 @@ inline TableChoice choose_table_depths(uint64_t total, uint64_t block_bytes, uin
 // ---- spacing of the pair blocks (rank_ops.hpp): 128 = disjoint, 96 = overlapping (1.33 bytes per symbol) --------
 // Overlapping blocks rank a range up to 32 wide from ONE line.  Whether that pays is a property of the DATA: on
 // a real 30x read set the range of a present k-mer stays about as wide as the coverage down to the last step
-// (every fifth pair step would fetch a second line from disjoint blocks), on a stream of independent symbols
-// it collapses to width 1 within a few steps and the overlap buys nothing.  The packed table knows which: it
-// holds the width of every range that survives `depth` symbols.
-//   typical width = sum(w x w) / sum(w) over the table's ranges = the width of the range that a random PRESENT
-//   suffix -- a k-mer drawn from the reads -- finds itself in when its search leaves the table.
-inline double typical_range_width(uint64_t sum_w, uint64_t sum_w_times_w) { return sum_w ? double(sum_w_times_w) / double(sum_w) : -1.0; }
-
+// (every fifth pair step would need a second line from disjoint blocks), on a stream of independent symbols
+// it collapses to width 1 within a few steps and the overlap buys nothing.  The loader measures which it is:
+// launch_probe_widths (kernels.hpp) walks a few thousand pseudo-random rows backwards and reports how often the
+// kProbeSteps-mer read off each of them occurs; `typical_width` is the median.
+constexpr uint32_t kProbeSamples = 4096, kProbeSteps = 24;
 constexpr double kWideRangeThreshold = 8.0;  // from here on a second line per pair step is common enough to pay 0.33 bytes per symbol
 
-// First decision, before any table exists: overlapping blocks when they are cheap (their blocks and build scratch
-// take at most a quarter of the free HBM: C3 / C4-sized indexes), disjoint otherwise.
-inline int provisional_pair_stride(uint64_t bytes_stride96, uint64_t free_bytes) { return bytes_stride96 <= free_bytes / 4 ? 96 : 128; }
+// bytes96 / bytes128: pair blocks + superblock table (+ build scratch) at either spacing; expected_table_bytes: the
+// suffix table the loader is going to build beside DISJOINT blocks (its policy budgets against those; the
+// overlap is paid from the reserve); free_bytes: HBM free once the plane blocks are in place; an eighth of the
+// device's HBM stays free for the caller's batches.  typical_width < 0 = unknown.
+inline int choose_pair_stride(uint64_t bytes96, uint64_t expected_table_bytes, uint64_t free_bytes, uint64_t hbm_total_bytes, double typical_width) {
+    if (bytes96 <= free_bytes / 4) return 96;  // cheap (C3 / C4-sized indexes): taken whatever the data look like
+    if (typical_width < kWideRangeThreshold) return 128;
+    return bytes96 + expected_table_bytes + hbm_total_bytes / 8 <= free_bytes ? 96 : 128;
+}
 
-// Second decision, once the packed table has been built beside disjoint blocks: switch to overlapping ones when
-// the data keep ranges wide AND the bigger blocks fit -- `free_bytes` is what is free NOW (table and disjoint pair
-// blocks in place), `held_bytes` what freeing the disjoint blocks gives back, and `reserve_bytes` stays free for
-// the caller's batches.  typical_width < 0 = unknown (no packed table): keep what there is.
-inline int final_pair_stride(int current, double typical_width, uint64_t bytes_stride96, uint64_t free_bytes, uint64_t held_bytes,
-                             uint64_t reserve_bytes) {
-    if (current != 128 || typical_width < kWideRangeThreshold) return current;
-    return bytes_stride96 + reserve_bytes <= free_bytes + held_bytes ? 96 : 128;
+// peak HBM the table takes while it is built with `free_bytes` free (flat parent + packed lines side by side)
+inline uint64_t expected_table_bytes(uint64_t total, uint64_t block_bytes, uint64_t free_bytes, bool pair_index, bool packing_allowed) {
+    const TableChoice c = choose_table_depths(total, block_bytes, free_bytes, pair_index, packing_allowed);
+    const uint64_t flat_b = c.flat ? uint64_t(16) << (2 * c.flat) : 0;
+    return c.packed ? flat_b + packed_table_bytes(c.packed) : flat_b;
 }
 
 }  // namespace msbwt

@@ -194,6 +194,13 @@ class RleBWT(BWT):
         if rc:
             _raise(rc, self._h)
 
+    def allgather_counts(self, comm, d_mine, n_mine, d_all, wire_bits=64, stream=0):
+        """msbwt_rle_allgather_counts: d_all[r * n_mine + i] = rank r's d_mine[i] on every rank (device pointers,
+        u64 counts), asynchronous on `stream`; wire_bits 16 / 32 narrows the payload (overflow -> device_status)."""
+        rc = _lib.lib().msbwt_rle_allgather_counts(self._h, comm._c, d_mine, n_mine, d_all, wire_bits, stream)
+        if rc:
+            _raise(rc, self._h)
+
     # ---- several GPUs of one node ---------------------------------------------------------
     def replicate(self, device):
         """A new RleBWT on `device` holding a GPU -> GPU copy of this index (no rebuild, no upload)."""
@@ -252,7 +259,7 @@ class RleBWT(BWT):
         return int(_lib.lib().msbwt_rle_get_pair_stride(self._h))
 
     def get_typical_range_width(self):
-        """Width of the range a present k-mer leaves the packed suffix table with (-1.0 without one)."""
+        """Median number of occurrences of a present 24-mer, probed at load time (-1.0: not probed)."""
         return float(_lib.lib().msbwt_rle_get_typical_range_width(self._h))
 
     BLOCK_FORMATS = {"planes": 0, "runs": 1}
@@ -300,6 +307,39 @@ class RleBWT(BWT):
 
     def device_ordinal(self):
         return int(_lib.lib().msbwt_rle_device_ordinal(self._h))
+
+
+class RankComm:
+    """An RCCL communicator over the GPUs of a one-process-per-GPU job, made through the library
+    (msbwt_comm_*): rank 0 calls RankComm.unique_id(), the bytes reach the other ranks by any channel
+    (torch.distributed.broadcast in bench.py), every rank calls RankComm(nranks, id, rank) with its GPU current."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+        rc = _lib.lib().msbwt_comm_get_unique_id(buf)
+        if rc:
+            raise MsbwtError(rc, "msbwt_comm_get_unique_id (is librccl.so there?)")
+        return bytes(buf)
+
+    def __init__(self, nranks, unique_id, rank):
+        self._c = C.c_void_p()
+        self.nranks, self.rank = nranks, rank
+        buf = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        rc = _lib.lib().msbwt_comm_init_rank(C.byref(self._c), nranks, buf, rank)
+        if rc:
+            raise MsbwtError(rc, "msbwt_comm_init_rank")
+
+    def close(self):
+        c, self._c = self._c, None
+        if c:
+            _lib.lib().msbwt_comm_destroy(c)
+
+    def __del__(self):
+        try:
+            self.close()
+        except (TypeError, AttributeError):
+            pass
 
 
 def _handles(replicas):

@@ -47,6 +47,12 @@ extern "C" {
     fn msbwt_rle_count_read_kmers_multi(replicas: *const *const MsbwtRle, n_replicas: usize, reads: *const u8,
                                         read_len: usize, n_reads: usize, k: usize, ascii: c_int,
                                         out_fwd: *mut u64, out_rc: *mut u64) -> c_int;
+    // one process per GPU: the final count gather over RCCL (librccl.so is bound at run time)
+    fn msbwt_comm_get_unique_id(out_id: *mut c_void) -> c_int;
+    fn msbwt_comm_init_rank(out_comm: *mut *mut c_void, nranks: c_int, id: *const c_void, rank: c_int) -> c_int;
+    fn msbwt_comm_destroy(comm: *mut c_void) -> c_int;
+    fn msbwt_rle_allgather_counts(bwt: *const MsbwtRle, comm: *mut c_void, d_mine: *const c_void, n_mine: usize,
+                                  d_all: *mut c_void, wire_bits: c_int, hip_stream: *mut c_void) -> c_int;
 }
 
 /// Same role as `RleBWT` (src/rle_bwt.rs:14-24); the index lives in HBM.
@@ -144,6 +150,41 @@ impl GpuRleBWTSet {
         let rc = unsafe { msbwt_rle_count_kmers_multi(raws.as_ptr(), raws.len(), kmers.as_ptr(), k, n, out.as_mut_ptr()) };
         if rc != MSBWT_OK { panic!("count_kmers_multi: code {}", rc); }
         out
+    }
+}
+
+/// One rank of a one-process-per-GPU job: an RCCL communicator over the node's GPUs.  Rank 0 calls
+/// `RankComm::unique_id()`, ships the 128 bytes to the other ranks (MPI, a file, the environment), every rank calls
+/// `RankComm::init` with its GPU current; `GpuRleBWT::allgather_counts` is then the job's one exchange step.
+pub struct RankComm { raw: *mut c_void, pub nranks: usize }
+
+impl RankComm {
+    pub fn unique_id() -> [u8; 128] {
+        let mut id = [0u8; 128];
+        let rc = unsafe { msbwt_comm_get_unique_id(id.as_mut_ptr() as *mut c_void) };
+        assert!(rc == MSBWT_OK, "msbwt_comm_get_unique_id: code {}", rc);
+        id
+    }
+    pub fn init(nranks: usize, id: &[u8; 128], rank: usize) -> Self {
+        let mut raw: *mut c_void = std::ptr::null_mut();
+        let rc = unsafe { msbwt_comm_init_rank(&mut raw, nranks as c_int, id.as_ptr() as *const c_void, rank as c_int) };
+        assert!(rc == MSBWT_OK && !raw.is_null(), "msbwt_comm_init_rank: code {}", rc);
+        RankComm { raw, nranks }
+    }
+}
+
+impl Drop for RankComm {
+    fn drop(&mut self) { unsafe { msbwt_comm_destroy(self.raw); } }
+}
+
+impl GpuRleBWT {
+    /// Every rank ends up with all ranks' counts: `d_all[r * n_mine + i]` = rank r's `d_mine[i]` (device pointers to
+    /// u64; every rank passes the same `n_mine`).  `wire_bits` 16 or 32 narrows the counts on the wire; a count that
+    /// does not fit is reported by the next `device_status` (repeat with 64).
+    pub unsafe fn allgather_counts(&self, comm: &RankComm, d_mine: *const c_void, n_mine: usize, d_all: *mut c_void,
+                                   wire_bits: i32, hip_stream: *mut c_void) {
+        let rc = msbwt_rle_allgather_counts(self.raw, comm.raw, d_mine, n_mine, d_all, wire_bits as c_int, hip_stream);
+        if rc != MSBWT_OK { panic!("allgather_counts: {}", self.last_error()); }
     }
 }
 

@@ -640,6 +640,43 @@ def test_long_launch_on_one_stream_and_many_short_ones_on_another():
         assert np.array_equal(d_o.cpu().numpy().astype(np.uint64), o.count_kmers(q))
 
 
+def test_native_allgather_of_counts_over_rccl_one_rank(search_kernel):
+    """msbwt_rle_allgather_counts on REAL RCCL with the one-rank communicator a one-GPU box allows: the id /
+    init / gather / destroy calls, all three wire widths, and the overflow report of the narrow ones."""
+    if search_kernel != "auto":
+        pytest.skip("the gather does not depend on the search kernel")
+    torch = pytest.importorskip("torch")
+    reads, rle = _real_bwt(41, 200, 80)
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    k = 21
+    qs = np.concatenate([np.array([orc.convert_stoi(r[5:5 + k]) for r in reads], dtype=np.uint8), random_kmers(5, 1000, k)])
+    exp = o.count_kmers(qs)
+    comm = msbwt.RankComm(1, msbwt.RankComm.unique_id(), 0)
+    d_q = torch.from_numpy(qs).to(dev)
+    d_mine = torch.zeros(len(qs), dtype=torch.int64, device=dev)
+    b.count_kmers_device(d_q.data_ptr(), k, len(qs), d_mine.data_ptr(), stream)
+    for bits in (64, 32, 16):
+        d_all = torch.full((len(qs),), -1, dtype=torch.int64, device=dev)
+        b.allgather_counts(comm, d_mine.data_ptr(), len(qs), d_all.data_ptr(), bits, stream)
+        b.device_status(stream)
+        assert np.array_equal(d_all.cpu().numpy().astype(np.uint64), exp), bits
+    # a count beyond the wire width is reported, not truncated silently
+    big = torch.tensor([1, 70000, 3, 2 ** 40], dtype=torch.int64, device=dev)
+    out = torch.zeros(4, dtype=torch.int64, device=dev)
+    b.allgather_counts(comm, big.data_ptr(), 4, out.data_ptr(), 32, stream)
+    with pytest.raises(msbwt.MsbwtError) as err:
+        b.device_status(stream)
+    assert err.value.code == msbwt._lib.ERR_OVERFLOW
+    b.allgather_counts(comm, big.data_ptr(), 4, out.data_ptr(), 64, stream)
+    b.device_status(stream)
+    assert out.tolist() == [1, 70000, 3, 2 ** 40]
+    comm.close()
+
+
 def test_introspection(search_kernel):
     needs_plane_blocks(search_kernel)
     rle = random_stream(2, 30000, "short")

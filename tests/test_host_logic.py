@@ -264,3 +264,29 @@ def test_automatic_table_depths_are_what_design_md_says():
         flat, packed = auto(total, 300 * GB)
         assert 0 <= flat <= 15 and packed in (0, flat + 2) and (flat == 0 or 4 ** flat <= max(total, 4 ** (packed - 2) if packed else 0))
         assert packed == 0 or 4 ** packed <= 16 * total
+
+
+def test_automatic_pair_stride_follows_memory_first_and_then_the_data():
+    """csrc/table_policy.hpp through msbwt_auto_pair_stride (no device).  Small indexes take the overlapping
+    (stride-96) pair blocks because they are cheap; a human-scale index takes them only when the load-time probe
+    reports that present k-mers keep wide ranges (a real 30x read set: ~ the coverage; a stream of independent
+    symbols: 1) and the bigger blocks fit beside the suffix table with an eighth of the HBM to spare."""
+    GB = 10 ** 9
+    hbm = 288 * 2 ** 30
+    stride = msbwt.auto_pair_stride
+    human, free_after_planes = 90_000_000_000, hbm - 45 * GB - 2 * GB
+    assert stride(233_629_767, 300 * GB, hbm) == 96                         # C3: 0.3 GB of pair blocks
+    assert stride(1_946_213_783, 300 * GB, hbm) == 96                       # C4: 2.6 GB
+    assert stride(human, free_after_planes, hbm, typical_width=-1.0) == 128  # nothing known about the data
+    assert stride(human, free_after_planes, hbm, typical_width=1.0) == 128   # the stand-in stream: independent symbols
+    assert stride(human, free_after_planes, hbm, typical_width=7.0) == 128
+    assert stride(human, free_after_planes, hbm, typical_width=8.0) == 96    # real data from ~10x coverage on
+    assert stride(human, free_after_planes, hbm, typical_width=27.0) == 96   # 30x
+    # ... but only when 120 GB of overlapping blocks fit beside the table (90 GB while it is packed) and the reserve
+    assert stride(human, 240 * GB, hbm, typical_width=27.0) == 128
+    assert stride(human, 100 * GB, hbm, typical_width=27.0) == 128
+    # a 9e9-symbol index: 12 GB of overlapping blocks are cheap from the start
+    assert stride(9_000_000_000, 280 * GB, hbm, typical_width=1.0) == 96
+    for total in (10, 10 ** 6, 10 ** 9, 2 ** 39):
+        for width in (-1.0, 2.0, 30.0):
+            assert stride(total, 250 * GB, hbm, width) in (96, 128)

@@ -13,6 +13,7 @@ C_TO_RUST = {
     "const uint8_t *": "*const u8", "uint8_t *": "*mut u8", "const uint64_t *": "*const u64", "uint64_t *": "*mut u64",
     "const char *": "*const c_char", "const void *": "*const c_void", "void *": "*mut c_void", "double *": "*mut f64",
     "msbwt_rle *": "*mut MsbwtRle", "const msbwt_rle *": "*const MsbwtRle", "const msbwt_rle *const *": "*const *const MsbwtRle",
+    "void **": "*mut *mut c_void",
     "void": "",
 }
 
