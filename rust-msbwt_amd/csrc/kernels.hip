@@ -440,9 +440,12 @@ int search_kernel_for(const IndexView &ix, uint32_t k) {
     return use_lanes_kernel(ix, k) ? kSearchLanes : kSearchGroups;
 }
 
+bool lanes_serves(const IndexView &ix, uint32_t k) { return k >= 1 && k <= uint32_t(kMaxTiledK) && use_lanes_kernel(ix, k); }
+
 hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_t k, uint64_t n,
-                              uint64_t *counts, uint32_t *flags, hipStream_t stream) {
+                              uint64_t *counts, uint32_t *flags, hipStream_t stream, const uint8_t *inline_kmer) {
     if (n == 0) return hipSuccess;
+    if (inline_kmer != nullptr && !(n == 1 && lanes_serves(ix, k))) return hipErrorInvalidValue;
     const uint4 *blocks = static_cast<const uint4 *>(ix.blocks);
     const bool aligned = (reinterpret_cast<uintptr_t>(kmers) & 15u) == 0;
     if (k >= 1 && k <= uint32_t(kMaxTiledK) && aligned) {
@@ -452,6 +455,10 @@ hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_
         src.n = n;
         src.k = k;
         src.out_fwd = counts;
+        if (inline_kmer != nullptr) {
+            src.inline_n = 1;
+            __builtin_memcpy(src.inline_kmer, inline_kmer, k);
+        }
         if (use_lanes_kernel(ix, k)) return launch_lanes(ix, src, false, true, flags, stream);
         launch_tiled<false>(k > uint32_t(kMaxShortK), dim3(grid_for(tiles * 64, k > uint32_t(kMaxShortK) ? 4 : 6)), stream, ix, src, flags);
     } else {

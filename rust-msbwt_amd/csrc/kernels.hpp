@@ -49,6 +49,10 @@ struct IndexView {
     int search_kernel = kSearchAuto;
     uint64_t *debug = nullptr;  // 8 words: [0] != 0 once a consistency check has recorded its values in [1..]
     void *tile_counter = nullptr;  // kTicketBytes of ticket counters for the lanes kernel's tile dealing (zeroed per launch)
+    // one-wave launches of the lanes kernel (n <= 64): *done = done_seq (system scope) once every count is out, so
+    // that a host may poll instead of synchronising the stream; nullptr = not wanted
+    uint64_t *done = nullptr;
+    uint64_t done_seq = 0;
 };
 
 // counts[q] = count_kmer(kmers[q*k .. q*k+k)) for q < n.  Sets kFlagInvalidSymbol in *flags
@@ -56,8 +60,12 @@ struct IndexView {
 // Which kernel a count_kmers / count_read_kmers launch for k-symbol queries runs on this index:
 // kSearchLanes (lanes.hip), kSearchGroups (the tiled kernel of kernels.hip) or 0 (k > 64: generic kernel)
 int search_kernel_for(const IndexView &ix, uint32_t k);
+// inline_kmer (optional, HOST pointer, n == 1, k <= 64): the query travels inside the kernel arguments instead of being
+// read from `kmers` (lanes kernel only: ask lanes_serves(ix, k) first).
 hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_t k, uint64_t n,
-                              uint64_t *counts, uint32_t *flags, hipStream_t stream);
+                              uint64_t *counts, uint32_t *flags, hipStream_t stream, const uint8_t *inline_kmer = nullptr);
+// true when a count_kmers launch for k-symbol queries runs the lanes kernel (the only one that knows ix.done / inline queries)
+bool lanes_serves(const IndexView &ix, uint32_t k);
 
 // Every k-mer window of every read (n_reads x read_len bytes, symbol codes or ASCII), forward
 // and/or reverse-complemented; out_*[r * (read_len-k+1) + w].  1 <= k <= 32, k <= read_len.

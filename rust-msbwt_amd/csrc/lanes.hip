@@ -52,17 +52,15 @@ constexpr int kRing = 64;        // undecided queries waiting for a lane: one ti
 // cost 7 % (the queries of a tile take their first, widest step together), four more waves bring 13 %.
 // Round 3: ring entries shrank to 24 / 36 bytes (RingItemT) and the line list moved INTO the line area,
 // so searches of k > 32 fit the same 10 regions and 12 waves (they had 14 regions and 8 waves).
-// MSBWT_LANES_SPLIT (default): a range that straddles two lines takes TWO iterations -- first the line of l,
-// then the line of h -- instead of a second-line slot in the same iteration: exactly one line per lane and
-// iteration, 8 regions, no compaction of second lines, no lane ever sits a step out, and the wave no longer
-// runs the second-line rank code whenever ANY of its 64 lanes straddles (which was nearly always).
-#ifndef MSBWT_LANES_SPLIT
-#define MSBWT_LANES_SPLIT 1
-#endif
+// Tried in round 3 and dropped: no second-line slots at all -- a range that straddles two lines takes TWO
+// iterations (the line of l, then the line of h): 8 regions, 170 instead of 260 VALU per wave step, 120 VGPRs.
+// Human scale 4.65 against 5.16 x 10^9 q/s, C4 read-derived 5.57 against 5.89, C3 fused 9.16 against 9.02: the
+// lanes of a tile fall out of step (the refill code then runs every iteration instead of once per tile) and a
+// straddling lane holds its slot for two memory round trips.
 #ifdef MSBWT_LANES_REGIONS  // experiments
 template <int kWords> constexpr int kRegionsFor = MSBWT_LANES_REGIONS;
 #else
-template <int kWords> constexpr int kRegionsFor = MSBWT_LANES_SPLIT ? 8 : 10;
+template <int kWords> constexpr int kRegionsFor = 10;
 #endif
 #ifndef MSBWT_LANES_WAVE_CAP
 #define MSBWT_LANES_WAVE_CAP 12
@@ -83,7 +81,7 @@ struct LaneScratchT {
     static constexpr int kRegions = kRegionsFor<kWords>;
     static constexpr int kLineSlots = kRegions * 8;
     static constexpr uint32_t kMaxSecond = uint32_t(kLineSlots) - 64u;  // lanes beyond that with a second line sit the step out
-    static_assert(kRegions >= 8 && kRegions % 2 == 0, "first-bound lines take 8 regions; regions come in padded pairs");
+    static_assert(kRegions >= 10 && kRegions % 2 == 0, "first-bound lines take 8 regions; regions come in padded pairs");
     // Region i (one LDS-DMA instruction: lane j writes 16 bytes at 16 j) starts at uint4 index
     // region_base(i): every odd region is pushed 128 bytes further, so that the 64 lanes'
     // read-back of "chunk j of my line" touches every bank exactly once per 16 lanes (lanes 16 m ..
@@ -181,7 +179,8 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
                                                           const uint4 *__restrict__ pair_blocks,
                                                           const uint64_t *__restrict__ pair_super, const QuerySource src,
                                                           uint32_t *__restrict__ flags, uint64_t *__restrict__ debug,
-                                                          unsigned long long *__restrict__ tile_counter, uint32_t grain) {
+                                                          unsigned long long *__restrict__ tile_counter, uint32_t grain,
+                                                          uint64_t *__restrict__ done, uint64_t done_seq) {
     using Scratch = LaneScratchT<kWords>;
     using RingItem = RingItemT<kWords>;
     constexpr int kPieces = Scratch::kMaxK / 16;  // 16-byte pieces of a tile per lane: 2 or 4
@@ -240,10 +239,6 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
     uint64_t l = 0, h = 0;
     uint32_t w[kWords], rem = 0;
     uint64_t qid = 0;  // global index of the lane's query
-#if MSBWT_LANES_SPLIT
-    bool half = false;     // l has taken this step already (its new value waits in new_l); h's line comes next
-    uint64_t new_l = 0;
-#endif
 #pragma unroll
     for (int i = 0; i < kWords; ++i) w[i] = 0;
 
@@ -269,6 +264,10 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
     auto fetch_tile_bytes = [&](uint64_t tile) {
         if (tile >= ntiles) return;
         if (!kReads) {
+            if (src.inline_n != 0u) {  // the one query came with the kernel arguments: pieces 0..3 belong to lanes 0..3
+                staged_next[0] = lane == 0u ? src.inline_kmer[0] : lane == 1u ? src.inline_kmer[1] : lane == 2u ? src.inline_kmer[2] : lane == 3u ? src.inline_kmer[3] : make_uint4(0, 0, 0, 0);
+                return;
+            }
             const uint64_t q0 = tile * kTile;
             const uint32_t nbytes = uint32_t(min(uint64_t(kTile), n - q0)) * k;
 #pragma unroll
@@ -347,9 +346,6 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
                 rem = (it.meta >> 16) & 0xFFu;
                 qid = ring_tile * kTile + (it.meta >> 24);
                 have = true;
-#if MSBWT_LANES_SPLIT
-                half = false;
-#endif
             }
             const uint32_t taken = min(ring_count, uint32_t(__popcll(idle)));
             ring_head = (ring_head + taken) & (kRing - 1);
@@ -471,69 +467,6 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
         // off: one branch-free load instruction per region is cheaper than the exec-mask dance
         const uint64_t dummy = reinterpret_cast<uint64_t>(blocks);
         uint64_t *list = reinterpret_cast<uint64_t *>(ws.lines);  // this step's line addresses: read back before the first line lands
-#if MSBWT_LANES_SPLIT
-        // ONE line per lane: that of l -- which also serves h when h fits the same line (overlapping pair
-        // blocks hold 32 positions beyond their own 96) -- or, when the lane took l's line in the previous
-        // iteration and h did not fit (`half`), that of h.
-        const uint64_t cur = half ? h : l;
-        const uint64_t bc = pair ? pair_block_of(cur, s96) : cur >> 8;
-        const uint64_t start_c = pair ? pair_block_start(bc, s96) : bc << 8;
-        const bool same = !half && (pair ? (h - start_c) < 128u : (h >> 8) == bc);
-        const uint32_t r_c = uint32_t(cur - start_c), r_h = uint32_t(h - start_c);  // (r_h: only when `same`)
-        list[lane] = have ? base + bc * 128u : dummy;
-        // pair steps: K[a][b] + occ2 at the superblock start (L2-resident table), one 8-byte load per lane
-        uint64_t super_c = 0;
-        if (pair) super_c = pair_super[(bc >> kPairSuperBlocks) * 16u + a2 * 4u + b2];
-        wave_lds_sync();
-        {   // all line addresses first (one LDS round trip), then the LDS-DMA loads back to back
-            uint64_t addr[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) addr[i] = list[8u * i + dma_group] + dma_chunk_bytes;
-            // the list lives in the line area: every address must be in registers before a line may land on it
-            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
-            wave_lds_sync();
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const bool wanted = ((busy >> (8 * i)) & 0xFFull) != 0ull;  // wave-uniform
-                if (wanted) __builtin_amdgcn_global_load_lds((global_void *)addr[i], (lds_void *)&ws.lines[region_base(i)], 16, 0, 0);
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): every line has landed in LDS (and the table entries of step C are here)
-        wave_lds_sync();
-        if (have) {
-            uint64_t v_c, v_h;  // the new bound of `cur`, and of h when it shares the line
-            if (pair) {
-                PairLine L;
-                read_pair_line(ws.lines, lane, a2, b2, L);
-                v_c = pair_line_bound(L, super_c, r_c);
-                v_h = pair_line_bound(L, super_c, r_h);
-            } else {
-                PlaneLine L;
-                read_plane_line(ws.lines, lane, s1, L);
-                v_c = plane_line_bound(L, s1, cur);
-                v_h = plane_line_bound(L, s1, h);
-            }
-            if (!half && !same) {  // l is done; h's own line comes next iteration (the symbols stay)
-                new_l = v_c;
-                half = true;
-            } else {
-                l = half ? new_l : v_c;
-                h = half ? v_c : v_h;
-                half = false;
-                if (pair) {
-                    consume_symbols<kWords>(w, 6);
-                    rem -= 2u;
-                } else {
-                    consume_symbols<kWords>(w, 3);
-                    --rem;
-                }
-                if (rem == 0u || l == h) {
-                    store_count<kReads>(src, qid, h - l);
-                    have = false;
-                }
-            }
-        }
-#else
         // the block of l -- and h's own block only when h does not fit the same line (overlapping pair
         // blocks hold 32 positions beyond their own 96)
         const uint64_t bl = pair ? pair_block_of(l, s96) : l >> 8;
@@ -545,7 +478,7 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
         const uint64_t second_mask = __ballot(second);
         const uint32_t second_rank = __builtin_amdgcn_mbcnt_hi(uint32_t(second_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(second_mask), 0u));
         const uint32_t nsecond = min(uint32_t(__popcll(second_mask)), kMaxSecond);
-        // room for 48 second lines per step: a lane beyond that sits this step out (its query simply
+        // room for 16 second lines per step: a lane beyond that sits this step out (its query simply
         // takes the step in the next iteration)
         const bool act = have && !(second && second_rank >= kMaxSecond);
         const uint32_t slot_l = lane, slot_h = second ? 64u + second_rank : lane;
@@ -608,8 +541,14 @@ __global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restric
                 have = false;
             }
         }
-#endif
         wave_lds_sync();  // the next iteration overwrites the lines
+    }
+    // Small host batches run as ONE wave and announce their completion in host-visible memory, so that the caller
+    // can poll a word instead of paying for a stream synchronisation: every count of this wave is out (system
+    // scope) before the word changes.
+    if (done != nullptr) {
+        __threadfence_system();
+        if (lane == 0u) __hip_atomic_store(done, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -661,7 +600,7 @@ hipError_t launch_variant(hipStream_t stream, const IndexView &ix, const QuerySo
     hipLaunchKernelGGL((k_count_kmers_lanes<kReads, kPair, kWords, kStride96>), dim3(uint32_t(waves)), dim3(64), 0, stream,
                        static_cast<const uint4 *>(ix.blocks), ix.total, table, uint32_t(ix.table.depth), ix.table.packed ? 1u : 0u, filter, filter_mask,
                        static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags, ix.debug,
-                       tickets ? static_cast<unsigned long long *>(ix.tile_counter) : nullptr, grain);
+                       tickets ? static_cast<unsigned long long *>(ix.tile_counter) : nullptr, grain, waves == 1 ? ix.done : nullptr, ix.done_seq);
     return hipGetLastError();
 }
 

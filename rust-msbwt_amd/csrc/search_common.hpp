@@ -31,6 +31,11 @@ struct QuerySource {
     // owns the global windows [win_off[r], win_off[r+1]); nullptr = fixed read_len
     const uint64_t *read_off, *win_off;
     uint64_t n_reads;
+    // single-query calls (the trait's count_kmer, msbwt_core.rs:124): the k <= 64 symbols travel INSIDE the kernel
+    // arguments, which the wave reads at start-up anyway -- one PCIe round trip less than fetching them from the
+    // host's buffer.  inline_n = 1: the batch is this one query (matrix mode, lanes kernel only).
+    uint32_t inline_n;
+    uint4 inline_kmer[4];
 };
 
 namespace {

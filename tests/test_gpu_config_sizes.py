@@ -128,7 +128,7 @@ def test_stream_beyond_2_pow_33_symbols_hbm_regime():
     assert bwt.get_total_size() == total == ref.get_total_size()
     k = 31
     present = bench.walk_kmers(torch, np, bwt, dev, total, 2_000_000, k, 99)
-    absent = bench.device_random_kmers(torch, dev, 2_000_000, k, 98)
+    absent = bench.device_random_kmers(torch, dev, 0, 2_000_000, k, 98)
     d_q = torch.cat([present, absent])
     q = d_q.cpu().numpy()
     exp = ref.count_kmers(q, nthreads=NCPU)
@@ -148,3 +148,54 @@ def test_stream_beyond_2_pow_33_symbols_hbm_regime():
     ol, oh = ref.constrain_ranges(syms, a, b)
     assert np.array_equal(gl, ol) and np.array_equal(gh, oh)
     assert int(gl.max()) > 2**32
+
+
+def test_human_scale_9e10_symbols_against_the_oracle():
+    """The size the metric is quoted on: a 9e10-symbol stand-in stream (positions beyond 2^36, 40-bit header counts
+    with high bytes up to 20, the full 208-238 GB index with its depth-17 packed table): 2e6 present (LF-walk) +
+    2e6 random 31-mers under both search kernels, and 1e6 batched constrain_range calls with l, h > 2^36, all
+    against the oracle on the same stream.  Needs ~250 GB of HBM and ~20 GB of host memory; about two minutes."""
+    import synth
+    sys.path.insert(0, ROOT)
+    import bench
+    torch, dev = _torch()
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 250 * 10**9:
+        pytest.skip("needs 250 GB of free HBM")
+    hist = synth.HISTOGRAM_FILE if os.path.exists(synth.HISTOGRAM_FILE) else None
+    rle, total = synth.rle_stream(int(bench.HUMAN_SYMBOLS), 6.0, 77, histogram=hist)   # bench.py's default stream
+    assert total == 90_000_000_000 > 2**36
+    bwt = RleBWT(device=0)
+    bwt.load_vector(rle)
+    assert bwt.get_total_size() == total and bwt.get_table_depth() == 17 and bwt.get_pair_index()
+    ref = orc.OracleRleBWT()
+    ref.load_vector(rle)
+    assert ref.get_total_size() == total
+    assert [bwt.get_symbol_count(s) for s in range(6)] == [ref.get_symbol_count(s) for s in range(6)]
+    k = 31
+    present = bench.walk_kmers(torch, np, bwt, dev, total, 2_000_000, k, 4242)
+    absent = bench.device_random_kmers(torch, dev, 0, 2_000_000, k, 98)
+    d_q = torch.cat([present, absent])
+    q = d_q.cpu().numpy()
+    exp = ref.count_kmers(q, nthreads=NCPU)
+    assert exp[:2_000_000].min() >= 1
+    for mode in ("lanes", "groups"):
+        bwt.set_search_kernel(mode)
+        got = _count_matrix(torch, dev, bwt, d_q).cpu().numpy().astype(np.uint64)
+        assert np.array_equal(got, exp), mode
+    # k > 32 takes the other instantiation of the lanes kernel (6 words of symbols): 59-mers, fmlrc's long k
+    bwt.set_search_kernel("auto")
+    long_q = bench.walk_kmers(torch, np, bwt, dev, total, 500_000, 59, 7)
+    got = _count_matrix(torch, dev, bwt, long_q).cpu().numpy().astype(np.uint64)
+    assert np.array_equal(got, ref.count_kmers(long_q.cpu().numpy(), nthreads=NCPU)) and got.min() >= 1
+    # batched constrain_range with both bounds beyond 2^36
+    rng = np.random.default_rng(23)
+    n = 1_000_000
+    a = rng.integers(2**36, total + 1, size=n, dtype=np.uint64)
+    b = a + rng.integers(0, 5000, size=n).astype(np.uint64) * rng.integers(0, 2, size=n).astype(np.uint64)
+    b = np.minimum(b, np.uint64(total))
+    syms = rng.integers(0, 6, size=n).astype(np.uint8)
+    gl, gh = bwt.constrain_ranges(syms, a, b)
+    ol, oh = ref.constrain_ranges(syms, a, b)
+    assert np.array_equal(gl, ol) and np.array_equal(gh, oh)
+    assert int(gl.max()) > 2**36
