@@ -97,8 +97,10 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="human", choices=["human", "c2", "c3", "c4", "big"])
     ap.add_argument("--big-symbols", type=float, default=2.0**33, help="workload big: BWT length")
     ap.add_argument("--big-mean-run", type=float, default=6.0)
-    ap.add_argument("--stream", default="histogram", choices=["histogram", "geometric"],
-                    help="human / big: run lengths of the stand-in stream from C4's measured histogram (default) or geometric")
+    ap.add_argument("--stream", default="reads", choices=["reads", "histogram", "geometric"],
+                    help="human / big: what the index is built from.  reads (default) = the EXACT multi-string BWT of an error-free 30x read "
+                         "set (150-bp reads of a random genome), built on the GPU without suffix-sorting the reads (synth/bwt_reads.py); "
+                         "histogram / geometric = a stream of independent symbols with run lengths from C4's measured histogram / a geometric law")
     ap.add_argument("--stats-sample", type=int, default=2_000_000, help="queries used for the algorithmic-byte counters (0 = all)")
     ap.add_argument("--queries", type=int, default=0, help="queries per step, whole job (0 = the config's)")
     ap.add_argument("--k", type=int, default=0, help="override k")
@@ -332,6 +334,8 @@ def main():
         nq = max(1000, int(nq * min(1.0, args.scale * (4 if not human else 40))))
     symbols = int((HUMAN_SYMBOLS if human else args.big_symbols) * (args.scale if human else 1.0))
     hist_file = synth.HISTOGRAM_FILE if (args.stream == "histogram" and os.path.exists(synth.HISTOGRAM_FILE)) else None
+    exact_bwt = big and args.stream == "reads"
+    read_len, coverage = 150, 30.0
 
     bwt = msbwt.RleBWT(device=local_rank)
     bwt.set_block_format(args.blocks)
@@ -340,10 +344,20 @@ def main():
     t0 = time.time()
     rle = npy = reads = None
     if big:
-        # structure-equivalent synthetic RLE stream (NOT a real BWT): sizes that cannot be
-        # suffix-sorted here.  Same seed on every rank => identical replicas.
-        rle, _ = synth.rle_stream(symbols, args.big_mean_run, 77, histogram=hist_file)
-        log("rank %d: synthetic RLE stream of %d bytes in %.1fs (%d host threads)" % (rank, len(rle), time.time() - t0, host_threads))
+        if exact_bwt:
+            # the exact MSBWT of an error-free read set, built on this GPU from the genome's own suffix order (no suffix
+            # sort of the 9e10 read suffixes: synth/bwt_reads.py).  Same seed, same device type => identical replicas.
+            from synth import bwt_reads
+            genome_len = max(2000, int(symbols * read_len / (coverage * (read_len + 1))))
+            genome, cnt = bwt_reads.read_set(genome_len, read_len, coverage, 77, device=dev)
+            rle, _, n_reads_total = bwt_reads.msbwt_rle(genome, cnt, read_len, log=lambda m: log("rank %d: bwt: %s" % (rank, m)))
+            del genome, cnt
+            torch.cuda.empty_cache()
+            log("rank %d: exact MSBWT of %d error-free %d-bp reads: %d RLE bytes in %.1fs" % (rank, n_reads_total, read_len, len(rle), time.time() - t0))
+        else:
+            # structure-equivalent synthetic RLE stream (NOT a real BWT): independent symbols.  Same seed on every rank => identical replicas.
+            rle, _ = synth.rle_stream(symbols, args.big_mean_run, 77, histogram=hist_file)
+            log("rank %d: synthetic RLE stream of %d bytes in %.1fs (%d host threads)" % (rank, len(rle), time.time() - t0, host_threads))
         t0 = time.time()
         bwt.load_vector(rle)
         if rank != 0:
@@ -580,7 +594,11 @@ def main():
             log("native gather failed: %r" % (e,))
 
     kind_text = {"walk": "present (LF-walk)", "random": "random", "reads": "read-derived"}[kind]
-    if big:
+    if exact_bwt:
+        wl = ("%s: EXACT multi-string BWT of %d error-free synthetic %d-bp reads (%.0fx of a random %d-bp genome; built on the GPU from the genome's "
+              "suffix order, synth/bwt_reads.py), %d symbols; %d %s %d-mers per step"
+              % (args.workload, n_reads_total, read_len, coverage, genome_len, total, nq, kind_text, k))
+    elif big:
         wl = ("%s: structure-equivalent synthetic RLE stream (NOT a real BWT; 30x-human-scale stand-in), %d symbols, run lengths %s; "
               "%d %s %d-mers per step" % (args.workload, total, "drawn from the run-length histogram of config C4's real MSBWT (synth/c4_run_histogram.json)"
                                           if hist_file else "geometric, mean %.1f" % args.big_mean_run, nq, kind_text, k))

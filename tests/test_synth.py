@@ -108,3 +108,33 @@ def test_workload_index_small_scale(tmp_path, monkeypatch):
     assert o.count_kmers(q).min() >= 1
     npy2, rd2 = synth.workload_index("c2", scale=0.001)      # second call: served from the cache
     assert npy2 == npy and np.array_equal(rd, rd2)
+
+
+@pytest.mark.parametrize("g,L,cov,seed", [(2000, 40, 8, 1), (20000, 60, 20, 2), (120000, 100, 30, 3), (1000, 150, 30, 4)])
+def test_exact_bwt_of_a_read_set_without_suffix_sorting_the_reads(g, L, cov, seed):
+    """synth/bwt_reads.py (the human-scale index of bench.py) against the suffix-sorting builder on the same reads:
+    same symbol totals and the same count for every k-mer tried, k = 1 .. read length (the two streams differ only in
+    the order of identical suffixes, which no '$'-free count depends on)."""
+    from synth import bwt_reads
+    from oracle import oracle as orc
+    genome, cnt = bwt_reads.read_set(g, L, cov, seed)
+    rle, totals, nreads = bwt_reads.msbwt_rle(genome, cnt, L)
+    reads = bwt_reads.reads_of(genome, cnt, L)
+    assert reads.shape == (nreads, L)
+    true = synth.rle_encode(synth.build_msbwt_symbols(reads))
+    a, b = orc.OracleRleBWT(), orc.OracleRleBWT()
+    a.load_vector(rle)
+    b.load_vector(true)
+    assert a.get_total_size() == b.get_total_size() == nreads * (L + 1)
+    assert [a.get_symbol_count(s) for s in range(6)] == [b.get_symbol_count(s) for s in range(6)] == [int(t) for t in totals]
+    for k in (1, 2, 3, 4, 5, 8, 12, 17, 21, 29, 31, 33, L):
+        q = np.concatenate([synth.read_kmers(reads, k, limit=2000, seed=k), synth.random_kmers(1000, k, seed + k)])
+        assert np.array_equal(a.count_kmers(q), b.count_kmers(q)), k
+    # a read-derived k-mer occurs at least as often as reads cover its window (exactly that, unless the genome repeats it)
+    k = 25
+    starts = np.repeat(np.arange(g), cnt.numpy().astype(np.int64))
+    pos = starts[:200] + 3
+    q = np.array([1, 2, 3, 5], dtype=np.uint8)[genome.numpy()[pos[:, None] + np.arange(k)[None, :]]]
+    covering = np.array([int(cnt.numpy()[max(0, p + k - L):p + 1].sum()) for p in pos])
+    got = a.count_kmers(q)
+    assert (got >= covering).all() and (got == covering).mean() > 0.9
