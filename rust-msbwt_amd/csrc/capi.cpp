@@ -975,10 +975,25 @@ int msbwt_rle_constrain_ranges(const msbwt_rle *ch, const uint8_t *syms, const u
         std::memcpy(h->mail + kMailSyms, syms, n);
         std::memcpy(h->mail + kMailL, l, n * sizeof(uint64_t));
         std::memcpy(h->mail + kMailH, hh, n * sizeof(uint64_t));
-        HIP_TRY(h, launch_constrain_ranges(view_of(h), h->d_mail + kMailSyms, reinterpret_cast<const uint64_t *>(h->d_mail + kMailL),
+        IndexView v = view_of(h);
+        volatile uint64_t *done = reinterpret_cast<volatile uint64_t *>(h->mail + kMailDone);
+        const uint64_t seq = ++h->mail_seq;
+        const bool poll = n <= 8;  // one wave of 8-lane groups: the kernel announces completion in the mailbox
+        if (poll) {
+            v.done = reinterpret_cast<uint64_t *>(h->d_mail + kMailDone);
+            v.done_seq = seq;
+        }
+        HIP_TRY(h, launch_constrain_ranges(v, h->d_mail + kMailSyms, reinterpret_cast<const uint64_t *>(h->d_mail + kMailL),
                                            reinterpret_cast<const uint64_t *>(h->d_mail + kMailH), n, reinterpret_cast<uint64_t *>(h->d_mail + kMailOutL),
                                            reinterpret_cast<uint64_t *>(h->d_mail + kMailOutH), h->d_flags + kHostFlags, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        bool seen = false;
+        if (poll) {
+            const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+            for (unsigned spins = 0; !(seen = *done == seq); ++spins)
+                if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() > give_up) break;
+        }
+        if (!seen) HIP_TRY(h, hipStreamSynchronize(h->stream));
+        std::atomic_thread_fence(std::memory_order_acquire);
         const uint64_t *ol = reinterpret_cast<const uint64_t *>(h->mail + kMailOutL), *oh = reinterpret_cast<const uint64_t *>(h->mail + kMailOutH);
         bool flagged = false;
         for (size_t i = 0; i < n; ++i) {

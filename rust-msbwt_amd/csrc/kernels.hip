@@ -379,7 +379,8 @@ __global__ __launch_bounds__(256) void k_constrain_ranges(const uint4 *__restric
                                                           const uint8_t *__restrict__ syms,
                                                           const uint64_t *__restrict__ l, const uint64_t *__restrict__ h,
                                                           uint64_t n, uint64_t *__restrict__ out_l,
-                                                          uint64_t *__restrict__ out_h, uint32_t *__restrict__ flags) {
+                                                          uint64_t *__restrict__ out_h, uint32_t *__restrict__ flags,
+                                                          uint64_t *__restrict__ done, uint64_t done_seq) {
     const uint32_t sub = threadIdx.x & (kGroup - 1);
     const uint64_t ngroups = (uint64_t(gridDim.x) * blockDim.x) / kGroup;
     for (uint64_t i = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) / kGroup; i < n; i += ngroups) {
@@ -398,6 +399,10 @@ __global__ __launch_bounds__(256) void k_constrain_ranges(const uint4 *__restric
             out_l[i] = r.l;
             out_h[i] = r.h;
         }
+    }
+    if (done != nullptr) {  // one-wave launches only (IndexView::done): the results are out before the word changes
+        __threadfence_system();
+        if (threadIdx.x == 0u) __hip_atomic_store(done, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -517,9 +522,10 @@ hipError_t launch_constrain_ranges(const IndexView &ix, const uint8_t *syms, con
                                    const uint64_t *h, uint64_t n, uint64_t *out_l, uint64_t *out_h,
                                    uint32_t *flags, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_constrain_ranges, dim3(grid_for(n * kGroup)), dim3(256), 0, stream,
+    const bool one_wave = ix.done != nullptr && n <= 64 / kGroup;  // a polled completion word needs a single wave
+    hipLaunchKernelGGL(k_constrain_ranges, dim3(one_wave ? 1 : grid_for(n * kGroup)), dim3(one_wave ? 64 : 256), 0, stream,
                        static_cast<const uint4 *>(ix.blocks), uint32_t(ix.block_format), static_cast<const uint4 *>(ix.overflow), ix.total, syms,
-                       l, h, n, out_l, out_h, flags);
+                       l, h, n, out_l, out_h, flags, one_wave ? ix.done : nullptr, ix.done_seq);
     return hipGetLastError();
 }
 

@@ -53,6 +53,13 @@ def _encode_runs(torch, sym, length):
     return out
 
 
+def _nonzero(torch, x, chunk=1 << 30):
+    """indices of the non-zero elements of a 1-D tensor (torch.nonzero is limited to 2^31 - 1 elements per call)"""
+    if x.numel() <= chunk:
+        return torch.nonzero(x).squeeze(1)
+    return torch.cat([torch.nonzero(x[lo:lo + chunk]).squeeze(1) + lo for lo in range(0, x.numel(), chunk)])
+
+
 class _RunWriter:
     """Takes runs part by part (in final order), merges equal neighbours across part borders, keeps bytes on the host."""
 
@@ -162,7 +169,7 @@ def msbwt_rle(genome, cnt, read_len, log=None):
 
     def level_rows(m):
         """rows of one shallow level over ALL positions, in genome-suffix order: (sorted keys, symbols, copies)"""
-        p = torch.nonzero(cntp[m:m + npos]).squeeze(1)
+        p = _nonzero(torch, cntp[m:m + npos])
         k, order = torch.sort(key[p], stable=True)
         p = p[order]
         return k, prev[p], cntp[p + m].to(i64)
@@ -183,7 +190,7 @@ def msbwt_rle(genome, cnt, read_len, log=None):
             out.add(*low_segment(1, grp // 16))
         if grp % 4 == 0:
             out.add(*low_segment(2, grp // 4))
-        idx = torch.nonzero(top3 == grp).squeeze(1)
+        idx = _nonzero(torch, top3 == grp)
         if idx.numel() == 0:
             continue
         ks, order = torch.sort(key[idx], stable=True)
