@@ -22,12 +22,16 @@ root, kernel, out_path, bench_line, rel_path = sys.argv[1:6]
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 out = {}
+# only the launches of the bench line's MAIN measurement count: the first warmup + steps dispatches of the kernel (a
+# default run goes on to other lines -- the C4 extra, the 1e9-query line -- that may use the same kernel instantiation)
+main = json.loads(open(bench_line).read().strip().splitlines()[-1])
+n_main = int(main["steps"]) + int(main["warmup"])
 for f in sorted(glob.glob(root + "/pmc_*/**/*counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if kernel in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for r in sorted((r for r in csv.DictReader(open(f)) if kernel in r["Kernel_Name"]), key=lambda r: int(r["Dispatch_Id"])):
+        agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
+        v = v[:n_main]
         out[k] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
 d = {}
 if "FETCH_SIZE" in out:

@@ -191,6 +191,10 @@ CONFIGS = {
                nq=None, qseed=13, queries="reads"),
     "c4": dict(genome=64_444_167, gseed=21, nreads=12_888_833, rlen=150, rseed=22, err=0.005, k=31,
                nq=100_000_000, qseed=23, queries="random"),
+    # not a BASELINE config: three times C4 (5.84e9 symbols), the largest real MSBWT (reads with substitutions, suffix-sorted)
+    # that the GPU box's host share builds within its memory cap (~205 GB) -- a size point between C4 and human scale
+    "c4x3": dict(genome=193_332_501, gseed=31, nreads=38_666_499, rlen=150, rseed=32, err=0.005, k=31,
+                 nq=100_000_000, qseed=33, queries="reads"),
 }
 
 

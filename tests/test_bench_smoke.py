@@ -40,6 +40,18 @@ def test_bench_contract(extra):
     assert "workload" in r["config"] and "model" not in r["config"]
 
 
+def test_bench_default_run_carries_the_real_msbwt_line():
+    """The default run's extra key c4_real_reads (the REAL MSBWT of config C4, read-derived 31-mers), here on a
+    shrunk C4 beside a shrunk human-scale index: own value, roofline, parity."""
+    r = _run(["--scale", "0.00003", "--c4-scale", "0.002", "--steps", "2", "--warmup", "1", "--cpu-sample", "2000", "--parity-sample", "5000"])
+    c4 = r["c4_real_reads"]
+    assert c4["value"] > 0 and c4["parity"]["mismatches"] == 0 and c4["parity"]["checked"] > 0
+    assert c4["parity"]["mean_count_in_sample"] > 5      # a real 30x read set: present k-mers occur ~ coverage times
+    assert c4["roofline"]["kernel_ms"] > 0 and c4["config"]["k"] == 31 and "REAL" in c4["config"]["workload"]
+    assert "EXACT multi-string BWT" in r["config"]["workload"] and r["parity"]["mismatches"] == 0
+    assert r["config"]["typical_range_width"] > 8        # ... and so does the human-scale index's read set
+
+
 def test_bench_default_is_the_metric_config():
     """The driver runs `python3 bench.py --gpus 1 --steps K --warmup W`: that must be k = 31 on the
     human-scale index (checked on the argument defaults; the full-size run is the driver's)."""

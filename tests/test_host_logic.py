@@ -153,7 +153,11 @@ def test_default_bench_has_a_fresh_pmc_traffic_entry():
     fresh = [e for e in entries if e["workload"] == "human" and e["k"] == 31 and e.get("kernel_stamp") == stamp]
     assert fresh, "no profiles/traffic.json entry for the default bench matches kernel stamp %s" % stamp
     e = fresh[-1]
-    assert e["bwt_symbols"] == int(bench.HUMAN_SYMBOLS) and e["query_kind"] == "walk"
+    # the default index is the exact MSBWT of a Poisson read set: ~9e10 symbols, the same number on every run (seeded)
+    assert abs(e["bwt_symbols"] - bench.HUMAN_SYMBOLS) < 1e-3 * bench.HUMAN_SYMBOLS and e["query_kind"] == "walk"
+    # also the extra line of the default run on the real C4 MSBWT
+    c4 = [x for x in entries if x["workload"] == "c4" and x.get("query_kind") == "reads" and x.get("kernel_stamp") == stamp]
+    assert c4 and os.path.exists(os.path.join(ROOT, c4[-1]["source"]))
     assert os.path.exists(os.path.join(ROOT, e["source"]))
     assert 0 < e["traffic_bytes_per_query"] < 31 * 2 * 184  # far below the reference algorithm's worst case
 
