@@ -151,8 +151,9 @@ def test_stream_beyond_2_pow_33_symbols_hbm_regime():
 
 
 def test_human_scale_9e10_symbols_against_the_oracle():
-    """The size the metric is quoted on: a 9e10-symbol stand-in stream (positions beyond 2^36, 40-bit header counts
-    with high bytes up to 20, the full 208-238 GB index with its depth-17 packed table): 2e6 present (LF-walk) +
+    """The size and the index the metric is quoted on: the exact MSBWT of 5.96e8 error-free reads, 9e10 symbols (positions
+    beyond 2^36, 40-bit header counts with high bytes up to 20, the full 238 GB index: depth-17 packed table, overlapping
+    pair blocks addressed at human scale): 2e6 present (LF-walk) +
     2e6 random 31-mers under both search kernels, and 1e6 batched constrain_range calls with l, h > 2^36, all
     against the oracle on the same stream.  Needs ~250 GB of HBM and ~20 GB of host memory; about two minutes."""
     import synth
@@ -162,12 +163,19 @@ def test_human_scale_9e10_symbols_against_the_oracle():
     free, _ = torch.cuda.mem_get_info(dev)
     if free < 250 * 10**9:
         pytest.skip("needs 250 GB of free HBM")
-    hist = synth.HISTOGRAM_FILE if os.path.exists(synth.HISTOGRAM_FILE) else None
-    rle, total = synth.rle_stream(int(bench.HUMAN_SYMBOLS), 6.0, 77, histogram=hist)   # bench.py's default stream
-    assert total == 90_000_000_000 > 2**36
+    # bench.py's default index: the exact MSBWT of a 30x error-free read set, built on the GPU (synth/bwt_reads.py)
+    from synth import bwt_reads
+    genome, cnt = bwt_reads.read_set(int(bench.HUMAN_SYMBOLS * 150 / (30 * 151)), 150, 30.0, 77, device=dev)
+    rle, totals, n_reads = bwt_reads.msbwt_rle(genome, cnt, 150)
+    del genome, cnt
+    torch.cuda.empty_cache()
+    total = int(totals.sum())
+    assert total == n_reads * 151 and abs(total - bench.HUMAN_SYMBOLS) < 1e-3 * bench.HUMAN_SYMBOLS and total > 2**36
     bwt = RleBWT(device=0)
     bwt.load_vector(rle)
     assert bwt.get_total_size() == total and bwt.get_table_depth() == 17 and bwt.get_pair_index()
+    # a real 30x BWT: present k-mers keep ranges ~ coverage wide, and the loader answers with overlapping pair blocks
+    assert bwt.get_typical_range_width() >= 20 and bwt.get_pair_stride() == 96
     ref = orc.OracleRleBWT()
     ref.load_vector(rle)
     assert ref.get_total_size() == total
