@@ -133,7 +133,7 @@ def parse_args(argv=None):
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 code path (process group, all_gather of the counts, barriers) even with one rank: "
                          "a one-GPU rehearsal of the RCCL calls themselves")
-    ap.add_argument("--c5-queries", type=int, default=1_000_000_000)
+    ap.add_argument("--c5-queries", type=int, default=0, help="queries of the extra random-31-mer line (0 = 1e9 at full scale, none on a shrunk index)")
     ap.add_argument("--parity-sample", type=int, default=200_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     return ap.parse_args(argv)
@@ -580,7 +580,26 @@ def main():
             if rank == 0:
                 id_t.copy_(torch.frombuffer(bytearray(msbwt.RankComm.unique_id()), dtype=torch.uint8))
             dist.broadcast(id_t, 0)
-            comm = msbwt.RankComm(world, bytes(id_t.cpu().numpy().tobytes()), rank)
+            # the communicator is set up on a side thread with a deadline: a bootstrap that never returns must cost this
+            # extra, not the run (every rank applies the same rule, and all must have succeeded for the step to be taken)
+            import threading
+            box = {}
+
+            def make_comm():
+                try:
+                    torch.cuda.set_device(local_rank)
+                    box["comm"] = msbwt.RankComm(world, bytes(id_t.cpu().numpy().tobytes()), rank)
+                except Exception as e:  # noqa: BLE001
+                    box["error"] = repr(e)
+
+            th = threading.Thread(target=make_comm, daemon=True)
+            th.start()
+            th.join(timeout=120.0)
+            ok_t = torch.tensor([1.0 if "comm" in box else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+            if ok_t.item() < 1.0:
+                raise RuntimeError("communicator set-up failed or timed out on some rank: %s" % box.get("error", "no answer within 120 s"))
+            comm = box["comm"]
             n_out, n_all, n_elapsed, n_kms, _, n_narrow = measure(main_batch, lo, hi, cap, native=comm)
             same = bool(torch.equal(n_all, d_all))
             native = {"value": nq * args.steps / n_elapsed, "unit": "queries/s", "ms_per_step": n_elapsed / args.steps * 1e3,
@@ -656,9 +675,9 @@ def main():
 
     # ---- BASELINE configs[4] in its literal shape: 1e9 random 31-mers generated in HBM, sharded over the ranks ----
     c5 = None
-    if human and not args.no_c5 and args.scale == 1.0:
+    if human and not args.no_c5 and (args.scale == 1.0 or args.c5_queries > 0):
         t0 = time.time()
-        n5 = args.c5_queries
+        n5 = args.c5_queries or 1_000_000_000
         lo5, hi5, cap5 = shard(n5)
         d_q5 = device_random_kmers(torch, dev, lo5, hi5, k, 99)
         b5 = Batch(bwt, d_q5, lo5)

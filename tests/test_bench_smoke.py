@@ -76,6 +76,18 @@ def test_bench_self_launch_two_ranks(scaling):
         assert r["config"]["queries_per_gpu"] * 2 >= r["config"]["queries_per_step"]
 
 
+def test_bench_two_ranks_sharded_random_line():
+    """The literal configs[4] shape at N = 2 (gloo rehearsal on the shared GPU): the device-generated random 31-mers are
+    defined chunk by chunk, each rank generates only its shard, all counts are gathered; plus the per-rank timing block."""
+    r = _run(["--gpus", "2", "--dist-backend", "gloo", "--scale", "0.00003", "--steps", "2", "--warmup", "1", "--parity-sample", "5000",
+              "--c5-queries", "300000", "--no-weak"])
+    c5 = r["c5_random_1e9"]
+    assert c5["queries"] == 300000 and c5["queries_per_gpu"] in (150000, 150016) and c5["parity"]["mismatches"] == 0 and c5["value"] > 0
+    assert "sharded over 2 ranks" in c5["kind"]
+    ranks = r["ranks"]
+    assert len(ranks["kernel_ms"]) == 2 and ranks["kernel_ms_min"] > 0 and ranks["exchange_ms_alone"] > 0
+
+
 @pytest.mark.parametrize("payload", ["auto", "int64"])
 def test_bench_two_ranks_rehearsal(payload):
     """The N>1 code path of bench.py (barriers, per-rank batches, gather of all counts, max over

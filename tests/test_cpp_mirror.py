@@ -57,3 +57,27 @@ def test_c_example_counts_two_string(tmp_path):
                        text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "total symbols: 10" in r.stdout and "ACGT\t1" in r.stdout and "TGCA\t1" in r.stdout and "CCCC\t0" in r.stdout
+
+
+def _build_rank_gather(out):
+    subprocess.check_call(["gcc", "-std=gnu11", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+                           os.path.join(ROOT, "examples", "rank_gather.c"), "-o", out, "-L", LIBDIR, "-lmsbwt_hip",
+                           "-Wl,-rpath," + LIBDIR, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+
+
+def test_rank_gather_example_compiles(tmp_path):
+    """examples/rank_gather.c: a C host of the one-process-per-GPU form (msbwt_comm_*, msbwt_rle_allgather_counts)."""
+    exe = str(tmp_path / "rank_gather")
+    _build_rank_gather(exe)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+
+
+@pytest.mark.gpu
+def test_rank_gather_example_one_rank(tmp_path):
+    exe = str(tmp_path / "rank_gather")
+    _build_rank_gather(exe)
+    r = subprocess.run([exe, os.path.join(GOLDEN_DIR, "two_string.npy"), "0", "1", str(tmp_path / "id"), "ACGT", "TGCA", "CCCC"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ACGT\t1" in r.stdout and "TGCA\t1" in r.stdout and "CCCC\t0" in r.stdout
