@@ -181,7 +181,7 @@ int msbwt_rle_get_table_depth(const msbwt_rle *bwt);
  * e.g. depth 17 in 73 GB for a 30x human BWT.  One line fetch per query as before, one search step
  * fewer -- and it is the widest-range step, the one that usually needs two lines.  mode 1 = on
  * (whenever a pair index exists), 0 = off, -1 = automatic (default: when the table depth itself is
- * automatic, 4^(depth+2) <= 16 x total symbols and the lines fit in half of the free HBM -- the flat
+ * automatic, 4^(depth+2) <= 256 x total symbols and the lines fit in half of the free HBM -- the flat
  * parent table is then built as deep as that packed table needs, up to 15 levels, and freed;
  * MSBWT_TABLE_PACKED=0/1 overrides).
  * msbwt_rle_get_table_depth reports the effective depth (flat depth + 2).  Lines whose deltas do not

@@ -27,14 +27,18 @@ inline int auto_flat_table_depth(uint64_t total, uint64_t block_bytes) {
 
 // Beside a pair index the flat table is only the (temporary) parent of a packed one, two levels deeper
 // (kernels.hpp, launch_pack_table): aim for the deepest packed table -- at most 17 levels, 73 GB --
-// that the data warrant (4^p <= 16 T: beyond that nearly every entry is empty) and HBM allows (its
-// lines take at most half of what is free, and parent and packed table fit side by side while packing).
+// that the data warrant and HBM allows (its lines take at most half of what is free, and parent and packed table
+// fit side by side while packing).  "Warrant": at most kTableEntriesPerSymbol entries per BWT symbol.  Most entries
+// of such a table are empty, but a PRESENT k-mer's entry never is, and every two levels spare it a pair step: round 2
+// stopped at 16 entries per symbol (C3: depth 15); with 256 a 2 x 10^8-symbol index gets the full depth 17 (73 GB that
+// a 288 GB part has to spare): C3 fused 8.9 -> 9.8 x 10^9 windows/s.  Toy indexes stay small (T = 10: depth 5).
+constexpr uint64_t kTableEntriesPerSymbol = 256;
 inline TableChoice choose_table_depths(uint64_t total, uint64_t block_bytes, uint64_t free_bytes, bool pair_index, bool packing_allowed) {
     TableChoice c{auto_flat_table_depth(total, block_bytes), 0};
     if (!pair_index || !packing_allowed) return c;
     const auto fits = [&](int p) {
         const uint64_t flat_b = uint64_t(16) << (2 * (p - 2));
-        return (uint64_t(1) << (2 * p)) <= 16 * total && 2 * packed_table_bytes(p) <= free_bytes && flat_b + packed_table_bytes(p) <= free_bytes;
+        return (uint64_t(1) << (2 * p)) <= kTableEntriesPerSymbol * total && 2 * packed_table_bytes(p) <= free_bytes && flat_b + packed_table_bytes(p) <= free_bytes;
     };
     for (int p = 17; p - 2 > c.flat; --p)
         if (fits(p)) {

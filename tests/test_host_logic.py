@@ -257,17 +257,18 @@ def test_automatic_table_depths_are_what_design_md_says():
     assert auto(1_946_213_783, 300 * GB) == (15, 17)         # C4: the flat parent is built deeper than its own budget allows
     assert auto(1_946_213_783, 100 * GB) == (14, 16)         # ... unless HBM is short: 2 x 73 GB do not fit
     assert auto(1_946_213_783, 20 * GB) == (13, 15)
-    assert auto(233_629_767, 300 * GB) == (13, 15)           # C3: 4^16 > 16 T
-    assert auto(101_000_000, 300 * GB) == (13, 15)           # C2
+    assert auto(233_629_767, 300 * GB) == (15, 17)           # C3: 73 entries per symbol -- most empty, a present k-mer's never
+    assert auto(101_000_000, 300 * GB) == (15, 17)           # C2: 170 per symbol (the limit is 256)
+    assert auto(60_000_000, 300 * GB) == (14, 16)            # below 6.7e7 symbols depth 17 would pass 256 entries per symbol
     assert auto(1_946_213_783, 300 * GB, pair_index=False) == (13, 0)   # no pair index: flat, within max(1 GiB, 2 x blocks)
     assert auto(90_000_000_000, 170 * GB, pair_index=False) == (15, 0)
-    assert auto(10, 300 * GB) == (1, 3)                      # TG$$CAGCCG
+    assert auto(10, 300 * GB) == (3, 5)                      # TG$$CAGCCG
     assert auto(0, 300 * GB) == (0, 0)
     assert auto(90_000_000_000, 0) == (15, 0)                # nothing known to be free: no packing
     for total in (5, 1000, 10 ** 6, 10 ** 9, 2 ** 39):
         flat, packed = auto(total, 300 * GB)
         assert 0 <= flat <= 15 and packed in (0, flat + 2) and (flat == 0 or 4 ** flat <= max(total, 4 ** (packed - 2) if packed else 0))
-        assert packed == 0 or 4 ** packed <= 16 * total
+        assert packed == 0 or 4 ** packed <= 256 * total
 
 
 def test_automatic_pair_stride_follows_memory_first_and_then_the_data():
