@@ -8,6 +8,7 @@
 // INTEGRATION.md.  Every query runs on the GPU; there is no CPU fallback.
 #pragma once
 
+#include <array>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -128,6 +129,18 @@ class RleBWT final : public BWT {
         return {std::move(fwd), std::move(rc)};
     }
 
+    /// Device batch (pointers on this handle's GPU), asynchronous on `hip_stream`; device_status() reports bad input.
+    void count_kmers_device(const void *d_kmers, std::size_t k, std::size_t n, void *d_out, void *hip_stream = nullptr) const {
+        check(msbwt_rle_count_kmers_device(raw_, d_kmers, k, n, d_out, hip_stream));
+    }
+    void device_status(void *hip_stream = nullptr) const { check(msbwt_rle_device_status(raw_, hip_stream)); }
+    /// One process per GPU: every rank ends up with all ranks' counts (d_all[r * n_mine + i] = rank r's d_mine[i]).
+    /// wire_bits 16 / 32 narrows the counts on the wire; device_status() throws Panic(MSBWT_ERR_OVERFLOW) if one did not fit.
+    void allgather_counts(void *comm, const void *d_mine, std::size_t n_mine, void *d_all, int wire_bits = 64,
+                          void *hip_stream = nullptr) const {
+        check(msbwt_rle_allgather_counts(raw_, comm, d_mine, n_mine, d_all, wire_bits, hip_stream));
+    }
+
     void set_table_depth(int depth) { check(msbwt_rle_set_table_depth(raw_, depth)); }
     void set_table_packed(int mode) { check(msbwt_rle_set_table_packed(raw_, mode)); }
     void set_pair_index(int mode) { check(msbwt_rle_set_pair_index(raw_, mode)); }
@@ -166,6 +179,30 @@ class RleBWT final : public BWT {
         }
     }
     msbwt_rle *raw_;
+};
+
+/// An RCCL communicator over the GPUs of a one-process-per-GPU job, made through the library (librccl.so is bound at run
+/// time).  Rank 0 calls RankComm::unique_id(), ships the bytes to the other ranks, every rank constructs a RankComm with its
+/// GPU current; RleBWT::allgather_counts takes raw().
+class RankComm {
+  public:
+    static std::array<unsigned char, MSBWT_COMM_ID_BYTES> unique_id() {
+        std::array<unsigned char, MSBWT_COMM_ID_BYTES> id{};
+        if (msbwt_comm_get_unique_id(id.data()) != MSBWT_OK) throw Panic(MSBWT_ERR_RCCL, "msbwt_comm_get_unique_id (is librccl.so there?)");
+        return id;
+    }
+    RankComm(int nranks, const std::array<unsigned char, MSBWT_COMM_ID_BYTES> &id, int rank) {
+        if (msbwt_comm_init_rank(&raw_, nranks, id.data(), rank) != MSBWT_OK) throw Panic(MSBWT_ERR_RCCL, "msbwt_comm_init_rank");
+    }
+    ~RankComm() {
+        if (raw_) msbwt_comm_destroy(raw_);
+    }
+    RankComm(const RankComm &) = delete;
+    RankComm &operator=(const RankComm &) = delete;
+    void *raw() const { return raw_; }
+
+  private:
+    void *raw_ = nullptr;
 };
 
 // ---- string_util (src/string_util.rs) and bwt_converter (src/bwt_converter.rs) ----
