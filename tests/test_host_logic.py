@@ -295,3 +295,31 @@ def test_automatic_pair_stride_follows_memory_first_and_then_the_data():
     for total in (10, 10 ** 6, 10 ** 9, 2 ** 39):
         for width in (-1.0, 2.0, 30.0):
             assert stride(total, 250 * GB, hbm, width) in (96, 128)
+
+
+def test_gather_entry_points_reject_bad_arguments_without_touching_a_device():
+    """The one-process-per-GPU entry points validate before they bind RCCL or touch HIP."""
+    import ctypes as C
+    L = _lib.lib()
+    comm = C.c_void_p()
+    ident = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+    assert L.msbwt_comm_get_unique_id(None) == _lib.ERR_INVALID_ARG
+    assert L.msbwt_comm_init_rank(None, 1, ident, 0) == _lib.ERR_INVALID_ARG
+    assert L.msbwt_comm_init_rank(C.byref(comm), 0, ident, 0) == _lib.ERR_INVALID_ARG      # no ranks
+    assert L.msbwt_comm_init_rank(C.byref(comm), 2, ident, 2) == _lib.ERR_INVALID_ARG      # rank outside the job
+    assert L.msbwt_comm_init_rank(C.byref(comm), 1, None, 0) == _lib.ERR_INVALID_ARG
+    assert L.msbwt_comm_destroy(None) == _lib.ERR_INVALID_ARG
+    assert L.msbwt_rle_allgather_counts(None, None, None, 0, None, 64, None) == _lib.ERR_INVALID_ARG
+    h = L.msbwt_rle_new(8)
+    try:
+        fake = C.c_void_p(1)
+        assert L.msbwt_rle_allgather_counts(h, None, None, 0, None, 64, None) == _lib.ERR_INVALID_ARG      # no communicator
+        assert L.msbwt_rle_allgather_counts(h, fake, None, 0, None, 48, None) == _lib.ERR_INVALID_ARG      # wire width
+        assert L.msbwt_rle_allgather_counts(h, fake, None, 5, None, 64, None) == _lib.ERR_INVALID_ARG      # counts without buffers
+        assert b"wire width" in L.msbwt_rle_last_error(h)
+        assert L.msbwt_rle_get_typical_range_width(h) == -1.0 and L.msbwt_rle_get_typical_range_width(None) == -1.0
+    finally:
+        L.msbwt_rle_free(h)
+    stride = C.c_int()
+    assert L.msbwt_auto_pair_stride(10**9, 10**11, 3 * 10**11, 30.0, None) == _lib.ERR_INVALID_ARG
+    assert L.msbwt_auto_pair_stride(10**9, 10**11, 3 * 10**11, 30.0, C.byref(stride)) == 0 and stride.value in (96, 128)
