@@ -128,6 +128,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-c4", action="store_true", help="skip the extra real-MSBWT (config C4, read-derived 31-mers) line of the default workload")
     ap.add_argument("--c4-scale", type=float, default=0.0, help="tests: run the extra C4 line on a shrunk C4 (0 = full size, only with --scale 1)")
     ap.add_argument("--c4-queries", type=int, default=100_000_000)
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="default workload, N = 1, full scale: do NOT re-measure the kernel's HBM traffic in this run (two rocprofv3 --pmc child "
+                         "passes of a shortened copy of the run, after the GPU has been handed back); roofline.traffic then comes from the committed "
+                         "summary under profiles/ only")
     ap.add_argument("--no-weak", action="store_true", help="N>1: skip the extra weak-scaling measurement")
     ap.add_argument("--no-native-gather", action="store_true", help="N>1: skip the extra measurement with the library's own RCCL all-gather")
     ap.add_argument("--force-dist", action="store_true",
@@ -246,6 +250,44 @@ def lookup_traffic(workload, k, bwt, kind, total, fused, full_size):
     except (OSError, KeyError, ValueError):
         pass
     return per_query, src, note, stamp
+
+
+def live_pmc_traffic(extra_args, queries, kernel_substr="k_count_kmers"):
+    """HBM-side bytes per query of the count kernel, measured NOW: two rocprofv3 --pmc child passes (FETCH_SIZE and
+    WRITE_SIZE separately, as MI355X_MICROARCH.md prescribes; the program goes directly after `--`) over a shortened copy
+    of this run -- same index (same seeds), `queries` present k-mers, one warm-up and two timed launches.  The caller
+    has released its GPU memory.  Returns (bytes per query, detail dict) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    means = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out_dir = tempfile.mkdtemp(prefix="msbwt_pmc_", dir="/tmp")
+        cmd = [prof, "--pmc", counter, "--kernel-include-regex", kernel_substr, "--kernel-trace", "--output-format", "csv", "-d", out_dir, "-o", "run",
+               "--", sys.executable, os.path.abspath(__file__), "--no-oracle", "--no-c5", "--no-c4", "--no-live-pmc", "--queries", str(queries),
+               "--steps", "2", "--warmup", "1"] + list(extra_args)
+        try:
+            done = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        except (OSError, subprocess.TimeoutExpired) as e:
+            shutil.rmtree(out_dir, ignore_errors=True)
+            return None, "%s pass failed: %r" % (counter, e)
+        vals = []
+        for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if kernel_substr in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                    vals.append(float(row["Counter_Value"]))
+        shutil.rmtree(out_dir, ignore_errors=True)
+        if done.returncode != 0 or not vals:
+            return None, "%s pass: rc %d, %d counter rows; %s" % (counter, done.returncode, len(vals), done.stderr[-300:].replace("\n", " | "))
+        means[counter] = (sum(vals) / len(vals), len(vals))
+    # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 tallies 128-byte read requests at 64 bytes (MI355X_MICROARCH.md, HBM section)
+    fetch_b, write_b = means["FETCH_SIZE"][0] * 1024 * 2, means["WRITE_SIZE"][0] * 1024
+    return (fetch_b + write_b) / queries, {"queries_per_launch": queries, "launches": means["FETCH_SIZE"][1],
+                                           "fetch_bytes_per_query_x2_gfx950": fetch_b / queries, "write_bytes_per_query": write_b / queries}
 
 
 def roofline_block(orc, ref, queries, k, ncpu, per_launch_q, kern_s, kernel_ms, launches, traffic_per_query, traffic_src, traffic_note,
@@ -753,9 +795,9 @@ def main():
                               "note": "%d sampled queries, static partition over all %d hardware threads of this box's share, same un-instrumented build" % (len(queries), nproc)},
             }
 
-    # ---- the REAL 30x MSBWT (config C4: 12.9 M reads, 1.95e9 symbols), read-derived 31-mers, one GPU ----------------
-    # The human-scale stand-in stream has independent symbols: a present k-mer's range collapses to width 1, searches
-    # are easier than on real data.  This line carries the real thing into the same record: ranges stay ~ coverage wide.
+    # ---- the REAL 30x MSBWT (config C4: 12.9 M reads WITH substitutions, 1.95e9 symbols, suffix-sorted on the host),
+    # read-derived 31-mers, one GPU: the human-scale index is an exact BWT too, but of error-free reads; this line carries
+    # reads with errors (14 % of their 31-mers end early) into the same record.
     c4_scale = args.c4_scale if args.c4_scale > 0 else (1.0 if args.scale == 1.0 else 0.0)
     if human and world == 1 and not multi and not args.no_c4 and c4_scale > 0 and rank == 0:
         del bwt, ref, rle, queries, got
@@ -812,6 +854,30 @@ def main():
             c4["roofline"] = {"kernel_ms": kms4, "kernel_launches": launches4}
         result["c4_real_reads"] = c4
         log("c4 line: %.3e q/s, %.2f ms per step" % (c4["value"], c4["ms_per_step"]))
+    # ---- the default line's HBM traffic, measured in THIS run (the committed summary stays beside it) ---------------------
+    if (human and rank == 0 and world == 1 and not multi and args.scale == 1.0 and not args.no_oracle and not args.no_live_pmc
+            and args.stream == "reads" and not args.queries and "roofline" in result and result.get("value")):
+        bwt = bwt4 = ref = ref4 = b4 = d_q4 = o4 = None   # hand the GPU (and 30 GB of host memory) to the child passes
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        t0 = time.time()
+        child_args = (["--k", str(args.k)] if args.k else []) + (["--table-depth", str(args.table_depth)] if args.table_depth > -2 else [])
+        per_q, detail = live_pmc_traffic(child_args, 100_000_000)
+        roof = result["roofline"]
+        if per_q is None:
+            roof["traffic_live"] = {"error": detail}
+            log("live PMC traffic: %s" % detail)
+        else:
+            kern_s = roof["kernel_ms"] / 1e3
+            committed = None if roof["traffic"] is None else roof["traffic"] / result["config"]["queries_per_gpu"]
+            traffic = per_q * result["config"]["queries_per_gpu"]
+            roof.update({"traffic": traffic, "achieved": traffic / kern_s / 1e9, "frac": traffic / kern_s / 1e9 / HBM_PEAK_GBS,
+                         "traffic_source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two child passes of this run (same index, %d present k-mers per launch)" % detail["queries_per_launch"],
+                         "traffic_note": None,
+                         "traffic_live": dict(detail, bytes_per_query=per_q, committed_bytes_per_query=committed, seconds=time.time() - t0),
+                         "random_lines": {"per_s": traffic / 128.0 / kern_s, "peak_per_s": RANDOM_LINE_PEAK, "frac": traffic / 128.0 / kern_s / RANDOM_LINE_PEAK}})
+            log("live PMC traffic: %.1f B per query (committed summary: %s) in %.0fs" % (per_q, "%.1f" % committed if committed else "none", time.time() - t0))
     if rank == 0:
         emit(result)
     if multi:
