@@ -173,7 +173,7 @@ __device__ __forceinline__ uint64_t pair_line_bound(const PairLine &L, uint64_t 
 }
 
 template <bool kReads, bool kPair, int kWords, bool kStride96>
-__global__ __launch_bounds__(64) void k_count_kmers_lanes(const uint4 *__restrict__ blocks, uint64_t total,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_count_kmers_lanes(const uint4 *__restrict__ blocks, uint64_t total,
                                                           const uint4 *__restrict__ table, uint32_t depth, uint32_t table_packed,
                                                           const uint32_t *__restrict__ filter, uint32_t filter_mask,
                                                           const uint4 *__restrict__ pair_blocks,

@@ -164,6 +164,17 @@ __device__ __forceinline__ void constexpr_shift_or(uint64_t (&bits)[kBits], uint
     }
 }
 
+// bits |= value << pos for a 12-bit value (pos is a compile-time constant after unrolling)
+template <int kBits>
+__device__ __forceinline__ void constexpr_shift_or12(uint64_t (&bits)[kBits], uint32_t value, uint32_t pos) {
+    const uint32_t word = pos >> 6, off = pos & 63u;
+#pragma unroll
+    for (int j = 0; j < kBits; ++j) {
+        if (word == uint32_t(j)) bits[j] |= uint64_t(value) << off;
+        if (j > 0 && word == uint32_t(j - 1) && off > 52u) bits[j] |= uint64_t(value) >> (64u - off);
+    }
+}
+
 template <int kWords>
 struct PackedQuery {
     static constexpr int kBits = (kWords + 1) / 2;
@@ -177,9 +188,65 @@ struct PackedQuery {
 // bytes that END at a query's last symbol, which for the tile's first queries start before the tile.
 constexpr uint32_t kStageLead = 64;
 
+// bytes `first`.. of a block are wanted: the mask of dword d's wanted bytes (wave-uniform arguments: scalar work)
+__device__ __forceinline__ uint32_t tail_byte_mask(uint32_t d, uint32_t first) {
+    const int lo = int(first) - int(4u * d);  // first wanted byte inside this dword
+    return lo <= 0 ? ~0u : (lo >= 4 ? 0u : (~0u << (8 * lo)));
+}
+
+// pack_query for a k-byte ROW of symbol codes in LDS (matrix queries, LDS-staged read windows), four symbols per
+// instruction (round 3; the byte-at-a-time version below cost ~5 of a random query's 6.5 VALU wave-instructions).
+// The block of kBlock bytes that ENDS at the row's last byte is read as dwords; step t (t = 0 first) is byte
+// kBlock-1-t, i.e. byte 3 - (t & 3) of dword D-1-(t >> 2):
+//   symbols >= 6   per byte, bit 7 of ((x + 0x7A) | x);
+//   3-bit packing  four bytes b0..b3 of a dword become the 12-bit group b3 | b2 << 3 | b1 << 6 | b0 << 9 (search
+//                  order: the highest address first) in two shift-or-mask rounds, group u lands at bit 12 u;
+//   table index    bytes outside the table's reach read as 'A' so that nothing borrows from them; A C G T -> 0..3 is
+//                  y - 1 - (y >> 2) per byte, the four 2-bit codes of a dword are gathered the same way; a '$' / 'N'
+//                  inside the reach (low two bits zero) turns the table off for this query.
+template <int kWords>
+__device__ __forceinline__ void pack_row_swar(uint32_t k, uint32_t depth, const uint8_t *row, PackedQuery<kWords> &pq) {
+    constexpr int kBits = PackedQuery<kWords>::kBits;
+    constexpr uint32_t kBlock = kWords == 3 ? 32u : 64u, D = kBlock / 4u;
+    uint32_t raw[D];
+    __builtin_memcpy(raw, row + k - kBlock, kBlock);  // LDS; the caller keeps kStageLead bytes in front of the tile
+    const uint32_t first_k = kBlock - k, first_d = kBlock - min(depth, k);
+#pragma unroll
+    for (int j = 0; j < kBits; ++j) pq.bits[j] = 0;
+    uint32_t bad = 0, nonacgt = 0;
+    uint64_t tidx = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < D; ++u) {  // steps 4u .. 4u+3
+        const uint32_t d = D - 1u - u;
+        const uint32_t x = raw[d] & tail_byte_mask(d, first_k);
+        bad |= ((x + 0x7A7A7A7Au) | x) & 0x80808080u;
+        const uint32_t y = x & 0x07070707u;
+        const uint32_t z = ((y >> 8) | (y << 3)) & 0x003F003Fu;
+        const uint32_t g = ((z >> 16) | (z << 6)) & 0xFFFu;
+        constexpr_shift_or12<kBits>(pq.bits, g, 12u * u);
+        if (u < 5u) {  // the table reaches at most 18 steps deep
+            const uint32_t dm = tail_byte_mask(d, first_d);
+            const uint32_t ys = (y & dm) | (0x01010101u & ~dm);
+            const uint32_t low2 = ys & 0x03030303u;
+            nonacgt |= (low2 - 0x01010101u) & ~low2 & 0x80808080u;  // some byte is 0 or 4 ('$' / 'N'; >= 6 is `bad`)
+            const uint32_t c = ys - 0x01010101u - ((ys >> 2) & 0x01010101u);
+            const uint32_t z2 = ((c >> 8) | (c << 2)) & 0x000F000Fu;
+            tidx |= uint64_t(((z2 >> 16) | (z2 << 4)) & 0xFFu) << (8u * u);
+        }
+    }
+    pq.tidx = tidx & ((1ull << (2u * min(depth, 20u))) - 1ull);
+    pq.bad = bad != 0u;
+    pq.acgt = nonacgt == 0u;
+}
+
 template <bool kReads, int kWords>
 __device__ __forceinline__ void pack_query(const QuerySource &src, uint32_t depth, const uint8_t *staged, uint64_t v,
                                            PackedQuery<kWords> &pq) {
+    if constexpr (!kReads) {
+        (void)v;
+        pack_row_swar<kWords>(src.k, depth, staged, pq);
+        return;
+    }
     constexpr int kBits = PackedQuery<kWords>::kBits;
     constexpr uint32_t kBlock = kWords == 3 ? 32u : 64u;  // >= k: the bytes of a query arrive as ONE block of wide loads
     const uint32_t k = src.k;
