@@ -138,3 +138,28 @@ def test_exact_bwt_of_a_read_set_without_suffix_sorting_the_reads(g, L, cov, see
     covering = np.array([int(cnt.numpy()[max(0, p + k - L):p + 1].sum()) for p in pos])
     got = a.count_kmers(q)
     assert (got >= covering).all() and (got == covering).mean() > 0.9
+
+
+def test_histogram_stream_follows_the_measured_run_lengths():
+    """synth.rle_stream(histogram=...): the independent-symbol stand-in draws (symbol, run length) from the committed histogram
+    of config C4's real MSBWT (synth/c4_run_histogram.json): exact symbol total, no two neighbouring runs of
+    one symbol, run-length distribution and mean as measured."""
+    import json
+    data = json.load(open(synth.HISTOGRAM_FILE))
+    assert data["symbols"] == 1_946_213_783 and abs(data["mean_run"] - data["symbols"] / data["runs"]) < 1e-9
+    rle, total = synth.rle_stream(30_000_000, 6.0, 5, histogram=synth.HISTOGRAM_FILE)
+    assert total == 30_000_000
+    sym = orc.decompress(rle)
+    assert len(sym) == total
+    hist = synth.run_histogram(rle)
+    lengths = np.arange(hist.shape[1], dtype=np.uint64)
+    assert int((hist * lengths[None, :]).sum()) == total          # runs decode to the symbol total: neighbours never merged
+    mean = total / hist.sum()
+    assert abs(mean - data["mean_run"]) < 0.15, mean
+    real_a = np.array([data["lengths"]["1"].get(str(l), 0) for l in range(1, 9)], dtype=np.float64) / data["runs_per_symbol"]["1"]
+    got_a = hist[1, 1:9] / hist[1].sum()
+    assert np.abs(real_a - got_a).max() < 0.01, (real_a, got_a)  # P(run length = 1..8 | symbol A)
+    assert hist[4].sum() == 0                                     # C4's reads hold no N
+    # deterministic for a given (target, seed)
+    again, _ = synth.rle_stream(30_000_000, 6.0, 5, histogram=synth.HISTOGRAM_FILE)
+    assert np.array_equal(rle, again)
