@@ -70,6 +70,12 @@ def main():
             got, exp = b.count_kmers(q), o.count_kmers(q)
             assert np.array_equal(got, exp), (kind, depth, k, len(rle))
             checks += len(q)
+            # the trait's own shape: single calls and tiny batches (kernel-argument / mailbox path, polled completion)
+            for i in rng.integers(0, len(q), size=4):
+                assert b.count_kmer(q[int(i)]) == int(exp[int(i)]), (kind, depth, k)
+            small = int(rng.integers(2, 65))
+            assert np.array_equal(b.count_kmers(q[:small]), exp[:small]), (kind, depth, k, small)
+            r1 = b.constrain_range(int(rng.integers(0, 6)), msbwt.BWTRange(0, total))
             # constrain_ranges around block / pair-block / superblock borders
             m = 300
             base = rng.integers(0, total + 1, size=m)
@@ -89,6 +95,12 @@ def main():
                 rcw = np.array([orc.reverse_complement_i(x) for x in wins], dtype=np.uint8)
                 assert np.array_equal(r.reshape(-1), o.count_kmers(rcw))
                 checks += 2 * len(wins)
+                # one strand only (a tile is 64 windows then), ASCII input
+                ascii_reads = np.frombuffer(b"$ACGNT", dtype=np.uint8)[sub]
+                f1, _ = b.count_read_kmers(ascii_reads, k, ascii=True, revcomp=False)
+                assert np.array_equal(f1, f)
+                _, r1 = b.count_read_kmers(sub, k, ascii=False, forward=False, revcomp=True)
+                assert np.array_equal(r1, r)
         rounds += 1
     print("stress ok: %d indexes, %d query checks in %.0fs" % (rounds, checks, time.time() - t0))
 
