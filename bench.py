@@ -121,6 +121,11 @@ def parse_args(argv=None):
                     help="N>1: strong = one fixed batch sharded over the ranks (default), weak = every rank the whole batch")
     ap.add_argument("--payload", default="auto", choices=["auto", "int64"],
                     help="N>1: auto = int16 counts on the wire when exact (falls back to int64), int64 = always wide")
+    ap.add_argument("--sort-queries", action="store_true",
+                    help="hand the batch over in the order of its batch-order keys (msbwt_rle_kmer_order_keys_device: by the last 17 symbols, then "
+                         "leftwards): the timed `value` is then that of an ordered batch.  The default human run reports it as the extra key "
+                         "`sorted_batch` instead")
+    ap.add_argument("--no-sorted", action="store_true", help="default workload: skip the extra `sorted_batch` measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-oracle", action="store_true",
                     help="profiling passes only: skip parity, algorithmic-byte counters and the CPU baseline (prints a lean line)")
@@ -441,6 +446,22 @@ def main():
     else:
         d_q = torch.from_numpy(synth.read_kmers(reads, k, limit=nq, seed=cfg["qseed"])).to(dev)
         nq = d_q.shape[0]
+    def table_order(q):
+        """the permutation that puts the rows of q into the order of their batch-order keys (msbwt_rle_kmer_order_keys_device)"""
+        keys = torch.empty(q.shape[0], dtype=torch.int64, device=dev)
+        bwt.kmer_order_keys_device(q.data_ptr(), q.shape[1], q.shape[0], keys.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        keys ^= -(2 ** 63)  # u64 order on int64 storage
+        return torch.argsort(keys)
+
+    def gathered(q, order, chunk=50_000_000):
+        out = torch.empty_like(q)
+        for lo_s in range(0, q.shape[0], chunk):
+            out[lo_s:lo_s + chunk] = q[order[lo_s:lo_s + chunk]]
+        return out
+
+    if args.sort_queries and d_q is not None:
+        d_q = gathered(d_q, table_order(d_q))
+        log("rank %d: batch ordered by its order keys" % rank)
     torch.cuda.synchronize(dev)
     log("rank %d: %d %s %d-mers in HBM in %.1fs" % (rank, nq, kind, k, time.time() - t0))
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -597,6 +618,24 @@ def main():
                       "note": "kernel_ms: average count-kernel duration per rank; exchange_ms_alone: narrow + all_gather + widen of one step "
                               "with no kernel running (max over ranks); inside a step the exchange overlaps the next step's kernel"}
 
+    # the same batch handed over in the order of its batch-order keys (include/msbwt_hip.h, "batch order"): what a caller
+    # that holds a sorted k-mer list, or counts a batch more than once, gets.  Counts must equal the unordered run's.
+    sorted_batch = None
+    if human and not multi and not args.sort_queries and not args.no_sorted and d_q is not None and rank == 0:
+        order = table_order(d_q)
+        d_sorted = gathered(d_q, order)
+        saved_steps, args.steps = args.steps, min(args.steps, 10)
+        s_out, _, s_elapsed, s_kms, _, _ = measure(Batch(bwt, d_sorted, 0), 0, nq, nq)
+        same = bool(torch.equal(s_out, d_counts[order]))
+        sorted_batch = {"value": nq * args.steps / s_elapsed, "unit": "queries/s", "ms_per_step": s_elapsed / args.steps * 1e3, "kernel_ms": s_kms,
+                        "steps": args.steps, "counts_equal_unordered_run": same,
+                        "note": "the same %d queries ordered by msbwt_rle_kmer_order_keys_device (sorting is outside the timed region: the caller's)" % nq}
+        args.steps = saved_steps
+        if not same:
+            log("PARITY FAILURE: the ordered batch's counts differ from the unordered run's")
+        del order, d_sorted, s_out
+        torch.cuda.empty_cache()
+
     weak = None
     if strong and not args.no_weak:
         # every rank the same (whole or 1e8-query) batch, all N x n counts gathered each step; bounded so that
@@ -699,6 +738,10 @@ def main():
         result["ranks"] = ranks_info
     if native is not None:
         result["native_gather"] = native
+    if sorted_batch is not None:
+        result["sorted_batch"] = sorted_batch
+        if not sorted_batch["counts_equal_unordered_run"]:
+            result["value"] = None
 
     # the rows the oracle will check travel to the host now; then the batch leaves HBM (the extra lines
     # below need up to 39 GB next to a 200 GB index)

@@ -167,6 +167,17 @@ int msbwt_comm_destroy(void *comm);
 int msbwt_rle_allgather_counts(const msbwt_rle *bwt, void *comm, const void *d_mine, size_t n_mine, void *d_all, int wire_bits,
                                void *hip_stream);
 
+/* ---- batch order (no reference counterpart) ----
+ * The order in which a batch is handed over does not change a single count, but it changes how fast they come: a batch whose
+ * k-mers are ordered by (their last 17 symbols as a string, then the symbols before those going leftwards) reads the suffix
+ * table in ascending order and keeps neighbouring queries on neighbouring index lines through the search -- measured 2.0x on
+ * dense batches (10^8 read-derived 31-mers over a 2 x 10^9-symbol BWT), +15 % on 3 x 10^8 31-mers over a 9 x 10^10-symbol one.
+ * The library does not reorder batches itself (sorting costs about what it saves on sparse batches); these calls hand out the
+ * 64-bit key to sort by (ascending), for callers that hold a sorted k-mer list anyway or count a batch more than once.
+ * kmers: n x k symbol codes; a '$' / 'N' / invalid symbol among the (at most 31) symbols the key reads gives UINT64_MAX. */
+int msbwt_kmer_order_keys(const uint8_t *kmers, size_t k, size_t n, uint64_t *out_keys);
+int msbwt_rle_kmer_order_keys_device(const msbwt_rle *bwt, const void *d_kmers, size_t k, size_t n, void *d_out_keys, void *hip_stream);
+
 /* ---- tuning / introspection (no reference counterpart) ---- */
 /* Depth of the precomputed suffix table (the reference's stubbed kmer_cache,
  * src/msbwt_core.rs:133-146): ranges for every ACGT suffix of length `depth` are computed

@@ -43,6 +43,8 @@ SIGNATURES = {
     "msbwt_comm_init_rank": (_int, [C.POINTER(C.c_void_p), _int, _vp, _int]),
     "msbwt_comm_destroy": (_int, [_vp]),
     "msbwt_rle_allgather_counts": (_int, [_vp, _vp, _vp, _sz, _vp, _int, _vp]),
+    "msbwt_kmer_order_keys": (_int, [_vp, _sz, _sz, _vp]),
+    "msbwt_rle_kmer_order_keys_device": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "msbwt_rle_set_table_depth": (_int, [_vp, _int]),
     "msbwt_rle_get_table_depth": (_int, [_vp]),
     "msbwt_rle_set_table_packed": (_int, [_vp, _int]),

@@ -20,6 +20,7 @@
 #include "kernels.hpp"
 #include "table_policy.hpp"
 #include "npy_io.hpp"
+#include "order.hpp"
 #include "pair_index.hpp"
 #include "plane_index.hpp"
 #include "rle_codec.hpp"
@@ -1267,6 +1268,24 @@ int msbwt_rle_allgather_counts(const msbwt_rle *ch, void *comm, const void *d_mi
                                           h->d_gather, h->d_flags + kDeviceFlags, static_cast<hipStream_t>(hip_stream), &why);
     if (e == hipSuccess) return MSBWT_OK;
     return why.empty() ? hip_fail(h, e, "all-gather of the counts") : fail(h, MSBWT_ERR_RCCL, why);
+}
+
+// ---- batch order keys (order.hip): sort a batch by them and it walks the index in ascending order -----------------------
+int msbwt_kmer_order_keys(const uint8_t *kmers, size_t k, size_t n, uint64_t *out_keys) {
+    if (k < 1 || k > 0xFFFFFFFFull || (n && (!kmers || !out_keys))) return MSBWT_ERR_INVALID_ARG;
+    order_keys_host(kmers, uint32_t(k), n, out_keys);
+    return MSBWT_OK;
+}
+
+int msbwt_rle_kmer_order_keys_device(const msbwt_rle *ch, const void *d_kmers, size_t k, size_t n, void *d_out_keys, void *hip_stream) {
+    msbwt_rle *h = const_cast<msbwt_rle *>(ch);
+    if (!h) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (k < 1 || k > 0xFFFFFFFFull || (n && (!d_kmers || !d_out_keys))) return fail(h, MSBWT_ERR_INVALID_ARG, "order keys need 1 <= k and buffers");
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    HIP_TRY(h, launch_order_keys(static_cast<const uint8_t *>(d_kmers), uint32_t(k), n, static_cast<uint64_t *>(d_out_keys), static_cast<hipStream_t>(hip_stream)));
+    return MSBWT_OK;
 }
 
 int msbwt_rle_set_table_depth(msbwt_rle *h, int depth) {

@@ -194,6 +194,12 @@ class RleBWT(BWT):
         if rc:
             _raise(rc, self._h)
 
+    def kmer_order_keys_device(self, d_kmers, k, n, d_out_keys, stream=0):
+        """msbwt_rle_kmer_order_keys_device: u64 keys (device pointers); a batch sorted by them ascending walks the index in order."""
+        rc = _lib.lib().msbwt_rle_kmer_order_keys_device(self._h, d_kmers, k, n, d_out_keys, stream)
+        if rc:
+            _raise(rc, self._h)
+
     def allgather_counts(self, comm, d_mine, n_mine, d_all, wire_bits=64, stream=0):
         """msbwt_rle_allgather_counts: d_all[r * n_mine + i] = rank r's d_mine[i] on every rank (device pointers,
         u64 counts), asynchronous on `stream`; wire_bits 16 / 32 narrows the payload (overflow -> device_status)."""
@@ -340,6 +346,20 @@ class RankComm:
             self.close()
         except (TypeError, AttributeError):
             pass
+
+
+def kmer_order_keys(kmers):
+    """msbwt_kmer_order_keys (host): the u64 key of every row of an (n, k) matrix of symbol codes; sort a batch by it
+    (ascending) and its queries read the suffix table, and then the index, in ascending order."""
+    a = np.ascontiguousarray(kmers, dtype=np.uint8)
+    if a.ndim != 2:
+        raise ValueError("kmers must be (n, k)")
+    n, k = a.shape
+    out = np.empty(n, dtype=np.uint64)
+    rc = _lib.lib().msbwt_kmer_order_keys(a.ctypes.data_as(C.c_void_p), k, n, out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise MsbwtError(rc, "msbwt_kmer_order_keys")
+    return out
 
 
 def _handles(replicas):

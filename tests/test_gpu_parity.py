@@ -677,6 +677,33 @@ def test_native_allgather_of_counts_over_rccl_one_rank(search_kernel):
     comm.close()
 
 
+def test_batch_order_keys_and_ordered_batches(search_kernel):
+    """msbwt_kmer_order_keys / _device: same keys on host and device; a batch sorted by them gives the same counts (permuted)."""
+    if search_kernel != "auto":
+        pytest.skip("the keys do not depend on the search kernel")
+    torch = pytest.importorskip("torch")
+    reads, rle = _real_bwt(51, 300, 90)
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for k in (3, 17, 21, 31, 40):
+        qs = np.concatenate([np.array([orc.convert_stoi(r[i:i + k]) for r in reads for i in (0, 11, 40)], dtype=np.uint8),
+                             random_kmers(k, 3000, k), random_kmers(k + 1, 200, k, alphabet=(0, 1, 2, 3, 4, 5))])
+        host_keys = msbwt.rle_bwt.kmer_order_keys(qs)
+        d_q = torch.from_numpy(qs).to(dev)
+        d_keys = torch.zeros(len(qs), dtype=torch.int64, device=dev)
+        b.kmer_order_keys_device(d_q.data_ptr(), k, len(qs), d_keys.data_ptr(), stream)
+        torch.cuda.synchronize(dev)
+        assert np.array_equal(d_keys.cpu().numpy().view(np.uint64), host_keys)
+        has_other = np.isin(qs[:, max(0, k - 31):], (0, 4)).any(axis=1)
+        assert np.array_equal(host_keys == np.uint64(2**64 - 1), has_other)
+        order = np.argsort(host_keys, kind="stable")
+        exp = o.count_kmers(qs)
+        assert np.array_equal(b.count_kmers(qs[order]), exp[order])
+
+
 def test_introspection(search_kernel):
     needs_plane_blocks(search_kernel)
     rle = random_stream(2, 30000, "short")
