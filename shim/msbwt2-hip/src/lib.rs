@@ -53,6 +53,8 @@ extern "C" {
     fn msbwt_comm_destroy(comm: *mut c_void) -> c_int;
     fn msbwt_rle_allgather_counts(bwt: *const MsbwtRle, comm: *mut c_void, d_mine: *const c_void, n_mine: usize,
                                   d_all: *mut c_void, wire_bits: c_int, hip_stream: *mut c_void) -> c_int;
+    // batch order: sort a batch by these keys (ascending) and it walks the index in order (up to 2x faster on dense batches)
+    fn msbwt_kmer_order_keys(kmers: *const u8, k: usize, n: usize, out_keys: *mut u64) -> c_int;
 }
 
 /// Same role as `RleBWT` (src/rle_bwt.rs:14-24); the index lives in HBM.
@@ -151,6 +153,17 @@ impl GpuRleBWTSet {
         if rc != MSBWT_OK { panic!("count_kmers_multi: code {}", rc); }
         out
     }
+}
+
+/// The key to sort a batch by (ascending) before it is counted: by the last 17 symbols of a k-mer, then leftwards -- the
+/// order in which the suffix table and the BWT lay the queries' ranges out.  Counts never depend on it, speed does.
+pub fn kmer_order_keys(kmers: &[u8], k: usize) -> Vec<u64> {
+    assert!(k >= 1 && kmers.len() % k == 0);
+    let n = kmers.len() / k;
+    let mut keys = vec![0u64; n];
+    let rc = unsafe { msbwt_kmer_order_keys(kmers.as_ptr(), k, n, keys.as_mut_ptr()) };
+    assert!(rc == MSBWT_OK, "msbwt_kmer_order_keys: code {}", rc);
+    keys
 }
 
 /// One rank of a one-process-per-GPU job: an RCCL communicator over the node's GPUs.  Rank 0 calls
