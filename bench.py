@@ -600,8 +600,11 @@ def main():
     lo, hi, cap = shard(nq)
     mine_n = hi - lo
     d_out, d_all, elapsed, kernel_ms, launches, narrow = measure(main_batch, lo, hi, cap)
-    if multi:  # the gathered vector must contain this rank's own counts where they belong
-        assert torch.equal(d_all[rank * cap:rank * cap + mine_n], d_out[:mine_n]), "gathered counts differ from the local ones"
+    # cross-rank consistency: a failed check does not abort the run (a crashed rank leaves no record at all); it is
+    # reported in the JSON line and voids `value`
+    inconsistent = []
+    if multi and not torch.equal(d_all[rank * cap:rank * cap + mine_n], d_out[:mine_n]):  # the gathered vector must contain this rank's own counts where they belong
+        inconsistent.append("rank %d: gathered counts differ from the local ones" % rank)
     ms_per_step = elapsed / args.steps * 1e3
     job_queries = nq if (strong or not multi) else nq * world
     value = job_queries * args.steps / elapsed
@@ -645,8 +648,10 @@ def main():
         was_strong, strong = strong, False
         w_out, w_all, w_elapsed, _, _, w_narrow = measure(main_batch, 0, nw, nw)
         strong = was_strong
-        assert torch.equal(w_all[rank * nw:(rank + 1) * nw], w_out)
-        assert torch.equal(w_out, d_counts[:nw]), "sharded counts differ from one GPU's counts of the same queries"
+        if not torch.equal(w_all[rank * nw:(rank + 1) * nw], w_out):
+            inconsistent.append("rank %d: weak-scaling gather differs from the local counts" % rank)
+        if not torch.equal(w_out, d_counts[:nw]):  # (also what would show if the replicas of the index differed between ranks)
+            inconsistent.append("rank %d: sharded counts differ from this GPU's own counts of the same queries" % rank)
         weak = {"value": nw * world * args.steps / w_elapsed, "unit": "queries/s", "ms_per_step": w_elapsed / args.steps * 1e3,
                 "queries_per_gpu": nw, "payload": "int16" if w_narrow else "int64",
                 "note": "every rank runs the same %d queries and all N x n counts are all_gathered each step" % nw}
@@ -739,6 +744,14 @@ def main():
         result["ranks"] = ranks_info
     if native is not None:
         result["native_gather"] = native
+    if multi:  # any rank's failed consistency check reaches rank 0
+        bad = torch.tensor([float(len(inconsistent))], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(bad, op=dist.ReduceOp.SUM)
+        if bad.item() > 0:
+            result["value"] = None
+            result["consistency_errors"] = inconsistent or ["%d check(s) failed on other ranks (see their stderr)" % int(bad.item())]
+            for msg in inconsistent:
+                log("CONSISTENCY FAILURE: " + msg)
     if sorted_batch is not None:
         result["sorted_batch"] = sorted_batch
         if not sorted_batch["counts_equal_unordered_run"]:
@@ -923,6 +936,8 @@ def main():
                          "random_lines": {"per_s": traffic / 128.0 / kern_s, "peak_per_s": RANDOM_LINE_PEAK, "frac": traffic / 128.0 / kern_s / RANDOM_LINE_PEAK}})
             log("live PMC traffic: %.1f B per query (committed summary: %s) in %.0fs" % (per_q, "%.1f" % committed if committed else "none", time.time() - t0))
     if rank == 0:
+        if result.get("value") is None:
+            rc = 1
         emit(result)
     if multi:
         dist.barrier()
