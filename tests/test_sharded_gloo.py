@@ -88,3 +88,23 @@ def test_sharded_count_matches_single_process(world, n):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n, 6, ret), nprocs=world, join=True)
     assert dict(ret) == {r: True for r in range(world)}
+
+
+def test_device_generated_batch_is_the_same_whichever_rank_generates_which_rows():
+    """bench.py's 1e9-query line at N > 1: the batch of random k-mers is defined chunk by chunk, a rank generates only the
+    rows of its shard -- every split must reproduce the rows of the whole (CPU generator here, same code path)."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cpu")
+    n, k, chunk = 10_000, 21, 1_024
+    whole = bench.device_random_kmers(torch, dev, 0, n, k, 99, chunk=chunk)
+    assert whole.shape == (n, k) and set(np.unique(whole.numpy())) <= {1, 2, 3, 5}
+    for world in (2, 3, 8):
+        parts = []
+        for rank in range(world):
+            lo, hi = shard_bounds(n, world, rank)
+            parts.append(bench.device_random_kmers(torch, dev, lo, hi, k, 99, chunk=chunk))
+        assert torch.equal(torch.cat(parts), whole), world
+    assert not torch.equal(bench.device_random_kmers(torch, dev, 0, n, k, 100, chunk=chunk), whole)   # the seed matters
