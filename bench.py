@@ -371,6 +371,7 @@ def main():
     nproc = os.cpu_count() or 1
     host_threads = max(1, min(16, nproc // max(1, world)))
     synth.set_threads(host_threads)
+    torch.set_num_threads(host_threads)
 
     human = args.workload == "human"
     big = human or args.workload == "big"
