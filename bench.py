@@ -125,6 +125,8 @@ def parse_args(argv=None):
                     help="hand the batch over in the order of its batch-order keys (msbwt_rle_kmer_order_keys_device: by the last 17 symbols, then "
                          "leftwards): the timed `value` is then that of an ordered batch.  The default human run reports it as the extra key "
                          "`sorted_batch` instead")
+    ap.add_argument("--sort-bits", type=int, default=0,
+                    help="with --sort-queries: order by the top B bits of the key only (stable; 0 = the whole key) -- how coarse a bucket pass may be")
     ap.add_argument("--no-sorted", action="store_true", help="default workload: skip the extra `sorted_batch` measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-oracle", action="store_true",
@@ -452,6 +454,9 @@ def main():
         """the permutation that puts the rows of q into the order of their batch-order keys (msbwt_rle_kmer_order_keys_device)"""
         keys = torch.empty(q.shape[0], dtype=torch.int64, device=dev)
         bwt.kmer_order_keys_device(q.data_ptr(), q.shape[1], q.shape[0], keys.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        if args.sort_bits > 0:  # the key's table index ends at bit 61
+            keys = (keys >> (62 - args.sort_bits)) & ((1 << args.sort_bits) - 1)
+            return torch.argsort(keys, stable=True)
         keys ^= -(2 ** 63)  # u64 order on int64 storage
         return torch.argsort(keys)
 

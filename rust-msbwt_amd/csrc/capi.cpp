@@ -64,6 +64,7 @@ struct msbwt_rle {
         void *counters = nullptr;
         hipEvent_t done = nullptr;
         bool used = false;  // `done` has been recorded at least once
+        hipStream_t last_stream = nullptr;  // the stream of the launch that used it last
     };
     std::vector<TicketSlot> tickets;
     // device status block (128 bytes): word 0 = flags of the host-pointer entry points (handle
@@ -184,12 +185,17 @@ IndexView view_of(msbwt_rle *h) {
 // until everything enqueued on `stream` so far -- the launch included -- has completed.  The caller holds h->mu.
 template <class Launch>
 hipError_t with_tickets(msbwt_rle *h, hipStream_t stream, Launch &&launch) {
+    // Launches queued back to back on ONE stream are ordered by the stream itself (the memset of the counters waits for the
+    // previous kernel), so they share a block without asking its event: a caller that enqueues N asynchronous launches
+    // gets one block, not N allocations inside its launch path.
     msbwt_rle::TicketSlot *slot = nullptr;
     for (auto &s : h->tickets)
-        if (!s.used || hipEventQuery(s.done) == hipSuccess) {
+        if (s.used && s.last_stream == stream) {
             slot = &s;
             break;
         }
+    for (auto &s : h->tickets)
+        if (!slot && (!s.used || hipEventQuery(s.done) == hipSuccess)) slot = &s;
     (void)hipGetLastError();  // hipErrorNotReady from a busy slot is not an error
     if (!slot) {
         msbwt_rle::TicketSlot fresh;
@@ -208,6 +214,7 @@ hipError_t with_tickets(msbwt_rle *h, hipStream_t stream, Launch &&launch) {
     // recorded even after a failed launch: the memset of the counters may already be queued
     const hipError_t r = hipEventRecord(slot->done, stream);
     slot->used = true;
+    slot->last_stream = stream;
     return e != hipSuccess ? e : r;
 }
 
@@ -230,7 +237,9 @@ constexpr size_t kMailKmers = 64, kMailCounts = kMailKmers + kMailKmerBytes, kMa
 int ensure_mail(msbwt_rle *h) {
     if (h->mail) return MSBWT_OK;
     void *host = nullptr, *dev = nullptr;
-    HIP_TRY(h, hipHostMalloc(&host, kMailBytes, hipHostMallocMapped));
+    // coherent explicitly: the host polls a word the kernel writes (HIP_HOST_COHERENT=0 in the environment must not turn every
+    // single-query call into a 2 ms spin)
+    HIP_TRY(h, hipHostMalloc(&host, kMailBytes, hipHostMallocMapped | hipHostMallocCoherent));
     const hipError_t e = hipHostGetDevicePointer(&dev, host, 0);
     if (e != hipSuccess) {
         (void)hipHostFree(host);
@@ -600,11 +609,20 @@ int flags_to_code(msbwt_rle *h, uint32_t flags) {
     return MSBWT_OK;
 }
 
-// Folds the recorded start/stop pairs into the running sum (waits for the kernels they bracket).
-int drain_timing_events(msbwt_rle *h) {
+// Folds the recorded start/stop pairs into the running sum.  wait = true (msbwt_rle_kernel_time_ms): waits for the kernels
+// they bracket; wait = false (inside an asynchronous launch): only the pairs whose kernel has completed -- in stream order, so
+// stopping at the first pending one loses nothing -- and never blocks the caller.
+int drain_timing_events(msbwt_rle *h, bool wait = true) {
     int rc = MSBWT_OK;
+    size_t kept = 0;
     for (size_t i = 0; i + 1 < h->events.size(); i += 2) {
         float ms = 0.f;
+        if (!wait && hipEventQuery(h->events[i + 1]) != hipSuccess) {
+            (void)hipGetLastError();
+            h->events[kept++] = h->events[i];
+            h->events[kept++] = h->events[i + 1];
+            continue;
+        }
         hipError_t e = hipEventSynchronize(h->events[i + 1]);
         if (e == hipSuccess) e = hipEventElapsedTime(&ms, h->events[i], h->events[i + 1]);
         if (e == hipSuccess) {
@@ -616,7 +634,7 @@ int drain_timing_events(msbwt_rle *h) {
         (void)hipEventDestroy(h->events[i]);
         (void)hipEventDestroy(h->events[i + 1]);
     }
-    h->events.clear();
+    h->events.resize(kept);
     return rc;
 }
 
@@ -641,7 +659,9 @@ int timed_launch(msbwt_rle *h, hipStream_t stream, Launch &&launch) {
     }
     h->events.push_back(start);
     h->events.push_back(stop);
-    if (h->events.size() >= 2 * kMaxTimedEvents) return drain_timing_events(h);  // a caller that never reads the timer must not grow this forever
+    // a caller that never reads the timer must not grow this forever: completed pairs are folded away without blocking; only a
+    // caller with more than 16 x kMaxTimedEvents launches IN FLIGHT is made to wait
+    if (h->events.size() >= 2 * kMaxTimedEvents) return drain_timing_events(h, h->events.size() >= 32 * kMaxTimedEvents);
     return MSBWT_OK;
 }
 

@@ -36,14 +36,17 @@ const Rccl &rccl() {
     static const Rccl bound = [] {
         Rccl r;
         // an instance that is already mapped wins (one RCCL per process), then the system one
+        // MSBWT_RCCL_LIB names THE library to use: an explicit wish is taken literally (no search beside it)
         const char *env = std::getenv("MSBWT_RCCL_LIB");
-        if (env && *env) r.lib = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+        const bool named = env && *env;
+        if (named) r.lib = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
         for (const char *name : {"librccl.so", "librccl.so.1"})
-            if (!r.lib) r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+            if (!r.lib && !named) r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-            if (!r.lib) r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!r.lib && !named) r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (!r.lib) {
-            r.why = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : "");
+            const char *msg = dlerror();  // once: the call clears the error it reports
+            r.why = std::string("librccl.so not found: ") + (msg ? msg : "");
             return r;
         }
         r.get_unique_id = reinterpret_cast<decltype(r.get_unique_id)>(dlsym(r.lib, "ncclGetUniqueId"));

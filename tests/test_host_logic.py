@@ -323,3 +323,24 @@ def test_gather_entry_points_reject_bad_arguments_without_touching_a_device():
     stride = C.c_int()
     assert L.msbwt_auto_pair_stride(10**9, 10**11, 3 * 10**11, 30.0, None) == _lib.ERR_INVALID_ARG
     assert L.msbwt_auto_pair_stride(10**9, 10**11, 3 * 10**11, 30.0, C.byref(stride)) == 0 and stride.value in (96, 128)
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """A host without RCCL: the communicator entry points return MSBWT_ERR_RCCL (include/msbwt_hip.h) -- in a fresh process,
+    with MSBWT_RCCL_LIB naming a library that does not exist (an explicit name is taken literally: no search beside it)."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, importlib, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "L = importlib.import_module('rust-msbwt_amd')._lib\n"
+        "ident = (C.c_uint8 * L.COMM_ID_BYTES)()\n"
+        "comm = C.c_void_p()\n"
+        "a = L.lib().msbwt_comm_get_unique_id(ident)\n"
+        "b = L.lib().msbwt_comm_init_rank(C.byref(comm), 1, ident, 0)\n"
+        "c = L.lib().msbwt_comm_destroy(C.c_void_p(1))\n"
+        "print(a, b, c)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, MSBWT_RCCL_LIB="/nonexistent/librccl_not_here.so")
+    done = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert done.returncode == 0, done.stderr[-400:]
+    assert done.stdout.split() == [str(_lib.ERR_RCCL)] * 3, done.stdout + done.stderr[-400:]
