@@ -5,10 +5,10 @@ One "step" = one pass of the hot path (msbwt_rle_count_kmers_device) over one ba
 queries that is already resident in HBM.
 
 Default workload ("human") = the configuration BASELINE.json quotes its metric on, on ONE GPU:
-k = 31 on a 30x-human-scale index (9e10 symbols; a structure-equivalent synthetic RLE stream whose
-runs are drawn from the run-length histogram of config C4's real MSBWT), 3e8 PRESENT
-31-mers per step (LF-walk; every query runs all 31 steps -- the read-corrector case).  Extra keys of the
-default run:
+k = 31 on a 30x-human-scale index -- 9e10 symbols, the EXACT multi-string BWT of 5.96e8 error-free 150-bp
+reads of a random 2.98e9-bp genome, built on the GPU in the run (synth/bwt_reads.py; --stream histogram /
+geometric select the independent-symbol stand-ins of rounds 1-2) -- and 3e8 PRESENT 31-mers per step
+(LF-walk; every query runs all 31 steps -- the read-corrector case).  Extra keys of the default run:
   c5_random_1e9  the literal configs[4] line: 1e9 random 31-mers generated in HBM, sharded over the ranks
                  and gathered when N > 1;
   c4_real_reads  (N = 1) the REAL multi-string BWT of config C4 (12.9 M reads, 1.95e9 symbols, built on the
@@ -94,7 +94,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="human", choices=["human", "c2", "c3", "c4", "c4x3", "big"])
+    ap.add_argument("--workload", default="human", choices=["human", "c2", "c3", "c4", "c4r", "c4x3", "big"])
     ap.add_argument("--big-symbols", type=float, default=2.0**33, help="workload big: BWT length")
     ap.add_argument("--big-mean-run", type=float, default=6.0)
     ap.add_argument("--stream", default="reads", choices=["reads", "histogram", "geometric"],
@@ -145,6 +145,10 @@ def parse_args(argv=None):
                     help="run the N>1 code path (process group, all_gather of the counts, barriers) even with one rank: "
                          "a one-GPU rehearsal of the RCCL calls themselves")
     ap.add_argument("--c5-queries", type=int, default=0, help="queries of the extra random-31-mer line (0 = 1e9 at full scale, none on a shrunk index)")
+    ap.add_argument("--counters", action="store_true",
+                    help="one extra, untimed pass with the library's search counters on (msbwt_rle_set_search_counters): steps, second lines, "
+                         "escape lines per query -> `search_counters` in the JSON line")
+    ap.add_argument("--no-table-side", action="store_true", help="packed table without its side array: queries of escape lines search from scratch (round 3)")
     ap.add_argument("--parity-sample", type=int, default=200_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     return ap.parse_args(argv)
@@ -299,29 +303,54 @@ def live_pmc_traffic(extra_args, queries, kernel_substr="k_count_kmers"):
 
 
 def roofline_block(orc, ref, queries, k, ncpu, per_launch_q, kern_s, kernel_ms, launches, traffic_per_query, traffic_src, traffic_note,
-                   stamp, label, stats_sample):
-    """roofline object of one measured line: counter traffic / kernel time / 8 TB/s, next to the
-    algorithmic bytes of the REFERENCE algorithm for this query set (exact counters from the instrumented oracle)."""
+                   stamp, label, stats_sample, table_depth=0, pair_index=True, ordered=False):
+    """roofline object of one measured line ("Bytes"): counter traffic / kernel time / 8 TB/s, next to
+    (a) layout_algorithmic -- the bytes the RUNNING layout must move for this query set: one 128-byte table line (k >= table
+        depth), then one 128-byte line per search step -- a pair step for every two remaining symbols, a plane step for an odd
+        last one -- for the share of steps the queries execute (exact step counters of the instrumented oracle), + k + 8
+        bytes of query and count; and
+    (b) reference_algorithm -- SURVEY 8(d)'s figure, the bytes the REFERENCE's algorithm touches for the same queries."""
     st = orc.Stats()
     nst = min(len(queries), stats_sample) if stats_sample else len(queries)
     ref.count_kmers(queries[:nst], nthreads=ncpu, stats=st)
     alg_bytes = st.algorithmic_bytes(k) / nst * per_launch_q  # exact when nst == nq, else scaled from the sample
     traffic = None if traffic_per_query is None else traffic_per_query * per_launch_q
     achieved = None if traffic is None else traffic / kern_s / 1e9
+    # (a): the layout's own minimum.  mean_steps = reference steps executed per query (a query ends at its first empty range)
+    mean_steps = st.steps / nst
+    use_table = table_depth > 0 and k >= table_depth
+    after = k - table_depth if use_table else k
+    step_lines_full = ((after + 1) // 2) if pair_index else after          # pair steps (+ one plane step for an odd remainder)
+    executed = 1.0 if after == 0 else max(0.0, min(1.0, (mean_steps - (table_depth if use_table else 0)) / after))
+    lines = (1.0 if use_table else 0.0) + step_lines_full * executed
+    layout_bytes = lines * 128.0 + k + 8
+    layout = {
+        "bytes_per_query": layout_bytes, "lines_per_query": lines, "table_line": 1 if use_table else 0,
+        "search_lines_if_all_steps_run": step_lines_full, "share_of_steps_executed": executed,
+        "frac_algorithmic": layout_bytes * per_launch_q / kern_s / 1e9 / HBM_PEAK_GBS,
+        "traffic_over_algorithmic": None if traffic_per_query is None else traffic_per_query / layout_bytes,
+        "note": "bytes the layout that RUNS must move per query: (1 table line if k >= depth %d) + ceil((k - depth) / 2) pair lines "
+                "(+ 1 plane line for an odd remainder) x 128 B x the share of post-table steps the queries execute (oracle step counters: "
+                "%.2f of %d reference steps per query) + k + 8; frac_algorithmic = that / kernel time / 8 TB/s; traffic_over_algorithmic = "
+                "counter bytes / it (> 1: ranges straddling two lines, superblock words; < 1: lines served by L2 / Infinity Cache)"
+                % (table_depth, mean_steps, k)}
+    if ordered:
+        layout["note"] += "; this launch includes the library's batch-ordering pass, whose streaming traffic is not part of the minimum"
     return {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": None if achieved is None else achieved / HBM_PEAK_GBS,
         "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note, "kernel_stamp": stamp,
         "kernel": label, "kernel_ms": kernel_ms, "kernel_launches": launches,
-        "algorithmic": {
+        "layout_algorithmic": layout,
+        "reference_algorithm": {
             "bytes_per_launch": int(alg_bytes), "bytes_per_query": alg_bytes / per_launch_q,
-            "GBps": alg_bytes / kern_s / 1e9, "x_hbm_peak": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
-            "mean_steps_per_query": st.steps / nst, "mean_bin_visits_per_query": st.visits / nst, "stats_queries": int(nst),
+            "GBps": alg_bytes / kern_s / 1e9, "speedup_over_hbm_peak_at_reference_bytes": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
+            "mean_steps_per_query": mean_steps, "mean_bin_visits_per_query": st.visits / nst, "stats_queries": int(nst),
             "note": "bytes the REFERENCE algorithm touches for this query set (SURVEY 8d: 56 B of samples + scanned RLE bytes per "
                     "bin visit, + k + 8 per query) / kernel time.  The suffix table and pair steps make this kernel move fewer "
-                    "bytes than that, so it is a speed-up measure, not a bandwidth fraction"},
-        "note": "achieved/frac = measured HBM-side traffic of one launch (rocprofv3 PMC, committed summary) / kernel time measured "
-                "live with HIP events on the launch stream / 8 TB/s",
+                    "bytes than that: a speed-up measure (it exceeds 1 x peak), never a bandwidth fraction"},
+        "note": "achieved/frac = measured HBM-side traffic of one launch (rocprofv3 PMC: FETCH_SIZE x 2 + WRITE_SIZE, separate passes) / "
+                "kernel time measured live with HIP events on the launch stream / 8 TB/s",
         "random_lines": None if traffic is None else {
             "per_s": traffic / 128.0 / kern_s, "peak_per_s": RANDOM_LINE_PEAK, "frac": traffic / 128.0 / kern_s / RANDOM_LINE_PEAK},
     }
@@ -392,6 +421,8 @@ def main():
     bwt.set_block_format(args.blocks)
     if args.table_depth > -2:
         bwt.set_table_depth(args.table_depth)
+    if args.no_table_side:
+        bwt.set_table_side(0)
     t0 = time.time()
     rle = npy = reads = None
     if big:
@@ -589,6 +620,28 @@ def main():
             res = timed(batch, False, a, b, per_rank, native, exchange)
         return res[:5] + (narrow,)
 
+    def counted_pass(the_bwt, batch, a, b, per_rank):
+        """what one launch does to the index, per query: one untimed pass with the library's search counters on"""
+        the_bwt.search_counters(stream)
+        the_bwt.set_search_counters(True)
+        run_steps(batch, 1, False, a, b, per_rank)
+        c = the_bwt.search_counters(stream)
+        the_bwt.set_search_counters(False)
+        nqs = max(1, b - a)
+        info = the_bwt.table_info()
+        return {"queries": b - a, "raw": c,
+                "lines_per_query": (c["first_lines"] + c["second_lines"]) / nqs + (1.0 if the_bwt.get_table_depth() else 0.0),
+                "search_lines_per_query": (c["first_lines"] + c["second_lines"]) / nqs,
+                "steps_per_searched_query": c["lane_steps"] / max(1, c["searched"]),
+                "second_line_rate": c["second_lines"] / max(1, c["lane_steps"]),
+                "sat_out_per_step": c["sat_out"] / max(1, c["lane_steps"]),
+                "lanes_busy_per_wave_step": c["lane_steps"] / max(1, c["wave_steps"]),
+                "escape_query_fraction": c["escape_queries"] / nqs, "escape_restart_fraction": c["escape_restarts"] / nqs,
+                "decided_by_table_fraction": c["table_decided"] / nqs,
+                "table": info, "escape_line_fraction": info["escape_lines"] / max(1, info["lines"]),
+                "note": "lines_per_query = lines the search asked for (first + second bound lines, side-array lines included) + one table line; "
+                        "counted by the kernel itself in an extra pass (msbwt_rle_set_search_counters)"}
+
     def shard(n_all):
         if strong:
             a, b = msbwt.sharded.shard_bounds(n_all, world, rank)  # 16-query aligned: every shard keeps the fast kernels
@@ -612,6 +665,9 @@ def main():
     if multi and not torch.equal(d_all[rank * cap:rank * cap + mine_n], d_out[:mine_n]):  # the gathered vector must contain this rank's own counts where they belong
         inconsistent.append("rank %d: gathered counts differ from the local ones" % rank)
     ms_per_step = elapsed / args.steps * 1e3
+    counters = None
+    if args.counters and not multi:
+        counters = counted_pass(bwt, main_batch, lo, hi, cap)
     job_queries = nq if (strong or not multi) else nq * world
     value = job_queries * args.steps / elapsed
     d_counts = stitch(d_all, d_out, nq, cap)
@@ -715,9 +771,9 @@ def main():
               "%d %s %d-mers per step" % (args.workload, total, "drawn from the run-length histogram of config C4's real MSBWT (synth/c4_run_histogram.json)"
                                           if hist_file else "geometric, mean %.1f" % args.big_mean_run, nq, kind_text, k))
     else:
-        wl = ("%s: %d synthetic %d-bp reads (%.0fx of a %d-bp random genome, %.1f%% subst.) -> MSBWT of %d symbols; %d %s %d-mers per step"
+        wl = ("%s: %d synthetic %d-bp reads (%.0fx of a %d-bp %s genome, %.1f%% subst.) -> MSBWT of %d symbols; %d %s %d-mers per step"
               % (args.workload, len(reads), reads.shape[1], len(reads) * reads.shape[1] / max(1, int(cfg["genome"] * args.scale)),
-                 int(cfg["genome"] * args.scale), cfg["err"] * 100, total, nq,
+                 int(cfg["genome"] * args.scale), "repeat-bearing (synth.REPEAT_FAMILIES)" if cfg.get("repeats") else "random", cfg["err"] * 100, total, nq,
                  "read-derived (ALL windows of ALL reads, prepared in-kernel)" if fused else kind_text, k))
     result = {
         "metric": "k-mer count queries/sec (whole node)",
@@ -758,6 +814,8 @@ def main():
             result["consistency_errors"] = inconsistent or ["%d check(s) failed on other ranks (see their stderr)" % int(bad.item())]
             for msg in inconsistent:
                 log("CONSISTENCY FAILURE: " + msg)
+    if counters is not None:
+        result["search_counters"] = counters
     if sorted_batch is not None:
         result["sorted_batch"] = sorted_batch
         if not sorted_batch["counts_equal_unordered_run"]:
@@ -841,7 +899,8 @@ def main():
         kern_s = kernel_ms / 1e3 if launches else elapsed / args.steps
         tq, tsrc, tnote, stamp = lookup_traffic(args.workload, k, bwt, kind, total, fused, args.scale == 1.0)
         result["roofline"] = roofline_block(orc, ref, queries, k, ncpu, per_launch_q, kern_s, kernel_ms, launches, tq, tsrc, tnote, stamp,
-                                            kernel_label(bwt, k, fused), args.stats_sample)
+                                            kernel_label(bwt, k, fused), args.stats_sample, bwt.get_table_depth(), bwt.get_pair_index(),
+                                            (not fused) and bwt.batch_order_for(k, per_launch_q))
         if world == 1 and not args.no_cpu_baseline:
             ncs = min(len(queries), args.cpu_sample)
             t0 = time.time()
@@ -906,7 +965,8 @@ def main():
                 rc = 1
             tq, tsrc, tnote, stamp = lookup_traffic("c4", 31, bwt4, "reads", total4, False, c4_scale == 1.0)
             c4["roofline"] = roofline_block(orc, ref4, qs4, 31, ncpu, n4, kms4 / 1e3 if launches4 else el4 / args.steps, kms4, launches4, tq, tsrc,
-                                            tnote, stamp, kernel_label(bwt4, 31, False), args.stats_sample)
+                                            tnote, stamp, kernel_label(bwt4, 31, False), args.stats_sample, bwt4.get_table_depth(), bwt4.get_pair_index(),
+                                            bwt4.batch_order_for(31, n4))
             if not args.no_cpu_baseline:
                 ncs4 = min(len(qs4), args.cpu_sample // 4)
                 t0 = time.time()

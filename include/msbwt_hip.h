@@ -97,6 +97,20 @@ int msbwt_rle_constrain_ranges_device(const msbwt_rle *bwt, const void *d_syms, 
                                       void *hip_stream);
 int msbwt_rle_device_status(const msbwt_rle *bwt, void *hip_stream);
 
+/* ---- compact queries: two bits per symbol (no reference counterpart; the trait's count_kmer takes one byte per symbol,
+ * src/msbwt_core.rs:125, codes as string_util.rs:15-67 makes them) ----
+ * A k-mer over ACGT, 1 <= k <= 64, as ceil(k / 32) u64 words: the k-mer read as a base-4 number with A C G T -> 0 1 2 3 and
+ * its FIRST symbol most significant -- the usual 2-bit k-mer of k-mer counters: the last symbol sits in bits 0-1 of word 0,
+ * symbol k-33 (k > 32) in bits 0-1 of word 1; bits beyond 2k are ignored.  8 bytes per 31-mer instead of 31: the host entry
+ * point moves 8 + 8 (or 8 + 4) bytes per query over PCIe instead of 31 + 8, and the search kernel reads the words as they are.
+ * '$' and 'N' cannot be said: such queries go through msbwt_rle_count_kmers.  Counts are those of the byte form, always.
+ * msbwt_kmers_pack_2bit: n x k symbol codes -> words (MSBWT_ERR_INVALID_SYMBOL for a code outside A C G T).
+ * count_bits: 64 (uint64_t out_counts[n]) or 32 (uint32_t out_counts[n]; a count that does not fit makes the call return
+ * MSBWT_ERR_OVERFLOW).  Device form: d_kmers2bit 8-byte aligned, u64 counts, asynchronous like msbwt_rle_count_kmers_device. */
+int msbwt_kmers_pack_2bit(const uint8_t *kmers, size_t k, size_t n, uint64_t *out_words);
+int msbwt_rle_count_kmers_packed(const msbwt_rle *bwt, const uint64_t *kmers2bit, size_t k, size_t n, void *out_counts, int count_bits);
+int msbwt_rle_count_kmers_packed_device(const msbwt_rle *bwt, const void *d_kmers2bit, size_t k, size_t n, void *d_out_counts, void *hip_stream);
+
 /* Fused query preparation + counting: every k-mer window of every read, on the forward strand
  * and/or reverse-complemented, without materialising the n x k query matrix.  Replaces the
  * host-side loop  convert_stoi (src/string_util.rs:63-67) -> windows -> reverse_complement_i
@@ -176,6 +190,17 @@ int msbwt_rle_allgather_counts(const msbwt_rle *bwt, void *comm, const void *d_m
  * 64-bit key to sort by (ascending), for callers that hold a sorted k-mer list anyway or count a batch more than once.
  * kmers: n x k symbol codes; a '$' / 'N' / invalid symbol among the (at most 31) symbols the key reads gives UINT64_MAX. */
 int msbwt_kmer_order_keys(const uint8_t *kmers, size_t k, size_t n, uint64_t *out_keys);
+/* Since round 4 the library orders DENSE batches itself, inside the launch: a bucket pass on the device by the top 22 key bits
+ * (MSBWT_ORDER_BITS), the queries packed to two bits per symbol on the way; the search kernel counts the ordered batch and
+ * writes every count to its query's own place in the caller's buffer -- the caller sees its order, only sooner.  mode -1 =
+ * automatic (default): batches of at least 2^22 queries with at least two queries per 128 BWT positions, on an index large
+ * enough to have no presence filter -- 10^8 read-derived 31-mers over a 2 x 10^9-symbol BWT: yes; 3 x 10^8 over 9 x 10^10: no
+ * (the pass costs more than the order saves there); 0 = never, 1 = whenever the pass applies (pair index, 12 <= k <= 64,
+ * 4096 <= n < 2^32).  MSBWT_ORDER=0|1|auto in the environment sets the initial mode.  Applies to msbwt_rle_count_kmers[_device]
+ * and the packed forms.  msbwt_rle_batch_order_for: 1 if a batch of n k-symbol queries would be ordered now.  Results never change. */
+int msbwt_rle_set_batch_order(msbwt_rle *bwt, int mode);
+int msbwt_rle_get_batch_order(const msbwt_rle *bwt);
+int msbwt_rle_batch_order_for(const msbwt_rle *bwt, size_t k, size_t n);
 int msbwt_rle_kmer_order_keys_device(const msbwt_rle *bwt, const void *d_kmers, size_t k, size_t n, void *d_out_keys, void *hip_stream);
 
 /* ---- tuning / introspection (no reference counterpart) ---- */
@@ -198,6 +223,15 @@ int msbwt_rle_get_table_depth(const msbwt_rle *bwt);
  * msbwt_rle_get_table_depth reports the effective depth (flat depth + 2).  Lines whose deltas do not
  * fit 16 bits are marked and their queries search from scratch.  Results never change. */
 int msbwt_rle_set_table_packed(msbwt_rle *bwt, int mode);
+/* Escape lines of the packed table -- lines holding a range 2^16 or more wide, or further than that from the line's
+ * first range: the suffixes of high-copy repeats (Alu-, L1-like families, satellites) -- keep their 30 ranges as flat
+ * 16-byte entries in a SIDE array (512 bytes per such line): a query that lands on one pays one more line fetch, like any
+ * search step, instead of searching from scratch (the reference's constrain_range costs the same for any range width,
+ * src/rle_bwt.rs:202-287).  mode 1 = on (default), 0 = off (MSBWT_TABLE_SIDE=0 in the environment).  Results never change.
+ * msbwt_rle_table_info: lines of the packed table in HBM, how many are escape lines, bytes of the side array (all 0
+ * without a packed table). */
+int msbwt_rle_set_table_side(msbwt_rle *bwt, int mode);
+int msbwt_rle_table_info(const msbwt_rle *bwt, uint64_t *lines, uint64_t *escape_lines, uint64_t *side_bytes);
 /* The automatic choice, as a pure function (no device needed): levels of the flat table built first and of
  * the packed table it becomes (0 = stays flat), for an index of `total_symbols` symbols with `free_hbm_bytes`
  * of HBM free once plane and pair blocks are in place. */
@@ -236,6 +270,20 @@ double msbwt_rle_get_typical_range_width(const msbwt_rle *bwt);
  * `free_hbm_bytes` free once the plane blocks are in place on a device of `hbm_total_bytes`, given the typical
  * range width the probe reports (negative = unknown). */
 int msbwt_auto_pair_stride(uint64_t total_symbols, uint64_t free_hbm_bytes, uint64_t hbm_total_bytes, double typical_width, int *stride);
+/* A memory budget for the whole index -- the analogue of the reference's one space / time knob, `bin_power`
+ * (src/rle_bwt.rs:309-322; here results never depend on it, only speed).  bytes = HBM the loaded index may hold, 0 = no budget
+ * (default; MSBWT_MEMORY_BUDGET=<bytes> in the environment sets the initial value).  The plane blocks (0.5 byte per symbol) are
+ * always built; what the budget leaves goes, in this order, to the pair blocks (whenever they fit), to the
+ * deepest packed suffix table that fits, and to overlapping pair blocks when the data keep ranges wide -- one plan, made
+ * at load time (or at once, if an index is loaded: the optional structures are rebuilt).  Explicit settings
+ * (msbwt_rle_set_table_depth, _set_pair_index, _set_pair_stride) still win over the plan.
+ * msbwt_auto_index_plan: the plan as a pure function (no device needed) for an index of `total_symbols` symbols with
+ * `free_hbm_bytes` free once its plane blocks are in place; *index_bytes (optional) = what the planned index holds
+ * (presence filter, at most 2 MiB, and the table's side array not counted). */
+int msbwt_rle_set_memory_budget(msbwt_rle *bwt, uint64_t bytes);
+uint64_t msbwt_rle_get_memory_budget(const msbwt_rle *bwt);
+int msbwt_auto_index_plan(uint64_t total_symbols, uint64_t free_hbm_bytes, uint64_t hbm_total_bytes, double typical_width, uint64_t budget_bytes,
+                          int *pair_index, int *pair_stride, int *flat_depth, int *packed_depth, uint64_t *index_bytes);
 /* Block format of the index, chosen BEFORE a load (MSBWT_BLOCKS=runs in the environment sets the
  * initial choice): 0 = bit-plane blocks (default: 0.5 byte per symbol, fastest, the only format the
  * pair index and the lane-per-query kernel work on), 1 = run blocks -- the layout of the reference's
@@ -255,6 +303,16 @@ int msbwt_rle_get_search_kernel(const msbwt_rle *bwt);
 /* The kernel a batch of k-symbol queries runs on with the index and mode as they are now: 1 or 2 as
  * above, 0 for k > 64 (generic 8-lane kernel, no suffix table); negative = error. */
 int msbwt_rle_search_kernel_for(const msbwt_rle *bwt, size_t k);
+/* Search counters (measurement aid, off by default): with them on, every wave of the one-query-per-lane kernel adds what its
+ * queries did to a block of MSBWT_SEARCH_COUNTERS u64 -- [0] search steps of a wave, [1] steps taken by a query (one line
+ * fetch each), [2] of which two-symbol steps, [3] steps that needed a second line (range over two blocks), [4] steps a query
+ * waited because the second-line slots of its wave were taken, [5] queries whose packed-table line is an escape line,
+ * [6] of which searched from scratch (no side array), [7] queries decided by the table / presence filter alone, [8] queries
+ * that entered the search, [9] first lines fetched; the rest 0.  msbwt_rle_search_counters copies the block out and
+ * zeroes it (synchronises `hip_stream`, on which the counted launches ran).  Results never change. */
+#define MSBWT_SEARCH_COUNTERS 16
+int msbwt_rle_set_search_counters(msbwt_rle *bwt, int enabled);
+int msbwt_rle_search_counters(const msbwt_rle *bwt, uint64_t *out, void *hip_stream);
 /* Bytes of HBM held by the index (blocks + table + filter + pair index). */
 uint64_t msbwt_rle_device_bytes(const msbwt_rle *bwt);
 /* Average duration in ms of the count kernel launches since the last reset, measured with

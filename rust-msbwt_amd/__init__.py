@@ -44,3 +44,17 @@ def auto_pair_stride(total_symbols, free_hbm_bytes, hbm_total_bytes, typical_wid
     if rc:
         raise MsbwtError(rc, "msbwt_auto_pair_stride")
     return stride.value
+
+
+def auto_index_plan(total_symbols, free_hbm_bytes, hbm_total_bytes, typical_width=-1.0, budget_bytes=0):
+    """What the loader builds under a memory budget (msbwt_rle_set_memory_budget; 0 = none) for an index of that size:
+    {"pair_index", "pair_stride", "flat_depth", "packed_depth", "index_bytes"}.  Pure host logic (csrc/table_policy.hpp, plan_index)."""
+    import ctypes
+    pair, stride, flat, packed = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    size = ctypes.c_uint64(0)
+    rc = _lib.lib().msbwt_auto_index_plan(int(total_symbols), int(free_hbm_bytes), int(hbm_total_bytes), float(typical_width), int(budget_bytes),
+                                          ctypes.byref(pair), ctypes.byref(stride), ctypes.byref(flat), ctypes.byref(packed), ctypes.byref(size))
+    if rc:
+        raise MsbwtError(rc, "msbwt_auto_index_plan")
+    return {"pair_index": bool(pair.value), "pair_stride": stride.value, "flat_depth": flat.value, "packed_depth": packed.value, "index_bytes": size.value}
+

@@ -43,12 +43,25 @@ SIGNATURES = {
     "msbwt_comm_init_rank": (_int, [C.POINTER(C.c_void_p), _int, _vp, _int]),
     "msbwt_comm_destroy": (_int, [_vp]),
     "msbwt_rle_allgather_counts": (_int, [_vp, _vp, _vp, _sz, _vp, _int, _vp]),
+    "msbwt_kmers_pack_2bit": (_int, [_vp, _sz, _sz, _vp]),
+    "msbwt_rle_count_kmers_packed": (_int, [_vp, _vp, _sz, _sz, _vp, _int]),
+    "msbwt_rle_count_kmers_packed_device": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "msbwt_rle_set_batch_order": (_int, [_vp, _int]),
+    "msbwt_rle_get_batch_order": (_int, [_vp]),
+    "msbwt_rle_batch_order_for": (_int, [_vp, _sz, _sz]),
     "msbwt_kmer_order_keys": (_int, [_vp, _sz, _sz, _vp]),
     "msbwt_rle_kmer_order_keys_device": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "msbwt_rle_set_table_depth": (_int, [_vp, _int]),
     "msbwt_rle_get_table_depth": (_int, [_vp]),
     "msbwt_rle_set_table_packed": (_int, [_vp, _int]),
     "msbwt_rle_get_table_packed": (_int, [_vp]),
+    "msbwt_rle_set_memory_budget": (_int, [_vp, _u64]),
+    "msbwt_rle_get_memory_budget": (_u64, [_vp]),
+    "msbwt_auto_index_plan": (_int, [_u64, _u64, _u64, C.c_double, _u64, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _pu64]),
+    "msbwt_rle_set_table_side": (_int, [_vp, _int]),
+    "msbwt_rle_table_info": (_int, [_vp, _pu64, _pu64, _pu64]),
+    "msbwt_rle_set_search_counters": (_int, [_vp, _int]),
+    "msbwt_rle_search_counters": (_int, [_vp, _vp, _vp]),
     "msbwt_rle_set_presence_filter": (_int, [_vp, _int]),
     "msbwt_rle_get_presence_filter": (_int, [_vp]),
     "msbwt_rle_set_block_format": (_int, [_vp, _int]),

@@ -51,6 +51,11 @@ struct msbwt_rle {
     int table_depth = 0;         // symbols a table entry stands for (of the table currently in HBM)
     bool table_packed = false;   // packed lines (two levels deeper than the flat table it was made from)
     size_t table_bytes = 0;
+    void *d_table_side = nullptr;    // packed table: flat entries of its escape lines (512 bytes per line), or nullptr
+    uint64_t table_side_bytes = 0;
+    uint64_t table_lines = 0, table_escape_lines = 0;  // of the packed table in HBM
+    int wanted_table_side = 1;       // 0 = no side array (queries of escape lines search from scratch, as until round 3)
+    bool counting = false;           // search counters wanted (msbwt_rle_set_search_counters)
     int wanted_table_packed = -1; // -1 = pack when the data warrants it and it fits, 0 = never, 1 = whenever a pair index exists
     uint32_t *d_filter = nullptr;   // presence bits over the low 2*filter_depth index bits of the table
     int filter_depth = 0;
@@ -65,7 +70,14 @@ struct msbwt_rle {
         hipEvent_t done = nullptr;
         bool used = false;  // `done` has been recorded at least once
         hipStream_t last_stream = nullptr;  // the stream of the launch that used it last
+        void *order_scratch = nullptr;      // scratch of the batch-ordering pass (order.hip) of the launch that holds the slot
+        size_t order_bytes = 0;
     };
+    uint64_t memory_budget = 0;  // bytes of HBM the index may hold (0 = no budget): msbwt_rle_set_memory_budget
+    bool planned = false;        // a budget is in force: `plan` (table_policy.hpp, plan_index) decides the optional structures
+    IndexPlan plan{};
+    int wanted_order = -1;   // batch order: -1 = automatic (dense batches on large indexes), 0 = never, 1 = whenever possible
+    int order_bits = 22;     // key bits the bucket pass orders by (10 in the global pass + 12 inside each bucket)
     std::vector<TicketSlot> tickets;
     // device status block (128 bytes): word 0 = flags of the host-pointer entry points (handle
     // stream), word 1 = flags of the *_device entry points (caller streams; read and cleared only by
@@ -94,7 +106,10 @@ struct msbwt_rle {
 namespace {
 
 constexpr int kMaxTableDepth = 16;  // 4^16 x 16 B = 64 GiB
-constexpr size_t kStatusBytes = 1024;  // flag words, debug record (bytes 64..128)
+constexpr size_t kStatusBytes = 1024;  // flag words, debug record (bytes 64..128), search counters (bytes 128..256)
+constexpr size_t kCountersOffset = 128;
+static_assert(MSBWT_SEARCH_COUNTERS == kSearchCounters, "the header's counter block is the kernels'");
+constexpr size_t kPackScratchOffset = 256;  // two u64 of the table packer (escape-line count, side-array cursor)
 constexpr size_t kMaxTimedEvents = 256;  // start/stop pairs kept before timed_launch folds them into the running sum
 constexpr int kHostFlags = 0, kDeviceFlags = 1;  // words of the status block
 
@@ -145,6 +160,9 @@ void release_index(msbwt_rle *h) {
     h->d_overflow = nullptr;
     h->overflow_bytes = 0;
     if (h->d_table) (void)hipFree(h->d_table);
+    if (h->d_table_side) (void)hipFree(h->d_table_side);
+    h->d_table_side = nullptr;
+    h->table_side_bytes = h->table_lines = h->table_escape_lines = 0;
     if (h->d_filter) (void)hipFree(h->d_filter);
     h->d_filter = nullptr;
     h->filter_depth = 0;
@@ -173,6 +191,8 @@ IndexView view_of(msbwt_rle *h) {
     v.table.packed = h->d_table && h->table_packed;
     v.table.filter = h->d_table ? h->d_filter : nullptr;
     v.table.filter_depth = h->filter_depth;
+    v.table.side = (h->d_table && h->table_packed) ? h->d_table_side : nullptr;
+    v.counters = (h->counting && h->d_flags) ? reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(h->d_flags) + kCountersOffset) : nullptr;
     v.pair_blocks = h->d_pair_blocks;
     v.pair_super = static_cast<const uint64_t *>(h->d_pair_super);
     v.pair_stride96 = h->d_pair_blocks && h->pair_stride == 96;
@@ -184,7 +204,7 @@ IndexView view_of(msbwt_rle *h) {
 // Runs `launch(view)` with a ticket-counter block that no launch still in flight uses, and marks the block busy
 // until everything enqueued on `stream` so far -- the launch included -- has completed.  The caller holds h->mu.
 template <class Launch>
-hipError_t with_tickets(msbwt_rle *h, hipStream_t stream, Launch &&launch) {
+hipError_t with_slot(msbwt_rle *h, hipStream_t stream, Launch &&launch) {
     // Launches queued back to back on ONE stream are ordered by the stream itself (the memset of the counters waits for the
     // previous kernel), so they share a block without asking its event: a caller that enqueues N asynchronous launches
     // gets one block, not N allocations inside its launch path.
@@ -210,12 +230,17 @@ hipError_t with_tickets(msbwt_rle *h, hipStream_t stream, Launch &&launch) {
     }
     IndexView v = view_of(h);
     v.tile_counter = slot->counters;
-    hipError_t e = launch(v);
+    hipError_t e = launch(v, *slot);
     // recorded even after a failed launch: the memset of the counters may already be queued
     const hipError_t r = hipEventRecord(slot->done, stream);
     slot->used = true;
     slot->last_stream = stream;
     return e != hipSuccess ? e : r;
+}
+
+template <class Launch>
+hipError_t with_tickets(msbwt_rle *h, hipStream_t stream, Launch &&launch) {
+    return with_slot(h, stream, [&](const IndexView &v, msbwt_rle::TicketSlot &) { return launch(v); });
 }
 
 int ensure_runtime(msbwt_rle *h) {
@@ -302,12 +327,18 @@ int rebuild_table(msbwt_rle *h) {
     h->table_depth = 0;
     h->table_packed = false;
     h->table_bytes = 0;
+    if (h->d_table_side) (void)hipFree(h->d_table_side);
+    h->d_table_side = nullptr;
+    h->table_side_bytes = h->table_lines = h->table_escape_lines = 0;
     // Automatic depths come from ONE decision (table_policy.hpp, pinned by a CPU test through
     // msbwt_auto_table_depths): beside a pair index the flat table is built as deep as the packed one needs.
     const bool automatic = h->wanted_table_depth < 0;
     int depth = h->wanted_table_depth;
     bool pack = h->d_pair_blocks != nullptr && h->wanted_table_packed > 0;  // an explicit depth is packed only on request
-    if (automatic) {
+    if (automatic && h->planned) {  // a memory budget is in force: the plan has sized the table (table_policy.hpp, plan_index)
+        depth = h->plan.flat;
+        pack = h->plan.packed != 0 && h->d_pair_blocks != nullptr && h->wanted_table_packed != 0;
+    } else if (automatic) {
         size_t free_b = 0, total_b = 0;
         const bool know_free = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
         // the table budgets against DISJOINT pair blocks: what overlapping ones take on top was checked against the
@@ -342,13 +373,31 @@ int rebuild_table(msbwt_rle *h) {
     // blocks).  Needs the pair index.
     const uint64_t pbytes = packed_table_bytes(depth + 2);
     void *packed = nullptr;
+    unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(h->d_flags) + kPackScratchOffset);  // [0] escape lines, [1] side cursor
+    unsigned long long escapes = 0;
     hipError_t e = hipMalloc(&packed, pbytes);
-    if (e == hipSuccess) e = launch_pack_table(view_of(h), depth, h->d_table, packed, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 16, h->stream);
+    if (e == hipSuccess) e = launch_pack_table(view_of(h), depth, h->d_table, packed, d_cnt, nullptr, nullptr, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&escapes, d_cnt, sizeof escapes, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    // Escape lines (some delta beyond 16 bits: the suffixes of high-copy repeats) get their ranges as flat entries in a side
+    // array, 512 bytes per line, filled by a second pass over those lines only.  Optional: without it (no memory, or
+    // MSBWT_TABLE_SIDE=0) their queries search from scratch.
+    void *side = nullptr;
+    if (e == hipSuccess && escapes > 0 && h->wanted_table_side != 0) {
+        if (hipMalloc(&side, size_t(escapes) * 512) != hipSuccess) {
+            (void)hipGetLastError();
+            side = nullptr;
+        } else {
+            e = launch_pack_table(view_of(h), depth, h->d_table, packed, nullptr, side, d_cnt + 1, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        }
+    }
     if (e != hipSuccess) {
+        if (side) (void)hipFree(side);
         if (packed) (void)hipFree(packed);
         (void)hipGetLastError();
-        if (!automatic || h->wanted_table_packed > 0) return hip_fail(h, e, "pack suffix table");
+        if (!automatic || h->planned || h->wanted_table_packed > 0) return hip_fail(h, e, "pack suffix table");
         // optional structure: the handle keeps a flat table -- within the flat table's OWN budget, not the
         // deeper parent that was only meant to be packed away
         const int own = auto_flat_table_depth(h->totals.total, h->nblocks * kBlockBytes);
@@ -369,12 +418,27 @@ int rebuild_table(msbwt_rle *h) {
     h->table_depth = depth + 2;
     h->table_packed = true;
     h->table_bytes = pbytes;
+    h->d_table_side = side;
+    h->table_side_bytes = side ? uint64_t(escapes) * 512 : 0;
+    h->table_lines = pbytes / 128;
+    h->table_escape_lines = escapes;
     return MSBWT_OK;
 }
 
-// Pair index (two symbols per step, rank_ops.hpp): 1 byte/symbol on top of the plane blocks,
-// built on the device from them.  Default policy: build it when it fits in half of what is
-// still free in HBM after the blocks (it is a pure speed-for-memory trade).
+// A memory budget (msbwt_rle_set_memory_budget) turns the automatic choices into ONE plan, made once the plane blocks are in
+// HBM and the data have been probed (table_policy.hpp, plan_index: pair blocks, then the deepest packed table, then
+// overlapping pair blocks).  Run blocks have no optional structures but the flat table.
+void make_plan(msbwt_rle *h) {
+    h->planned = false;
+    if (h->memory_budget == 0 || h->block_format != kBlocksPlanes) return;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+    const PairIndexSizes wide = pair_index_sizes(h->nblocks, 96), narrow = pair_index_sizes(h->nblocks, 128);
+    h->plan = plan_index(h->totals.total, free_b, total_b, h->typical_width, h->memory_budget, narrow.pair_block_bytes + narrow.super_bytes,
+                         wide.pair_block_bytes + wide.super_bytes);
+    h->planned = true;
+}
+
 // How wide is the range of a k-mer that occurs?  (kernels.hpp, launch_probe_widths: the median over a few thousand
 // sampled 24-mers; -1 when it cannot be told.)  Cheap: microseconds of kernel time, one 32 KiB read-back.
 double probe_typical_width(msbwt_rle *h) {
@@ -414,7 +478,11 @@ int rebuild_pair_index(msbwt_rle *h) {
     const bool know_free = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
     int stride = h->wanted_pair_stride;
     bool by_data = false;
-    if (stride != 96 && stride != 128) {
+    if (h->planned && h->wanted_pair < 0 && !h->plan.pair) return MSBWT_OK;  // the memory budget has no room for pair blocks
+    if (h->planned && stride != 96 && stride != 128) {
+        stride = h->plan.stride;
+        by_data = true;  // (the plan has checked the fit)
+    } else if (stride != 96 && stride != 128) {
         const PairIndexSizes wide = pair_index_sizes(h->nblocks, 96), narrow = pair_index_sizes(h->nblocks, 128);
         const uint64_t bytes96 = wide.pair_block_bytes + wide.super_bytes + wide.scratch_bytes, bytes128 = narrow.pair_block_bytes + narrow.super_bytes;
         const uint64_t after128 = uint64_t(free_b) > bytes128 ? uint64_t(free_b) - bytes128 : 0;
@@ -568,6 +636,7 @@ int install(msbwt_rle *h, const uint8_t *rle, size_t n) {
     h->loaded = true;
     stage(h->block_format == kBlocksRuns ? "run blocks (host build)" : "plane blocks", h->nblocks * kBlockBytes + h->overflow_bytes);
     h->typical_width = probe_typical_width(h);
+    make_plan(h);
     rc = rebuild_pair_index(h);  // first: the table may be packed with its help
     if (!rc) stage(h->pair_stride == 96 ? "pair blocks, stride 96" : "pair blocks, stride 128", h->pair_bytes);
     if (!rc) rc = rebuild_table(h);
@@ -665,10 +734,84 @@ int timed_launch(msbwt_rle *h, hipStream_t stream, Launch &&launch) {
     return MSBWT_OK;
 }
 
+// Batch order (order.hip): is this launch worth a bucket pass?  Mode 1: whenever the pass applies (lanes kernel on a pair
+// index, 12 <= k <= 64, 4096 <= n < 2^32).  Automatic: a DENSE batch -- at least two queries per 128 positions of the BWT, so
+// that queries ordered next to each other share index lines -- of at least 2^22 queries, on an index without a presence
+// filter (with one, the index is small and most random queries end in the filter: nothing to order for).  Measured: C4,
+// 10^8 read-derived 31-mers (6.6 per 128 positions) pays; the human-scale default batch (0.4) does not.
+bool order_pays(msbwt_rle *h, const IndexView &v, size_t k, size_t n) {
+    if (h->wanted_order == 0 || v.block_format != kBlocksPlanes || v.pair_blocks == nullptr) return false;
+    if (k < 12 || k > 64 || n < 4096 || n > 0xFFFFFFFFull || !lanes_serves(v, uint32_t(k))) return false;
+    if (h->wanted_order > 0) return true;
+    return n >= (size_t(1) << 22) && double(n) * 128.0 >= 2.0 * double(v.total) && v.table.filter == nullptr;
+}
+
+// grows the slot's ordering scratch; false = no memory for it (the launch then runs unordered)
+bool ensure_order_scratch(msbwt_rle::TicketSlot &slot, size_t bytes) {
+    if (bytes <= slot.order_bytes) return true;
+    if (slot.order_scratch) (void)hipFree(slot.order_scratch);  // (waits for the device: nothing still reads it)
+    slot.order_scratch = nullptr;
+    slot.order_bytes = 0;
+    if (hipMalloc(&slot.order_scratch, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        slot.order_scratch = nullptr;
+        return false;
+    }
+    slot.order_bytes = bytes;
+    return true;
+}
+
+uint32_t order_reach(const IndexView &v, size_t k) {  // the symbols the bucket key reads: the table's own index, else 17
+    const uint32_t depth = (v.table.entries && v.table.depth > 0 && size_t(v.table.depth) <= k) ? uint32_t(v.table.depth) : 17u;
+    return uint32_t(std::min<size_t>(depth, k));
+}
+
 int launch_count(msbwt_rle *h, const uint8_t *d_kmers, size_t k, size_t n, uint64_t *d_out, hipStream_t stream, int which) {
     if (k > 0xFFFFFFFFull) return fail(h, MSBWT_ERR_INVALID_ARG, "k does not fit 32 bits");
     return timed_launch(h, stream, [&] {
-        return with_tickets(h, stream, [&](const IndexView &v) { return launch_count_kmers(v, d_kmers, uint32_t(k), n, d_out, h->d_flags + which, stream); });
+        return with_slot(h, stream, [&](const IndexView &v, msbwt_rle::TicketSlot &slot) {
+            if (order_pays(h, v, k, n)) {
+                const OrderPlan plan = plan_order(n, uint32_t(k), order_reach(v, k), uint32_t(h->order_bits), true);
+                if (ensure_order_scratch(slot, plan.scratch_bytes)) {
+                    const uint64_t *ordered = nullptr;
+                    const uint32_t *index = nullptr;
+                    hipError_t e = launch_order_batch(plan, d_kmers, nullptr, slot.order_scratch, stream, &ordered, &index);
+                    if (e == hipSuccess) e = launch_count_packed(v, ordered, uint32_t(k), n, d_out, index, h->d_flags + which, stream);
+                    if (e == hipSuccess) e = launch_count_exceptions(plan, v.blocks, v.total, d_kmers, slot.order_scratch, d_out, h->d_flags + which, stream);
+                    return e;
+                }
+            }
+            return launch_count_kmers(v, d_kmers, uint32_t(k), n, d_out, h->d_flags + which, stream);
+        });
+    });
+}
+
+// the same for queries handed over as 2-bit words (include/msbwt_hip.h, msbwt_rle_count_kmers_packed_device)
+int launch_count_2bit(msbwt_rle *h, const uint64_t *d_packed, size_t k, size_t n, uint64_t *d_out, hipStream_t stream, int which) {
+    if (k < 1 || k > 64) return fail(h, MSBWT_ERR_INVALID_ARG, "packed queries need 1 <= k <= 64");
+    if (reinterpret_cast<uintptr_t>(d_packed) & 7u) return fail(h, MSBWT_ERR_INVALID_ARG, "packed queries must be 8-byte aligned");
+    return timed_launch(h, stream, [&] {
+        return with_slot(h, stream, [&](const IndexView &v, msbwt_rle::TicketSlot &slot) {
+            if (v.block_format != kBlocksPlanes) {  // run blocks: no kernel reads 2-bit words; unpack into rows first
+                const size_t row_bytes = (n * k + 255) / 256 * 256;
+                if (!ensure_order_scratch(slot, row_bytes)) return hipErrorOutOfMemory;
+                uint8_t *rows = static_cast<uint8_t *>(slot.order_scratch);
+                hipError_t e = launch_unpack_rows(d_packed, uint32_t(k), n, rows, stream);
+                if (e == hipSuccess) e = launch_count_kmers(v, rows, uint32_t(k), n, d_out, h->d_flags + which, stream);
+                return e;
+            }
+            if (order_pays(h, v, k, n)) {
+                const OrderPlan plan = plan_order(n, uint32_t(k), order_reach(v, k), uint32_t(h->order_bits), false);
+                if (ensure_order_scratch(slot, plan.scratch_bytes)) {
+                    const uint64_t *ordered = nullptr;
+                    const uint32_t *index = nullptr;
+                    hipError_t e = launch_order_batch(plan, nullptr, d_packed, slot.order_scratch, stream, &ordered, &index);
+                    if (e == hipSuccess) e = launch_count_packed(v, ordered, uint32_t(k), n, d_out, index, h->d_flags + which, stream);
+                    return e;
+                }
+            }
+            return launch_count_packed(v, d_packed, uint32_t(k), n, d_out, nullptr, h->d_flags + which, stream);
+        });
     });
 }
 
@@ -686,10 +829,14 @@ msbwt_rle *msbwt_rle_new_on_device(uint8_t bin_power, int device) {
     h->device = device;
     if (const char *env = std::getenv("MSBWT_TABLE_DEPTH")) h->wanted_table_depth = std::max(-1, std::min(std::atoi(env), kMaxTableDepth));
     if (const char *env = std::getenv("MSBWT_TABLE_PACKED")) h->wanted_table_packed = std::atoi(env) ? 1 : 0;
+    if (const char *env = std::getenv("MSBWT_TABLE_SIDE")) h->wanted_table_side = std::atoi(env) ? 1 : 0;
     if (const char *env = std::getenv("MSBWT_PAIR_INDEX")) h->wanted_pair = std::atoi(env) ? 1 : 0;
     if (const char *env = std::getenv("MSBWT_PAIR_STRIDE")) h->wanted_pair_stride = std::atoi(env);
     if (const char *env = std::getenv("MSBWT_FILTER")) h->wanted_filter = std::atoi(env) ? -1 : 0;
     if (const char *env = std::getenv("MSBWT_BLOCKS")) h->wanted_block_format = std::strcmp(env, "runs") == 0 ? kBlocksRuns : kBlocksPlanes;
+    if (const char *env = std::getenv("MSBWT_MEMORY_BUDGET")) h->memory_budget = std::strtoull(env, nullptr, 10);
+    if (const char *env = std::getenv("MSBWT_ORDER")) h->wanted_order = std::strcmp(env, "auto") == 0 ? -1 : (std::atoi(env) ? 1 : 0);
+    if (const char *env = std::getenv("MSBWT_ORDER_BITS")) h->order_bits = std::max(1, std::min(std::atoi(env), 36));
     if (const char *env = std::getenv("MSBWT_SEARCH"))
         h->search_kernel = std::strcmp(env, "groups") == 0 ? kSearchGroups : std::strcmp(env, "lanes") == 0 ? kSearchLanes : kSearchAuto;
     return h;
@@ -706,6 +853,7 @@ void msbwt_rle_free(msbwt_rle *h) {
         for (auto &t : h->tickets) {
             if (t.done) (void)hipEventDestroy(t.done);
             if (t.counters) (void)hipFree(t.counters);
+            if (t.order_scratch) (void)hipFree(t.order_scratch);
         }
         h->pipe.release();
         if (h->mail) (void)hipHostFree(h->mail);
@@ -754,6 +902,86 @@ int msbwt_rle_count_kmers_device(const msbwt_rle *ch, const void *d_kmers, size_
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
     return launch_count(h, static_cast<const uint8_t *>(d_kmers), k, n, static_cast<uint64_t *>(d_out_counts),
                         static_cast<hipStream_t>(hip_stream), kDeviceFlags);
+}
+
+int msbwt_rle_count_kmers_packed_device(const msbwt_rle *ch, const void *d_kmers2bit, size_t k, size_t n, void *d_out_counts, void *hip_stream) {
+    msbwt_rle *h = const_cast<msbwt_rle *>(ch);
+    if (!h) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!h->loaded) return fail(h, MSBWT_ERR_NOT_LOADED, "no BWT loaded");
+    if (n && (!d_out_counts || !d_kmers2bit)) return fail(h, MSBWT_ERR_INVALID_ARG, "null device pointer");
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    if (n == 0) return MSBWT_OK;
+    return launch_count_2bit(h, static_cast<const uint64_t *>(d_kmers2bit), k, n, static_cast<uint64_t *>(d_out_counts), static_cast<hipStream_t>(hip_stream),
+                             kDeviceFlags);
+}
+
+int msbwt_rle_count_kmers_packed(const msbwt_rle *ch, const uint64_t *kmers2bit, size_t k, size_t n, void *out_counts, int count_bits) {
+    msbwt_rle *h = const_cast<msbwt_rle *>(ch);
+    if (!h) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!h->loaded) return fail(h, MSBWT_ERR_NOT_LOADED, "no BWT loaded");
+    if (k < 1 || k > 64 || (count_bits != 64 && count_bits != 32)) return fail(h, MSBWT_ERR_INVALID_ARG, "packed queries need 1 <= k <= 64 and 64- or 32-bit counts");
+    if (n && (!out_counts || !kmers2bit)) return fail(h, MSBWT_ERR_INVALID_ARG, "null pointer");
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    if (n == 0) return MSBWT_OK;
+    int rc = ensure_runtime(h);
+    if (rc) return rc;
+    // pipelined like msbwt_rle_count_kmers: 8 (16) bytes per query in, 8 or 4 out; the 32-bit form counts into a device
+    // buffer and narrows on the kernels' stream (a count beyond 32 bits is reported, not truncated silently)
+    const size_t words = k > 32 ? 2 : 1, chunk = size_t(1) << 22;
+    if (count_bits == 32 && (rc = ensure_stage(h, std::min(n, chunk) * sizeof(uint64_t))) != MSBWT_OK) return rc;
+    std::vector<HostArray> ins(1), outs(1);
+    ins[0].in = kmers2bit;
+    ins[0].item_bytes = words * sizeof(uint64_t);
+    outs[0].out = out_counts;
+    outs[0].item_bytes = size_t(count_bits / 8);
+    int launch_rc = MSBWT_OK;
+    const hipError_t e = h->pipe.run(n, chunk, ins, outs, h->stream,
+                                     [&](size_t, size_t m, void *const *d_in, void *const *d_out, hipStream_t stream) -> hipError_t {
+                                         uint64_t *d_counts = count_bits == 64 ? static_cast<uint64_t *>(d_out[0]) : static_cast<uint64_t *>(h->d_stage);
+                                         launch_rc = launch_count_2bit(h, static_cast<const uint64_t *>(d_in[0]), k, m, d_counts, stream, kHostFlags);
+                                         if (launch_rc) return hipErrorUnknown;
+                                         return count_bits == 64 ? hipSuccess : launch_narrow_counts32(d_counts, static_cast<uint32_t *>(d_out[0]), m, h->d_flags + kHostFlags, stream);
+                                     });
+    if (launch_rc) return launch_rc;
+    if (e != hipSuccess) return hip_fail(h, e, "count_kmers_packed pipeline");
+    uint32_t flags = 0;
+    rc = read_flags(h, h->stream, kHostFlags, &flags);
+    return rc ? rc : flags_to_code(h, flags);
+}
+
+int msbwt_kmers_pack_2bit(const uint8_t *kmers, size_t k, size_t n, uint64_t *out_words) {
+    if (k < 1 || k > 64 || (n && (!kmers || !out_words))) return MSBWT_ERR_INVALID_ARG;
+    const size_t words = k > 32 ? 2 : 1;
+    for (size_t q = 0; q < n; ++q) {
+        uint64_t w[2] = {0, 0};
+        for (size_t t = 0; t < k; ++t) {  // step t = symbol k-1-t, two bits each from bit 0 of word 0 up
+            const uint8_t s = kmers[q * k + k - 1 - t];
+            if (s != 1 && s != 2 && s != 3 && s != 5) return MSBWT_ERR_INVALID_SYMBOL;
+            w[t >> 5] |= uint64_t(s - 1 - (s >> 2)) << (2 * (t & 31));
+        }
+        for (size_t i = 0; i < words; ++i) out_words[q * words + i] = w[i];
+    }
+    return MSBWT_OK;
+}
+
+int msbwt_rle_set_batch_order(msbwt_rle *h, int mode) {
+    if (!h || mode < -1 || mode > 1) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->wanted_order = mode;
+    return MSBWT_OK;
+}
+
+int msbwt_rle_get_batch_order(const msbwt_rle *h) { return h ? h->wanted_order : 0; }
+
+int msbwt_rle_batch_order_for(const msbwt_rle *ch, size_t k, size_t n) {
+    msbwt_rle *h = const_cast<msbwt_rle *>(ch);
+    if (!h || !h->loaded) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    return order_pays(h, view_of(h), k, n) ? 1 : 0;
 }
 
 int msbwt_rle_constrain_ranges_device(const msbwt_rle *ch, const void *d_syms, const void *d_l, const void *d_h,
@@ -1070,6 +1298,7 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
     if (!h) return nullptr;
     h->wanted_table_depth = src->wanted_table_depth;
     h->wanted_table_packed = src->wanted_table_packed;
+    h->wanted_table_side = src->wanted_table_side;
     h->wanted_block_format = src->wanted_block_format;
     h->block_format = src->block_format;
     h->wanted_pair = src->wanted_pair;
@@ -1077,6 +1306,11 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
     h->pair_stride = src->pair_stride;
     h->wanted_filter = src->wanted_filter;
     h->search_kernel = src->search_kernel;
+    h->wanted_order = src->wanted_order;
+    h->order_bits = src->order_bits;
+    h->memory_budget = src->memory_budget;
+    h->planned = src->planned;
+    h->plan = src->plan;
     auto give_up = [&](hipError_t e, const char *what) -> msbwt_rle * {
         hip_fail(src, e, what);
         msbwt_rle_free(h);
@@ -1102,6 +1336,7 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
         {&src->d_blocks, &h->d_blocks, size_t(src->nblocks) * kBlockBytes},
         {&src->d_overflow, &h->d_overflow, src->d_overflow ? size_t(src->overflow_bytes) : 0},
         {&src->d_table, &h->d_table, src->d_table ? src->table_bytes : 0},
+        {&src->d_table_side, &h->d_table_side, src->d_table_side ? size_t(src->table_side_bytes) : 0},
         {reinterpret_cast<void *const *>(&src->d_filter), reinterpret_cast<void **>(&h->d_filter), src->d_filter ? (size_t(1) << (2 * src->filter_depth)) / 8 : 0},
         {&src->d_pair_blocks, &h->d_pair_blocks, src->d_pair_blocks ? psz.pair_block_bytes : 0},
         {&src->d_pair_super, &h->d_pair_super, src->d_pair_super ? psz.super_bytes : 0},
@@ -1120,6 +1355,9 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
     h->table_depth = src->table_depth;
     h->table_packed = src->table_packed;
     h->table_bytes = src->table_bytes;
+    h->table_side_bytes = src->table_side_bytes;
+    h->table_lines = src->table_lines;
+    h->table_escape_lines = src->table_escape_lines;
     h->typical_width = src->typical_width;
     h->pair_overlap_bytes = src->pair_overlap_bytes;
     h->filter_depth = src->filter_depth;
@@ -1368,6 +1606,91 @@ int msbwt_rle_set_table_packed(msbwt_rle *h, int mode) {
 
 int msbwt_rle_get_table_packed(const msbwt_rle *h) { return (h && h->d_table && h->table_packed) ? 1 : 0; }
 
+int msbwt_rle_set_memory_budget(msbwt_rle *h, uint64_t bytes) {
+    if (!h) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->memory_budget = bytes;
+    if (!h->loaded) return MSBWT_OK;
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    // the optional structures are rebuilt under the new budget (the plan counts the memory they hold now as free)
+    if (h->d_table) (void)hipFree(h->d_table);
+    if (h->d_table_side) (void)hipFree(h->d_table_side);
+    if (h->d_filter) (void)hipFree(h->d_filter);
+    if (h->d_pair_blocks) (void)hipFree(h->d_pair_blocks);
+    if (h->d_pair_super) (void)hipFree(h->d_pair_super);
+    h->d_table = h->d_table_side = h->d_pair_blocks = h->d_pair_super = nullptr;
+    h->d_filter = nullptr;
+    h->filter_depth = 0;
+    h->table_depth = 0;
+    h->table_packed = false;
+    h->table_bytes = 0;
+    h->table_side_bytes = h->table_lines = h->table_escape_lines = 0;
+    h->pair_bytes = h->pair_overlap_bytes = 0;
+    make_plan(h);
+    const int rc = rebuild_pair_index(h);
+    return rc ? rc : rebuild_table(h);
+}
+
+uint64_t msbwt_rle_get_memory_budget(const msbwt_rle *h) { return h ? h->memory_budget : 0; }
+
+int msbwt_auto_index_plan(uint64_t total_symbols, uint64_t free_hbm_bytes, uint64_t hbm_total_bytes, double typical_width, uint64_t budget_bytes,
+                          int *pair_index, int *pair_stride, int *flat_depth, int *packed_depth, uint64_t *index_bytes) {
+    if (!pair_index || !pair_stride || !flat_depth || !packed_depth) return MSBWT_ERR_INVALID_ARG;
+    const uint64_t nblocks = plane_block_count(total_symbols);
+    const PairIndexSizes wide = pair_index_sizes(nblocks, 96), narrow = pair_index_sizes(nblocks, 128);
+    const IndexPlan p = plan_index(total_symbols, free_hbm_bytes, hbm_total_bytes, typical_width, budget_bytes, narrow.pair_block_bytes + narrow.super_bytes,
+                                   wide.pair_block_bytes + wide.super_bytes);
+    *pair_index = p.pair ? 1 : 0;
+    *pair_stride = p.pair ? p.stride : 0;
+    *flat_depth = p.flat;
+    *packed_depth = p.packed;
+    if (index_bytes) *index_bytes = p.bytes;
+    return MSBWT_OK;
+}
+
+int msbwt_rle_set_table_side(msbwt_rle *h, int mode) {
+    if (!h || mode < 0 || mode > 1) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->wanted_table_side = mode;
+    if (!h->loaded) return MSBWT_OK;
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    return rebuild_table(h);
+}
+
+int msbwt_rle_table_info(const msbwt_rle *h, uint64_t *lines, uint64_t *escape_lines, uint64_t *side_bytes) {
+    if (!h) return MSBWT_ERR_INVALID_ARG;
+    const bool packed = h->d_table && h->table_packed;
+    if (lines) *lines = packed ? h->table_lines : 0;
+    if (escape_lines) *escape_lines = packed ? h->table_escape_lines : 0;
+    if (side_bytes) *side_bytes = packed ? h->table_side_bytes : 0;
+    return MSBWT_OK;
+}
+
+int msbwt_rle_set_search_counters(msbwt_rle *h, int enabled) {
+    if (!h) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->counting = enabled != 0;
+    return MSBWT_OK;
+}
+
+int msbwt_rle_search_counters(const msbwt_rle *ch, uint64_t *out, void *hip_stream) {
+    msbwt_rle *h = const_cast<msbwt_rle *>(ch);
+    if (!h || !out) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    std::memset(out, 0, MSBWT_SEARCH_COUNTERS * sizeof(uint64_t));
+    if (!h->d_flags) return MSBWT_OK;
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    char *d_counters = reinterpret_cast<char *>(h->d_flags) + kCountersOffset;
+    HIP_TRY(h, hipMemcpyAsync(out, d_counters, MSBWT_SEARCH_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(h, hipMemsetAsync(d_counters, 0, MSBWT_SEARCH_COUNTERS * sizeof(uint64_t), stream));
+    HIP_TRY(h, hipStreamSynchronize(stream));
+    return MSBWT_OK;
+}
+
 int msbwt_rle_get_presence_filter(const msbwt_rle *h) { return (h && h->d_filter) ? h->filter_depth : 0; }
 
 int msbwt_rle_set_block_format(msbwt_rle *h, int format) {
@@ -1419,7 +1742,7 @@ int msbwt_rle_search_kernel_for(const msbwt_rle *h, size_t k) {
 
 uint64_t msbwt_rle_device_bytes(const msbwt_rle *h) {
     if (!h || !h->loaded) return 0;
-    return h->nblocks * kBlockBytes + h->overflow_bytes + (h->d_table ? uint64_t(h->table_bytes) : 0) + h->pair_bytes +
+    return h->nblocks * kBlockBytes + h->overflow_bytes + (h->d_table ? uint64_t(h->table_bytes) + h->table_side_bytes : 0) + h->pair_bytes +
            (h->d_filter ? (uint64_t(1) << (2 * h->filter_depth)) / 8 : 0);
 }
 

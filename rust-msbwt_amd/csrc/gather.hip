@@ -93,6 +93,12 @@ uint32_t copy_grid(uint64_t n) { return uint32_t(std::min<uint64_t>(256 * 8, std
 
 }  // namespace
 
+hipError_t launch_narrow_counts32(const uint64_t *d_in, uint32_t *d_out, uint64_t n, uint32_t *flags, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL((k_narrow_counts<uint32_t>), dim3(copy_grid(n)), dim3(256), 0, stream, d_in, d_out, n, flags);
+    return hipGetLastError();
+}
+
 bool rccl_available(std::string *why) {
     const Rccl &r = rccl();
     if (why) *why = r.why;

@@ -75,7 +75,7 @@ template <bool kReads, int kWords>
 __global__ __launch_bounds__(256, kWords == 6 ? 4 : 6) void k_count_kmers_tiled(
     const uint4 *__restrict__ blocks, uint32_t format, const uint4 *__restrict__ overflow, uint64_t total,
     const uint4 *__restrict__ table, uint32_t depth, uint32_t table_packed, const uint32_t *__restrict__ filter,
-    uint32_t filter_mask, const QuerySource src, uint32_t *__restrict__ flags) {
+    uint32_t filter_mask, const uint4 *__restrict__ table_side, const QuerySource src, uint32_t *__restrict__ flags) {
     constexpr int kLanes = kGroup;
     using Scratch = WaveScratchT<kWords>;
     using WorkItem = WorkItemT<kWords>;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, kWords == 6 ? 4 : 6) void k_count_kmers_tiled(
     const uint64_t nwaves = uint64_t(gridDim.x) * kWavesPerBlock;
     const bool use_table = table != nullptr && depth > 0 && k >= depth;
 
-    const TableEnv env{table, depth, use_table, table_packed != 0u, filter, filter_mask, total};
+    const TableEnv env{table, depth, use_table, table_packed != 0u, filter, filter_mask, total, table_side};
     // A tile is at most 64 x kMaxK bytes = kPieces pieces per lane, all loads in flight at once.
     // For k <= 32 the loads of the NEXT tile are issued before the current tile is searched, hiding
     // their latency; the k <= 64 variant has no registers to spare for that and loads at the top
@@ -301,7 +301,11 @@ __device__ __forceinline__ uint64_t pair_bound_thread(const uint4 *__restrict__ 
 // (t mod 4^flat_depth) by the two symbols in t's top four bits, t = 30 line + i.
 __global__ __launch_bounds__(256) void k_table_pack(const uint4 *__restrict__ flat, uint32_t flat_depth,
                                                     const uint4 *__restrict__ pair_blocks, const uint64_t *__restrict__ pair_super,
-                                                    uint32_t stride96, uint32_t *__restrict__ packed, uint64_t nlines) {
+                                                    uint32_t stride96, uint32_t *__restrict__ packed, uint64_t nlines,
+                                                    unsigned long long *__restrict__ escape_count, uint4 *__restrict__ side,
+                                                    unsigned long long *__restrict__ side_cursor) {
+    // Second pass (side != nullptr): only the lines the first pass marked ESCAPE are visited again; each takes the next
+    // free group of the side array, stores its 30 ranges there as flat {l, h} entries and names the group in its base word.
     const uint32_t lane = threadIdx.x & 63u, i = lane & 31u, team_first = lane & 32u;
     const uint64_t entries = 1ull << (2u * (flat_depth + 2u)), parent_mask = (1ull << (2u * flat_depth)) - 1ull;
     const uint64_t nteams = (uint64_t(gridDim.x) * blockDim.x) / 32;
@@ -309,6 +313,7 @@ __global__ __launch_bounds__(256) void k_table_pack(const uint4 *__restrict__ fl
         const uint64_t t = line * kPackedPerLine + i;
         const bool valid = i < kPackedPerLine && t < entries;
         uint64_t l = 0, h = 0;
+        if (side != nullptr && (packed[line * 32 + 1] & 0x80000000u) == 0u) continue;  // (team-uniform)
         if (valid) {
             const uint4 e = flat[t & parent_mask];
             l = (uint64_t(e.y) << 32) | e.x;
@@ -330,11 +335,25 @@ __global__ __launch_bounds__(256) void k_table_pack(const uint4 *__restrict__ fl
         const bool wide = dl > 0xFFFFull || w > 0xFFFFull;
         const bool escape = (uint32_t(__ballot(wide) >> team_first)) != 0u;
         uint32_t *out = packed + line * 32;
+        if (side != nullptr) {  // an escape line (see above): flat entries into its group of the side array
+            unsigned long long g = 0;
+            if (i == 30u) g = atomicAdd(side_cursor, 1ull);
+            const uint64_t group = (uint64_t(uint32_t(__shfl(int(uint32_t(g >> 32)), int(team_first) + 30))) << 32) |
+                                   uint32_t(__shfl(int(uint32_t(g)), int(team_first) + 30));
+            if (i < kPackedPerLine) side[group * kSidePerLine + i] = make_uint4(uint32_t(l), uint32_t(l >> 32), uint32_t(h), uint32_t(h >> 32));
+            if (i == 30u) {
+                const uint64_t b = kPackedEscape | group;
+                out[0] = uint32_t(b);
+                out[1] = uint32_t(b >> 32);
+            }
+            continue;
+        }
         if (i < kPackedPerLine) out[2u + i] = uint32_t(dl & 0xFFFFu) | (uint32_t(w & 0xFFFFu) << 16);
         if (i == 30u) {
             const uint64_t b = (mine32 ? base : 0ull) | (escape ? kPackedEscape : 0ull);
             out[0] = uint32_t(b);
             out[1] = uint32_t(b >> 32);
+            if (escape && escape_count != nullptr) atomicAdd(escape_count, 1ull);
         }
     }
 }
@@ -432,10 +451,11 @@ void launch_tiled(bool longk, dim3 grid, hipStream_t stream, const IndexView &ix
     const uint32_t filter_mask = filter ? uint32_t((1ull << (2 * ix.table.filter_depth)) - 1ull) : 0u;
     const uint32_t packed = ix.table.packed ? 1u : 0u, format = uint32_t(ix.block_format);
     const uint4 *overflow = static_cast<const uint4 *>(ix.overflow);
+    const uint4 *side = table ? static_cast<const uint4 *>(ix.table.side) : nullptr;
     if (longk)  // 33 <= k <= 64
-        hipLaunchKernelGGL((k_count_kmers_tiled<kReads, 6>), grid, dim3(256), 0, stream, blocks, format, overflow, ix.total, table, depth, packed, filter, filter_mask, src, flags);
+        hipLaunchKernelGGL((k_count_kmers_tiled<kReads, 6>), grid, dim3(256), 0, stream, blocks, format, overflow, ix.total, table, depth, packed, filter, filter_mask, side, src, flags);
     else
-        hipLaunchKernelGGL((k_count_kmers_tiled<kReads, 3>), grid, dim3(256), 0, stream, blocks, format, overflow, ix.total, table, depth, packed, filter, filter_mask, src, flags);
+        hipLaunchKernelGGL((k_count_kmers_tiled<kReads, 3>), grid, dim3(256), 0, stream, blocks, format, overflow, ix.total, table, depth, packed, filter, filter_mask, side, src, flags);
 }
 
 }  // namespace
@@ -471,6 +491,24 @@ hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_
                            static_cast<const uint4 *>(ix.overflow), ix.total, kmers, k, n, counts, flags);
     }
     return hipGetLastError();
+}
+
+hipError_t launch_count_packed(const IndexView &ix, const uint64_t *packed, uint32_t k, uint64_t n, uint64_t *counts,
+                               const uint32_t *out_index, uint32_t *flags, hipStream_t stream) {
+    if (k < 1 || k > uint32_t(kMaxTiledK) || ix.block_format != kBlocksPlanes || (out_index != nullptr && n > 0xFFFFFFFFull)) return hipErrorInvalidValue;
+    if (n == 0) return hipSuccess;
+    QuerySource src{};
+    src.data = reinterpret_cast<const uint8_t *>(packed);
+    src.n = n;
+    src.k = k;
+    src.out_fwd = counts;
+    src.packed = 1;
+    src.out_index = out_index;
+    if (out_index != nullptr) {
+        static const uint32_t mode = [] { const char *e = std::getenv("MSBWT_PLACED_STORE"); return e ? uint32_t(std::atoi(e)) : 0u; }();
+        src.placed_store = mode;
+    }
+    return launch_lanes(ix, src, false, true, flags, stream);
 }
 
 hipError_t launch_count_read_kmers(const IndexView &ix, const uint8_t *reads, uint32_t read_len, uint64_t n_reads,
@@ -543,12 +581,12 @@ hipError_t launch_build_table(const IndexView &ix, int depth, void *entries, hip
 }
 
 hipError_t launch_pack_table(const IndexView &ix, int flat_depth, const void *flat_entries, void *packed_entries,
-                             hipStream_t stream) {
-    if (flat_depth < 1 || flat_depth > 16 || !ix.pair_blocks || !ix.pair_super) return hipErrorInvalidValue;
+                             unsigned long long *escape_count, void *side, unsigned long long *side_cursor, hipStream_t stream) {
+    if (flat_depth < 1 || flat_depth > 16 || !ix.pair_blocks || !ix.pair_super || (side && !side_cursor)) return hipErrorInvalidValue;
     const uint64_t nlines = packed_table_bytes(flat_depth + 2) / 128;
     hipLaunchKernelGGL(k_table_pack, dim3(grid_for(nlines * 32)), dim3(256), 0, stream, static_cast<const uint4 *>(flat_entries),
                        uint32_t(flat_depth), static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, ix.pair_stride96 ? 1u : 0u,
-                       static_cast<uint32_t *>(packed_entries), nlines);
+                       static_cast<uint32_t *>(packed_entries), nlines, escape_count, static_cast<uint4 *>(side), side_cursor);
     return hipGetLastError();
 }
 

@@ -23,6 +23,10 @@ struct TableView {
     // random table line.  nullptr = none.
     const uint32_t *filter = nullptr;
     int filter_depth = 0;
+    // packed tables: the ranges of the lines whose deltas do not fit 16 bits (high-copy repeats), 32 flat 16-byte
+    // {l, h} entries (30 used) per escaped line; the line's base word names its group.  nullptr = queries of an
+    // escaped line search from scratch.
+    const void *side = nullptr;
 };
 
 // which count_kmers kernel serves 1 <= k <= 64 (kernels.hip / lanes.hip)
@@ -53,6 +57,24 @@ struct IndexView {
     // that a host may poll instead of synchronising the stream; nullptr = not wanted
     uint64_t *done = nullptr;
     uint64_t done_seq = 0;
+    // optional search counters of the lanes kernel (kSearchCounters u64, added to by every wave): what a batch did to
+    // the index -- steps, second lines, escape lines ... (msbwt_rle_search_counters); nullptr = not wanted
+    uint64_t *counters = nullptr;
+};
+
+// indices into IndexView::counters
+enum SearchCounter {
+    kCntWaveSteps = 0,     // search steps of a wave (each costs the same whether 5 or 64 lanes take it)
+    kCntLaneSteps,         // steps taken by a lane's query (pair, single-symbol or side-array fetch)
+    kCntPairSteps,         // ... of which consumed two symbols
+    kCntSecondLines,       // steps whose range needed a second line (l and h in different blocks)
+    kCntSatOut,            // lane-steps lost because the step's second-line slots were taken
+    kCntEscapeQueries,     // queries whose packed table line is an escape line
+    kCntEscapeRestarts,    // ... that searched from [0, total) because the table has no side array
+    kCntTableDecided,      // queries decided by the table or the presence filter alone
+    kCntSearched,          // queries that entered the search
+    kCntFirstLines,        // first-bound lines fetched (one per lane-step)
+    kSearchCounters = 16
 };
 
 // counts[q] = count_kmer(kmers[q*k .. q*k+k)) for q < n.  Sets kFlagInvalidSymbol in *flags
@@ -64,6 +86,11 @@ int search_kernel_for(const IndexView &ix, uint32_t k);
 // read from `kmers` (lanes kernel only: ask lanes_serves(ix, k) first).
 hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_t k, uint64_t n,
                               uint64_t *counts, uint32_t *flags, hipStream_t stream, const uint8_t *inline_kmer = nullptr);
+// The same for queries handed over as 2-bit words (n x ceil(k / 32) u64: the k-mer as a base-4 number, first symbol most
+// significant, A C G T -> 0..3; search_common.hpp, QuerySource::packed), 1 <= k <= 64, plane blocks: always the lanes
+// kernel.  out_index (optional, n < 2^32): query v's count goes to counts[out_index[v]] -- an ordered batch (order.hip).
+hipError_t launch_count_packed(const IndexView &ix, const uint64_t *packed, uint32_t k, uint64_t n, uint64_t *counts,
+                               const uint32_t *out_index, uint32_t *flags, hipStream_t stream);
 // true when a count_kmers launch for k-symbol queries runs the lanes kernel (the only one that knows ix.done / inline queries)
 bool lanes_serves(const IndexView &ix, uint32_t k);
 
@@ -92,8 +119,10 @@ hipError_t launch_build_table(const IndexView &ix, int depth, void *entries, hip
 // Packs a finished FLAT table of `flat_depth` levels into a PACKED table two levels deeper
 // (`packed_entries`: ceil(4^(flat_depth+2) / 30) lines of 128 bytes): every entry is extended by
 // one two-symbol step of the pair index (required).  Returns the packed size through the helper.
+// escape_count (device, zeroed by the caller): receives the number of escape lines.  A second call with `side` (that many
+// groups of 512 bytes) and `side_cursor` (device, zeroed) gives every escape line its group of flat entries.
 hipError_t launch_pack_table(const IndexView &ix, int flat_depth, const void *flat_entries, void *packed_entries,
-                             hipStream_t stream);
+                             unsigned long long *escape_count, void *side, unsigned long long *side_cursor, hipStream_t stream);
 // d_out[g] (g < nsamples) = number of occurrences of a `steps`-mer that is PRESENT in the index (an LF walk from a
 // pseudo-random row, searched as it is read off; 0 = the walk met '$' / 'N').  What the pair-stride policy reads
 // (table_policy.hpp).  Plane blocks only.

@@ -71,8 +71,10 @@ template <int kWords> constexpr int kRegionsFor = 10;
 template <int kWords>
 struct RingItemT {
     uint32_t l_lo, h_lo;
-    uint32_t meta;        // l >> 32 (8 bits) | h >> 32 (8 bits) << 8 | remaining steps << 16 | lane in the tile << 24
+    uint32_t meta;        // l >> 32 (8 bits) | h >> 32 (8 bits) << 8 | remaining steps << 16 | lane in the tile << 24 | escape << 31
+                          // (escape: the range is still to be fetched from the packed table's side array; l = its entry index)
     uint32_t w[kWords];   // remaining symbols, 3 bits each, next step in the low bits
+    uint32_t out;         // QuerySource::out_index given: where the count goes (else unused: tile and lane say it)
 };
 
 template <int kWords>
@@ -90,7 +92,8 @@ struct LaneScratchT {
     // symbol codes), and at the start of a step its first 640 bytes hold the step's line addresses: they
     // are in registers (s_waitcnt lgkmcnt(0)) before the first LDS-DMA load is issued.
     uint4 lines[(kRegions / 2) * 136];   // 10.6 KiB
-    RingItemT<kWords> ring[kRing];       // 1.5 or 2.25 KiB
+    RingItemT<kWords> ring[kRing];       // 1.75 or 2.5 KiB
+    uint32_t cnt[kSearchCounters];       // optional search counters of this wave (kernels.hpp): in LDS, so that they cost no registers
 };
 static_assert(sizeof(LaneScratchT<6>) <= 160 * 1024 / 12, "12 one-wave workgroups per CU");
 
@@ -176,11 +179,11 @@ template <bool kReads, bool kPair, int kWords, bool kStride96>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_count_kmers_lanes(const uint4 *__restrict__ blocks, uint64_t total,
                                                           const uint4 *__restrict__ table, uint32_t depth, uint32_t table_packed,
                                                           const uint32_t *__restrict__ filter, uint32_t filter_mask,
-                                                          const uint4 *__restrict__ pair_blocks,
+                                                          const uint4 *__restrict__ table_side, const uint4 *__restrict__ pair_blocks,
                                                           const uint64_t *__restrict__ pair_super, const QuerySource src,
                                                           uint32_t *__restrict__ flags, uint64_t *__restrict__ debug,
                                                           unsigned long long *__restrict__ tile_counter, uint32_t grain,
-                                                          uint64_t *__restrict__ done, uint64_t done_seq) {
+                                                          uint64_t *__restrict__ done, uint64_t done_seq, uint64_t *__restrict__ counters) {
     using Scratch = LaneScratchT<kWords>;
     using RingItem = RingItemT<kWords>;
     constexpr int kPieces = Scratch::kMaxK / 16;  // 16-byte pieces of a tile per lane: 2 or 4
@@ -194,7 +197,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     const uint8_t *stage_bytes = reinterpret_cast<const uint8_t *>(ws.lines) + kStageLead;  // pack_query reads in front of a query
     const uint64_t ntiles = (n + kTile - 1) / kTile;
     const bool use_table = table != nullptr && depth > 0 && k >= depth;
-    const TableEnv env{table, depth, use_table, table_packed != 0u, filter, filter_mask, total};
+    const TableEnv env{table, depth, use_table, table_packed != 0u, filter, filter_mask, total, table_side};
+    // optional search counters (kernels.hpp, SearchCounter): wave sums kept in LDS, added to the caller's block at the end
+    if (counters != nullptr && lane < uint32_t(kSearchCounters)) ws.cnt[lane] = 0u;
+    auto count = [&](int which, uint64_t ballot) {
+        if (lane == 0u) ws.cnt[which] += uint32_t(__popcll(ballot));
+    };
     // this lane's part in the line fetches: 16 bytes (one chunk) of the line in list slot 8 i + dma_group
     const uint32_t dma_group = lane >> 3, dma_chunk_bytes = ((lane & 7u) ^ dma_group) * 16u;
 
@@ -204,6 +212,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     // wave's first ticket is its own index; further ones come from one of kTicketCounters counters
     // (counter c of n hands out tickets W + c, W + c + n, ...: one address takes only ~7 x 10^7 atomics/s,
     // which would be most of a SHORT launch's time), taken one segment ahead so that nobody waits for them.
+    // Neighbouring tiles thus run at the same time on ALL eight XCDs.  Round 4 tried the opposite for ordered batches --
+    // eight contiguous spans of the launch, one per XCD (workgroups b and b + 8 share an L2), so that an XCD's waves work
+    // through ONE run of consecutive queries: C4, batch ordered by 24 key bits, 9.2 ms against 8.4 ms this way (12: 14.1
+    // against 14.4; unordered: the same) -- with interleaved tiles one XCD's miss is the other seven's Infinity Cache hit.
     const uint32_t ncounters = min(uint32_t(kTicketCounters), max(1u, gridDim.x >> 3));  // every counter in use has waves drawing from it
     const uint32_t my_counter = (blockIdx.x >> 3) % ncounters;  // consecutive workgroups sit on different XCDs
     uint64_t static_next = (uint64_t(blockIdx.x) + gridDim.x) * grain;  // tile_counter == nullptr (small launches: no memset, no atomics): static striding
@@ -236,9 +248,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
 
     // the lane's running query
     bool have = false;
+    bool esc = false;  // the query's range is still in the side array of the packed table: l = index of its entry there
     uint64_t l = 0, h = 0;
     uint32_t w[kWords], rem = 0;
-    uint64_t qid = 0;  // global index of the lane's query
+    uint64_t qid = 0;  // where the count of the lane's query goes (its global index, or its place by QuerySource::out_index)
 #pragma unroll
     for (int i = 0; i < kWords; ++i) w[i] = 0;
 
@@ -261,6 +274,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     const bool reads_fast = kReads && src.win_off == nullptr && src.windows >= tile_windows;
     const double inv_windows = kReads ? 1.0 / double(src.windows) : 0.0;
     uint32_t staged_n0 = 0;  // wave-uniform
+    uint32_t staged_out = 0, prep_out = 0;  // QuerySource::out_index: the output place of this lane's query of the fetched / the prepared tile
+    const bool placed = !kReads && src.out_index != nullptr;  // launch-uniform
+    auto place_of = [&](uint64_t v, uint32_t out) -> uint64_t { return placed ? uint64_t(out) : v; };
     auto fetch_tile_bytes = [&](uint64_t tile) {
         if (tile >= ntiles) return;
         if (!kReads) {
@@ -269,6 +285,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 return;
             }
             const uint64_t q0 = tile * kTile;
+            if (src.out_index != nullptr && q0 + lane < n) staged_out = src.out_index[q0 + lane];
+            if (src.packed != 0u) {  // this lane's own query: one or two u64 words, a tile is one coalesced load
+                if (q0 + lane < n) {
+                    const uint64_t *words = reinterpret_cast<const uint64_t *>(kmers) + (q0 + lane) * (kWords == 3 ? 1u : 2u);
+                    const uint2 a = *reinterpret_cast<const uint2 *>(words);
+                    staged_next[0].x = a.x;
+                    staged_next[0].y = a.y;
+                    if constexpr (kWords == 6) {
+                        const uint2 b = *reinterpret_cast<const uint2 *>(words + 1);
+                        staged_next[0].z = b.x;
+                        staged_next[0].w = b.y;
+                    }
+                }
+                return;
+            }
             const uint32_t nbytes = uint32_t(min(uint64_t(kTile), n - q0)) * k;
 #pragma unroll
             for (int i = 0; i < kPieces; ++i) staged_next[i] = load_piece(kmers + q0 * k, nbytes, lane + 64u * i);
@@ -306,25 +337,43 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
         if (prepared && ring_count == 0u) {
             uint64_t pl = 0, ph = total;
             uint32_t skip = 0;
-            if (prep_kind == 1u && table_decode(env, prep_entry, pl, ph)) skip = depth;
-            else { pl = 0; ph = total; }  // no table for this query (non-ACGT suffix, or an escape line)
+            bool escaped = false, restart = false;
+            if (prep_kind == 1u) {
+                if (table_decode(env, prep_entry, pl, ph)) {
+                    skip = depth;
+                } else if (table_side != nullptr) {  // an escape line: the range comes from the side array, as this query's first step
+                    escaped = true;
+                    skip = depth;
+                } else {  // no side array: from scratch
+                    restart = true;
+                    pl = 0;
+                    ph = total;
+                }
+            }
             const uint32_t prep_rem = k - skip;
             uint32_t prep_w[kWords];
             unpack_words<kWords>(prep_q, skip, prep_w);
             bool pending = prep_kind != 0u;
-            if (pending && (prep_rem == 0u || pl == ph)) {  // decided by the table (or an empty index)
-                store_count<kReads>(src, prep_tile * kTile + lane, ph - pl);
+            if (pending && !escaped && (prep_rem == 0u || pl == ph)) {  // decided by the table (or an empty index)
+                store_count<kReads>(src, place_of(prep_tile * kTile + lane, prep_out), ph - pl);
                 pending = false;
             }
             const uint64_t pend_mask = __ballot(pending);
+            if (counters != nullptr) {
+                count(kCntEscapeQueries, __ballot(escaped || restart));
+                count(kCntEscapeRestarts, __ballot(restart));
+                count(kCntTableDecided, __ballot(prep_kind != 0u && !pending));
+                count(kCntSearched, pend_mask);
+            }
             if (pending) {
                 const uint32_t at = __builtin_amdgcn_mbcnt_hi(uint32_t(pend_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(pend_mask), 0u));
                 RingItem it;
                 it.l_lo = uint32_t(pl);
                 it.h_lo = uint32_t(ph);
-                it.meta = uint32_t(pl >> 32) | (uint32_t(ph >> 32) << 8) | (prep_rem << 16) | (lane << 24);  // l, h < 2^40; rem <= 64
+                it.meta = uint32_t(pl >> 32) | (uint32_t(ph >> 32) << 8) | (prep_rem << 16) | (lane << 24) | (escaped ? 0x80000000u : 0u);  // l, h < 2^40; rem <= 64
 #pragma unroll
                 for (int i = 0; i < kWords; ++i) it.w[i] = prep_w[i];
+                it.out = prep_out;
                 ws.ring[(ring_head + ring_count + at) & (kRing - 1)] = it;
             }
             ring_tile = prep_tile;  // the ring was empty: everything in it belongs to this tile
@@ -344,7 +393,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
 #pragma unroll
                 for (int i = 0; i < kWords; ++i) w[i] = it.w[i];
                 rem = (it.meta >> 16) & 0xFFu;
-                qid = ring_tile * kTile + (it.meta >> 24);
+                qid = place_of(ring_tile * kTile + ((it.meta >> 24) & 0x7Fu), it.out);
+                esc = (it.meta >> 31) != 0u;
                 have = true;
             }
             const uint32_t taken = min(ring_count, uint32_t(__popcll(idle)));
@@ -353,7 +403,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
         }
         // a range outside the index would turn into a wild line address: end such a query with
         // u64::MAX and a status flag instead (never seen on a well-formed index; cheap insurance)
-        const bool broken = have && (h > total || l > h);
+        const bool broken = have && !esc && (h > total || l > h);
         if (broken) {
             atomicOr(flags, kFlagInternal);
             if (debug != nullptr && atomicCAS(reinterpret_cast<unsigned long long *>(debug), 0ull, 1ull) == 0ull) {
@@ -375,9 +425,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             const uint64_t q0 = tile * kTile;
             const uint32_t in_tile = uint32_t(min(uint64_t(kTile), n - q0));
             const bool filter_now = filter != nullptr && filter_pause == 0;
-            bool looked_up = false, passed = false;
+            bool looked_up = false, passed = false, filtered = false;
             const uint32_t tile_n0 = staged_n0;  // (fetch_tile_bytes below replaces it with the next tile's)
-            if (!kReads) {  // the tile's bytes go through LDS (the line area is free between two steps)
+            const uint4 packed_words = staged_next[0];
+            prep_out = staged_out;
+            if (!kReads && src.packed != 0u) {
+                // (packed queries sit in this lane's registers already)
+            } else if (!kReads) {  // the tile's bytes go through LDS (the line area is free between two steps)
 #pragma unroll
                 for (int i = 0; i < kPieces; ++i) ws.lines[kStageLead / 16 + lane + 64u * i] = staged_next[i];
             } else if (reads_fast) {
@@ -401,7 +455,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             prep_tile = tile;
             if (lane < in_tile) {
                 PackedQuery<kWords> pq;
-                if (!kReads) {
+                if (!kReads && src.packed != 0u) {
+                    pack_two_bit<kWords>(k, depth, (uint64_t(packed_words.y) << 32) | packed_words.x, (uint64_t(packed_words.w) << 32) | packed_words.z, pq);
+                } else if (!kReads) {
                     pack_query<false, kWords>(src, depth, stage_bytes + lane * k, q0 + lane, pq);
                 } else if (reads_fast) {
                     // window j of the tile starts o bytes into the span (k - 1 more once the read border is
@@ -414,7 +470,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                     pack_query<true, kWords>(src, depth, stage_bytes, q0 + lane, pq);
                 }
                 if (pq.bad) {  // the reference asserts (msbwt_core.rs:127)
-                    store_count<kReads>(src, q0 + lane, ~0ull);
+                    store_count<kReads>(src, place_of(q0 + lane, prep_out), ~0ull);
                     atomicOr(flags, kFlagInvalidSymbol);
                 } else if (use_table && pq.acgt) {
                     bool maybe = true;
@@ -429,7 +485,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                         prep_kind = 1;
                         prep_q = pq;
                     } else {
-                        store_count<kReads>(src, q0 + lane, 0ull);
+                        store_count<kReads>(src, place_of(q0 + lane, prep_out), 0ull);
+                        filtered = true;
                     }
                 } else {
                     prep_kind = 2;
@@ -444,6 +501,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                     --filter_pause;
                 }
             }
+            if (counters != nullptr) count(kCntTableDecided, __ballot(filtered));
             prepared = true;
             wave_lds_sync();         // every lane has read its staged bytes: the line area may be overwritten
             fetch_tile_bytes(next_tile);  // the following tile's bytes start their trip now
@@ -459,19 +517,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
 
         // ---- D: one search step of every busy lane ----
         const uint32_t s1 = w[0] & 7u, s2 = (w[0] >> 3) & 7u;
-        const bool pair = kPair && have && rem >= 2u && (acgt_bit(s1) & acgt_bit(s2)) != 0u;
+        const bool pair = kPair && have && !esc && rem >= 2u && (acgt_bit(s1) & acgt_bit(s2)) != 0u;
         const uint32_t a2 = acgt_code(s1) & 3u, b2 = acgt_code(s2) & 3u;
         constexpr bool s96 = kStride96;  // compile-time: the stride-128 kernel carries no division
-        const uint64_t base = pair ? reinterpret_cast<uint64_t>(pair_blocks) : reinterpret_cast<uint64_t>(blocks);
+        const uint64_t base = esc ? reinterpret_cast<uint64_t>(table_side) : pair ? reinterpret_cast<uint64_t>(pair_blocks) : reinterpret_cast<uint64_t>(blocks);
         // an idle slot names the index's first block (an L2 hit) instead of masking its eight DMA lanes
         // off: one branch-free load instruction per region is cheaper than the exec-mask dance
         const uint64_t dummy = reinterpret_cast<uint64_t>(blocks);
         uint64_t *list = reinterpret_cast<uint64_t *>(ws.lines);  // this step's line addresses: read back before the first line lands
         // the block of l -- and h's own block only when h does not fit the same line (overlapping pair
         // blocks hold 32 positions beyond their own 96)
-        const uint64_t bl = pair ? pair_block_of(l, s96) : l >> 8;
+        // (a query whose range is still in the side array fetches the line of its 16-byte entry there: eight entries per line)
+        const uint64_t bl = esc ? l >> 3 : pair ? pair_block_of(l, s96) : l >> 8;
         const uint64_t start_l = pair ? pair_block_start(bl, s96) : bl << 8;
-        const bool same = pair ? (h - start_l) < 128u : (h >> 8) == bl;
+        const bool same = esc || (pair ? (h - start_l) < 128u : (h >> 8) == bl);
         const uint64_t bh = same ? bl : (pair ? pair_block_of(h, s96) : h >> 8);
         const uint32_t r_l = uint32_t(l - start_l), r_h = uint32_t(h - (same ? start_l : (pair ? pair_block_start(bh, s96) : bh << 8)));
         const bool second = have && !same;
@@ -514,9 +573,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
         }
         __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): every line has landed in LDS (and the table entries of step C are here)
         wave_lds_sync();
+        if (counters != nullptr) {
+            count(kCntWaveSteps, 1ull);
+            count(kCntLaneSteps, __ballot(act));
+            count(kCntPairSteps, __ballot(act && pair));
+            count(kCntSecondLines, __ballot(act && second));
+            count(kCntSatOut, __ballot(have && !act));
+        }
         if (act) {
             uint64_t nl, nh;
-            if (pair) {
+            if (esc) {  // the flat {l, h} entry of this query's table index: no symbol is consumed
+                const uint4 e = ws.lines[line_base(slot_l) + ((uint32_t(l) & 7u) ^ (slot_l & 7u))];
+                nl = (uint64_t(e.y) << 32) | e.x;
+                nh = (uint64_t(e.w) << 32) | e.z;
+                esc = false;
+            } else if (pair) {
                 PairLine L;
                 read_pair_line(ws.lines, slot_l, a2, b2, L);
                 nl = pair_line_bound(L, super_l, r_l);
@@ -546,6 +617,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     // Small host batches run as ONE wave and announce their completion in host-visible memory, so that the caller
     // can poll a word instead of paying for a stream synchronisation: every count of this wave is out (system
     // scope) before the word changes.
+    if (counters != nullptr) {
+        wave_lds_sync();
+        if (lane < uint32_t(kSearchCounters) && lane != uint32_t(kCntFirstLines))
+            atomicAdd(reinterpret_cast<unsigned long long *>(counters + lane), uint64_t(ws.cnt[lane]));
+        if (lane == uint32_t(kCntFirstLines)) atomicAdd(reinterpret_cast<unsigned long long *>(counters + lane), uint64_t(ws.cnt[kCntLaneSteps]));
+    }
     if (done != nullptr) {
         __threadfence_system();
         if (lane == 0u) __hip_atomic_store(done, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -599,8 +676,8 @@ hipError_t launch_variant(hipStream_t stream, const IndexView &ix, const QuerySo
     const uint32_t grain = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(16, tiles / (waves * 8))));
     hipLaunchKernelGGL((k_count_kmers_lanes<kReads, kPair, kWords, kStride96>), dim3(uint32_t(waves)), dim3(64), 0, stream,
                        static_cast<const uint4 *>(ix.blocks), ix.total, table, uint32_t(ix.table.depth), ix.table.packed ? 1u : 0u, filter, filter_mask,
-                       static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags, ix.debug,
-                       tickets ? static_cast<unsigned long long *>(ix.tile_counter) : nullptr, grain, waves == 1 ? ix.done : nullptr, ix.done_seq);
+                       table ? static_cast<const uint4 *>(ix.table.side) : nullptr, static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags, ix.debug,
+                       tickets ? static_cast<unsigned long long *>(ix.tile_counter) : nullptr, grain, waves == 1 ? ix.done : nullptr, ix.done_seq, ix.counters);
     return hipGetLastError();
 }
 
@@ -616,7 +693,7 @@ hipError_t launch_shape(bool pair, bool longk, hipStream_t stream, const IndexVi
 hipError_t launch_lanes(const IndexView &ix, const QuerySource &src, bool reads, bool pair, uint32_t *flags,
                         hipStream_t stream) {
     if (src.k < 1 || src.k > uint32_t(kMaxTiledK)) return hipErrorInvalidValue;
-    if (!reads && (reinterpret_cast<uintptr_t>(src.data) & 15u) != 0) return hipErrorInvalidValue;
+    if (!reads && (reinterpret_cast<uintptr_t>(src.data) & (src.packed ? 7u : 15u)) != 0) return hipErrorInvalidValue;
     if (src.n == 0) return hipSuccess;
     pair = pair && ix.pair_blocks != nullptr;
     const bool longk = src.k > uint32_t(kMaxShortK);

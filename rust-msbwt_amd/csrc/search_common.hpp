@@ -36,6 +36,14 @@ struct QuerySource {
     // host's buffer.  inline_n = 1: the batch is this one query (matrix mode, lanes kernel only).
     uint32_t inline_n;
     uint4 inline_kmer[4];
+    // matrix mode, PACKED queries (lanes kernel, k <= 64): `data` = n x ceil(k / 32) u64 words, two bits per symbol (A C G T ->
+    // 0..3), the k-mer read as a base-4 number with its FIRST symbol most significant -- the last symbol sits in bits 0-1 of
+    // word 0, symbol k - 33 in bits 0-1 of word 1.  8 bytes per 31-mer instead of 31; '$' / 'N' cannot be said.
+    uint32_t packed;
+    // where query v's count goes: out_fwd[out_index[v]] (an ordered batch is counted in index order and its counts return to
+    // the caller's order, order.hip); nullptr = out_fwd[v].  Matrix mode, lanes kernel; n <= 2^32.
+    const uint32_t *out_index;
+    uint32_t placed_store;  // how the counts of a placed batch are stored (store_count)
 };
 
 namespace {
@@ -69,27 +77,33 @@ struct TableEnv {
     const uint32_t *filter;
     uint32_t filter_mask;
     uint64_t total;
+    const uint4 *side;     // flat entries of the packed table's escape lines (nullptr: such queries search from scratch)
 };
 
 // Packed suffix table (TableView::packed): a 128-byte line = u64 base | 30 x u32 { l - base : 16, h - l : 16 }
 // for 30 consecutive table indices (consecutive indices are consecutive ranges, so the deltas are
-// small); bit 63 of base = ESCAPE (some entry of the line does not fit 16 bits: its queries search
-// from scratch).  4.27 bytes per entry instead of 16: two more table levels in the same HBM.
+// small); bit 63 of base = ESCAPE: some entry of the line does not fit 16 bits (the suffixes of a high-copy repeat).
+// The other bits of an escape line's base then name its group in the SIDE array: 32 flat 16-byte {l, h} entries (30
+// used), so that a query of such a line costs ONE more line fetch -- like any search step -- instead of a search from
+// scratch (round 4; the reference's constrain_range costs the same for any range width, rle_bwt.rs:202-287).
+// 4.27 bytes per entry instead of 16: two more table levels in the same HBM.
 constexpr uint32_t kPackedPerLine = 30;
+constexpr uint32_t kSidePerLine = 32;  // 16-byte slots of a side group (512 bytes: four lines)
 constexpr uint64_t kPackedEscape = 1ull << 63;
 
 // The raw bits of one table entry, as loaded (the loads may stay in flight):
-//   flat:   {l_lo, l_hi, h_lo, h_hi};   packed: {base_lo, base_hi, entry, 0}
+//   flat:   {l_lo, l_hi, h_lo, h_hi};   packed: {base_lo, base_hi, entry, slot in the line}
 __device__ __forceinline__ uint4 table_fetch(const TableEnv &env, uint64_t tidx) {
     if (!env.packed) return env.table[tidx];
     const uint64_t line = tidx / kPackedPerLine;
     const uint32_t slot = uint32_t(tidx - line * kPackedPerLine);
     const uint2 base = *reinterpret_cast<const uint2 *>(env.table + line * 8);
     const uint32_t e = reinterpret_cast<const uint32_t *>(env.table + line * 8)[2u + slot];
-    return make_uint4(base.x, base.y, e, 0u);
+    return make_uint4(base.x, base.y, e, slot);
 }
 
-// -> range; returns false when the entry cannot be used (escape line): search from [0, total)
+// -> range; returns false for an entry of an escape line: l = index of its 16-byte entry in the side array then
+// (meaningful when env.side != nullptr; without a side array the query searches from [0, total))
 __device__ __forceinline__ bool table_decode(const TableEnv &env, const uint4 raw, uint64_t &l, uint64_t &h) {
     if (!env.packed) {
         l = (uint64_t(raw.y) << 32) | raw.x;
@@ -97,9 +111,14 @@ __device__ __forceinline__ bool table_decode(const TableEnv &env, const uint4 ra
         return true;
     }
     const uint64_t base = (uint64_t(raw.y) << 32) | raw.x;
-    l = (base & ~kPackedEscape) + (raw.z & 0xFFFFu);
+    if ((base & kPackedEscape) != 0ull) {
+        l = (base & ~kPackedEscape) * kSidePerLine + raw.w;
+        h = l;
+        return false;
+    }
+    l = base + (raw.z & 0xFFFFu);
     h = l + (raw.z >> 16);
-    return (base & kPackedEscape) == 0ull;
+    return true;
 }
 
 __device__ __forceinline__ uint32_t ascii_to_code(uint32_t c) {
@@ -137,7 +156,11 @@ __device__ __forceinline__ uint4 load_piece(const uint8_t *__restrict__ src_byte
 template <bool kReads>
 __device__ __forceinline__ void store_count(const QuerySource &src, uint64_t v, uint64_t value) {
     if (!kReads) {
-        src.out_fwd[v] = value;
+        // counts that go to their queries' own places (an ordered batch) are scattered 8-byte writes: experiment switch
+        // 1 = non-temporal, 2 = write-through past the L2 (sc1), so that they do not push index lines out of it
+        if (src.placed_store == 2u) __hip_atomic_store(&src.out_fwd[v], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (src.placed_store == 1u) __builtin_nontemporal_store(value, &src.out_fwd[v]);
+        else src.out_fwd[v] = value;
     } else if (src.strands == 3u) {
         ((v & 1u) ? src.out_rc : src.out_fwd)[v >> 1] = value;
     } else {
@@ -237,6 +260,31 @@ __device__ __forceinline__ void pack_row_swar(uint32_t k, uint32_t depth, const 
     pq.tidx = tidx & ((1ull << (2u * min(depth, 20u))) - 1ull);
     pq.bad = bad != 0u;
     pq.acgt = nonacgt == 0u;
+}
+
+// pack_query for a query handed over as 2-bit codes (QuerySource::packed): `lo` = symbols k-1 .. k-32 from bit 0 up (search
+// order), `hi` = symbols k-33 .. (kWords == 6 only).  Nothing to validate; the table index is the low 2 x depth bits as they are.
+template <int kWords>
+__device__ __forceinline__ void pack_two_bit(uint32_t k, uint32_t depth, uint64_t lo, uint64_t hi, PackedQuery<kWords> &pq) {
+    constexpr int kBits = PackedQuery<kWords>::kBits;
+    constexpr uint32_t kMaxK = kWords == 3 ? 32u : 64u;
+#pragma unroll
+    for (int j = 0; j < kBits; ++j) pq.bits[j] = 0;
+    // symbols beyond k read as 'A' (code 1): never searched (rem counts the steps), but the words stay well-formed
+    if (k < 32u) lo &= (1ull << (2u * k)) - 1ull;
+    if (k < 64u && k > 32u) hi &= (1ull << (2u * (k - 32u))) - 1ull;
+    if (k <= 32u) hi = 0ull;
+#pragma unroll
+    for (uint32_t u = 0; u < kMaxK / 4u; ++u) {  // four symbols per round: 8 bits -> the 12-bit group of steps 4u .. 4u+3
+        const uint32_t x = uint32_t((u < 8u ? lo : hi) >> (8u * (u & 7u))) & 0xFFu;
+        const uint32_t y = (x & 0x03u) | ((x & 0x0Cu) << 1) | ((x & 0x30u) << 2) | ((x & 0xC0u) << 3);  // 2-bit fields on a 3-bit pitch
+        const uint32_t g = y + 0x249u + ((y & (y >> 1)) & 0x249u);  // A C G T -> 1 2 3 5: + 1, and + 1 more where the code is 3
+        constexpr_shift_or12<kBits>(pq.bits, g, 12u * u);
+    }
+    const uint32_t reach = min(depth, k);
+    pq.tidx = reach >= 32u ? lo : (lo & ((1ull << (2u * reach)) - 1ull));
+    pq.bad = false;
+    pq.acgt = true;
 }
 
 template <bool kReads, int kWords>
@@ -365,7 +413,13 @@ __device__ __forceinline__ bool prepare_query(const QuerySource &src, const Tabl
         } else if (table_decode(env, table_fetch(env, pq.tidx), l, h)) {
             skip = env.depth;
             rem = src.k - env.depth;
-        } else {  // escape line of a packed table: this query searches from scratch
+        } else if (env.side != nullptr) {  // escape line of a packed table: its flat entry, one dependent load further
+            const uint4 e = env.side[l];
+            l = (uint64_t(e.y) << 32) | e.x;
+            h = (uint64_t(e.w) << 32) | e.z;
+            skip = env.depth;
+            rem = src.k - env.depth;
+        } else {  // no side array: this query searches from scratch
             l = 0;
             h = env.total;
         }

@@ -18,8 +18,10 @@ struct TableChoice {
 
 // Flat table: the deepest that the data warrant (4^depth <= T) within max(1 GiB, 2 x the block array),
 // at most 15 levels (16 GiB).
-inline int auto_flat_table_depth(uint64_t total, uint64_t block_bytes) {
-    const uint64_t budget = std::max<uint64_t>(uint64_t(1) << 30, 2 * block_bytes);
+// `allowance`: what a memory budget (msbwt_rle_set_memory_budget) leaves for the table; ~0 = no budget.
+constexpr uint64_t kNoBudget = ~uint64_t(0);
+inline int auto_flat_table_depth(uint64_t total, uint64_t block_bytes, uint64_t allowance = kNoBudget) {
+    const uint64_t budget = std::min(allowance, std::max<uint64_t>(uint64_t(1) << 30, 2 * block_bytes));
     int d = 0;
     while (d < 15 && (uint64_t(4) << (2 * d)) <= total && (uint64_t(64) << (2 * d)) <= budget) ++d;
     return d;
@@ -33,13 +35,29 @@ inline int auto_flat_table_depth(uint64_t total, uint64_t block_bytes) {
 // stopped at 16 entries per symbol (C3: depth 15); with 256 a 2 x 10^8-symbol index gets the full depth 17 (73 GB that
 // a 288 GB part has to spare): C3 fused 8.9 -> 9.8 x 10^9 windows/s.  Toy indexes stay small (T = 10: depth 5).
 constexpr uint64_t kTableEntriesPerSymbol = 256;
-inline TableChoice choose_table_depths(uint64_t total, uint64_t block_bytes, uint64_t free_bytes, bool pair_index, bool packing_allowed) {
-    TableChoice c{auto_flat_table_depth(total, block_bytes), 0};
+inline TableChoice choose_table_depths(uint64_t total, uint64_t block_bytes, uint64_t free_bytes, bool pair_index, bool packing_allowed,
+                                       uint64_t allowance = kNoBudget) {
+    TableChoice c{auto_flat_table_depth(total, block_bytes, allowance), 0};
     if (!pair_index || !packing_allowed) return c;
+    // Under a memory budget the packed lines must fit what the budget leaves -- all of it: the caller has said how much the
+    // index may hold, so the "half of what is free" courtesy does not apply to the allowance (it still does to the HBM that is
+    // actually free, and the flat parent, which is freed after packing, only has to fit there).
     const auto fits = [&](int p) {
         const uint64_t flat_b = uint64_t(16) << (2 * (p - 2));
-        return (uint64_t(1) << (2 * p)) <= kTableEntriesPerSymbol * total && 2 * packed_table_bytes(p) <= free_bytes && flat_b + packed_table_bytes(p) <= free_bytes;
+        return (uint64_t(1) << (2 * p)) <= kTableEntriesPerSymbol * total && 2 * packed_table_bytes(p) <= free_bytes && flat_b + packed_table_bytes(p) <= free_bytes &&
+               packed_table_bytes(p) <= allowance;
     };
+    if (allowance != kNoBudget) {  // the deepest packed table the allowance holds, whatever the flat table's own depth would be
+        c.flat = 0;
+        for (int p = 17; p >= 3; --p)
+            if (fits(p)) {
+                c.flat = p - 2;
+                c.packed = p;
+                return c;
+            }
+        c.flat = auto_flat_table_depth(total, block_bytes, allowance);
+        return c;
+    }
     for (int p = 17; p - 2 > c.flat; --p)
         if (fits(p)) {
             c.flat = p - 2;
@@ -70,10 +88,55 @@ inline int choose_pair_stride(uint64_t bytes96, uint64_t expected_table_bytes, u
 }
 
 // peak HBM the table takes while it is built with `free_bytes` free (flat parent + packed lines side by side)
-inline uint64_t expected_table_bytes(uint64_t total, uint64_t block_bytes, uint64_t free_bytes, bool pair_index, bool packing_allowed) {
-    const TableChoice c = choose_table_depths(total, block_bytes, free_bytes, pair_index, packing_allowed);
+inline uint64_t expected_table_bytes(uint64_t total, uint64_t block_bytes, uint64_t free_bytes, bool pair_index, bool packing_allowed,
+                                     uint64_t allowance = kNoBudget) {
+    const TableChoice c = choose_table_depths(total, block_bytes, free_bytes, pair_index, packing_allowed, allowance);
     const uint64_t flat_b = c.flat ? uint64_t(16) << (2 * c.flat) : 0;
     return c.packed ? flat_b + packed_table_bytes(c.packed) : flat_b;
+}
+
+// ---- a memory budget for the whole index (msbwt_rle_set_memory_budget): the analogue of the reference's only space / time
+// knob, `bin_power` (rle_bwt.rs:309-322) -------------------------------------------------------------------------------------
+// The plane blocks (0.5 byte per symbol) are always built.  What the budget leaves goes, in this order, to the pair blocks
+// (two symbols per step: the largest single gain; disjoint blocks, 1 byte per symbol, whenever they fit with a little room
+// for a table), then to the deepest packed suffix table that fits (each two
+// levels spare a query a step), then -- if the probe says ranges stay wide -- to the overlapping pair blocks (+0.33 byte per
+// symbol).  A pure function of sizes, pinned by a CPU test through msbwt_auto_index_plan.
+struct IndexPlan {
+    bool pair;       // build pair blocks
+    int stride;      // 96 or 128 (meaningful when pair)
+    int flat, packed;
+    uint64_t bytes;  // HBM the finished index holds under this plan (blocks + pair blocks + table; filter and side array not counted)
+};
+
+// pair128_bytes / pair96_bytes: pair blocks + superblock table at either spacing (pair_index_sizes)
+inline IndexPlan plan_index(uint64_t total, uint64_t free_bytes, uint64_t hbm_total_bytes, double typical_width, uint64_t budget,
+                            uint64_t pair128_bytes, uint64_t pair96_bytes) {
+    const uint64_t nblocks = total / 256 + 1, plane_b = nblocks * 128;
+    IndexPlan p{false, 128, 0, 0, plane_b};
+    if (total == 0) return p;
+    const uint64_t left0 = budget == 0 ? kNoBudget : (budget > plane_b ? budget - plane_b : 0);
+    // two symbols per step halve the lines of every query, which no table depth that the same bytes would buy does: the pair
+    // blocks come first whenever they fit with a sixteenth of their size to spare for a table
+    p.pair = pair128_bytes <= free_bytes / 2 && (left0 == kNoBudget || pair128_bytes + pair128_bytes / 16 <= left0);
+    uint64_t left = left0, free_left = free_bytes;
+    if (p.pair) {
+        if (left != kNoBudget) left -= pair128_bytes;
+        free_left -= pair128_bytes;
+    }
+    const TableChoice c = choose_table_depths(total, plane_b, free_left, p.pair, true, left);
+    p.flat = c.flat;
+    p.packed = c.packed;
+    const uint64_t table_b = c.packed ? packed_table_bytes(c.packed) : (c.flat ? uint64_t(16) << (2 * c.flat) : 0);
+    if (left != kNoBudget) left = left > table_b ? left - table_b : 0;
+    if (p.pair) {
+        const uint64_t extra = pair96_bytes > pair128_bytes ? pair96_bytes - pair128_bytes : 0;
+        const bool affordable = left == kNoBudget || extra <= left;
+        const int want = choose_pair_stride(pair96_bytes, table_b, free_bytes, hbm_total_bytes, typical_width);
+        p.stride = (want == 96 && affordable) ? 96 : 128;
+    }
+    p.bytes = plane_b + (p.pair ? (p.stride == 96 ? pair96_bytes : pair128_bytes) : 0) + table_b;
+    return p;
 }
 
 }  // namespace msbwt

@@ -194,6 +194,40 @@ class RleBWT(BWT):
         if rc:
             _raise(rc, self._h)
 
+    def count_kmers_packed(self, words, k, count_bits=64, out=None):
+        """msbwt_rle_count_kmers_packed: `words` = (n, ceil(k / 32)) uint64, two bits per symbol (pack_2bit); returns uint64[n]
+        or, with count_bits=32, uint32[n] (`out`: optional preallocated result array of that type)."""
+        w = np.ascontiguousarray(words, dtype=np.uint64).reshape(-1, 2 if k > 32 else 1)
+        want = np.uint64 if count_bits == 64 else np.uint32
+        if out is None:
+            out = np.empty(len(w), dtype=want)
+        elif out.dtype != want or out.shape != (len(w),) or not out.flags.c_contiguous:
+            raise ValueError("out must be a contiguous array of n counts of the requested width")
+        rc = _lib.lib().msbwt_rle_count_kmers_packed(self._h, w.ctypes.data_as(C.c_void_p), k, len(w), out.ctypes.data_as(C.c_void_p), count_bits)
+        if rc:
+            _raise(rc, self._h)
+        return out
+
+    def count_kmers_packed_device(self, d_words, k, n, d_out, stream=0):
+        rc = _lib.lib().msbwt_rle_count_kmers_packed_device(self._h, d_words, k, n, d_out, stream)
+        if rc:
+            _raise(rc, self._h)
+
+    def set_batch_order(self, mode):
+        """-1 = the library orders dense batches itself (default), 0 = never, 1 = whenever the pass applies."""
+        rc = _lib.lib().msbwt_rle_set_batch_order(self._h, int(mode))
+        if rc:
+            _raise(rc, self._h)
+
+    def get_batch_order(self):
+        return int(_lib.lib().msbwt_rle_get_batch_order(self._h))
+
+    def batch_order_for(self, k, n):
+        rc = int(_lib.lib().msbwt_rle_batch_order_for(self._h, int(k), int(n)))
+        if rc < 0:
+            _raise(rc, self._h)
+        return bool(rc)
+
     def kmer_order_keys_device(self, d_kmers, k, n, d_out_keys, stream=0):
         """msbwt_rle_kmer_order_keys_device: u64 keys (device pointers); a batch sorted by them ascending walks the index in order."""
         rc = _lib.lib().msbwt_rle_kmer_order_keys_device(self._h, d_kmers, k, n, d_out_keys, stream)
@@ -235,6 +269,45 @@ class RleBWT(BWT):
 
     def get_table_packed(self):
         return bool(_lib.lib().msbwt_rle_get_table_packed(self._h))
+
+    def set_memory_budget(self, nbytes):
+        """HBM the loaded index may hold (0 = no budget); rebuilds the optional structures of a loaded index under it."""
+        rc = _lib.lib().msbwt_rle_set_memory_budget(self._h, int(nbytes))
+        if rc:
+            _raise(rc, self._h)
+
+    def get_memory_budget(self):
+        return int(_lib.lib().msbwt_rle_get_memory_budget(self._h))
+
+    def set_table_side(self, mode):
+        """1 = escape lines of the packed table keep flat entries in a side array (default), 0 = their queries search from scratch."""
+        rc = _lib.lib().msbwt_rle_set_table_side(self._h, int(mode))
+        if rc:
+            _raise(rc, self._h)
+
+    def table_info(self):
+        """{"lines", "escape_lines", "side_bytes"} of the packed table in HBM (zeros without one)."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        rc = _lib.lib().msbwt_rle_table_info(self._h, C.byref(a), C.byref(b), C.byref(c))
+        if rc:
+            _raise(rc, self._h)
+        return {"lines": a.value, "escape_lines": b.value, "side_bytes": c.value}
+
+    COUNTER_NAMES = ("wave_steps", "lane_steps", "pair_steps", "second_lines", "sat_out", "escape_queries", "escape_restarts",
+                     "table_decided", "searched", "first_lines")
+
+    def set_search_counters(self, enabled):
+        rc = _lib.lib().msbwt_rle_set_search_counters(self._h, 1 if enabled else 0)
+        if rc:
+            _raise(rc, self._h)
+
+    def search_counters(self, stream=0):
+        """The counters of the launches since the last call, by name (include/msbwt_hip.h); reads and zeroes them."""
+        out = (C.c_uint64 * 16)()
+        rc = _lib.lib().msbwt_rle_search_counters(self._h, out, stream)
+        if rc:
+            _raise(rc, self._h)
+        return {name: int(out[i]) for i, name in enumerate(self.COUNTER_NAMES)}
 
     def set_presence_filter(self, mode):
         """0 = no presence filter, anything else = automatic (kept when it can reject something)."""
@@ -379,6 +452,19 @@ def count_kmers_multi(replicas, kmers, out=None):
                                                 out.ctypes.data_as(C.c_void_p))
     if rc:
         raise MsbwtError(rc, "; ".join(_lib.lib().msbwt_rle_last_error(r._h).decode(errors="replace") for r in replicas))
+    return out
+
+
+def pack_2bit(kmers):
+    """(n, k) symbol codes over ACGT -> (n, ceil(k / 32)) uint64 words (msbwt_kmers_pack_2bit; include/msbwt_hip.h has the layout)."""
+    a = np.ascontiguousarray(kmers, dtype=np.uint8)
+    if a.ndim != 2:
+        raise ValueError("kmers must be (n, k)")
+    n, k = a.shape
+    out = np.empty((n, 2 if k > 32 else 1), dtype=np.uint64)
+    rc = _lib.lib().msbwt_kmers_pack_2bit(a.ctypes.data_as(C.c_void_p), k, n, out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise MsbwtError(rc, "a symbol outside A C G T cannot be packed into two bits")
     return out
 
 

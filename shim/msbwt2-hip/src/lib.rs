@@ -53,8 +53,16 @@ extern "C" {
     fn msbwt_comm_destroy(comm: *mut c_void) -> c_int;
     fn msbwt_rle_allgather_counts(bwt: *const MsbwtRle, comm: *mut c_void, d_mine: *const c_void, n_mine: usize,
                                   d_all: *mut c_void, wire_bits: c_int, hip_stream: *mut c_void) -> c_int;
-    // batch order: sort a batch by these keys (ascending) and it walks the index in order (up to 2x faster on dense batches)
+    // batch order: sort a batch by these keys (ascending) and it walks the index in order (up to 2x faster on dense batches);
+    // since round 4 the library orders dense batches itself (-1 = automatic, 0 = never, 1 = whenever the pass applies)
     fn msbwt_kmer_order_keys(kmers: *const u8, k: usize, n: usize, out_keys: *mut u64) -> c_int;
+    fn msbwt_rle_set_batch_order(bwt: *mut MsbwtRle, mode: c_int) -> c_int;
+    // compact queries: two bits per symbol -- 8 bytes per 31-mer over PCIe instead of 31, 32-bit counts on the way back
+    fn msbwt_kmers_pack_2bit(kmers: *const u8, k: usize, n: usize, out_words: *mut u64) -> c_int;
+    fn msbwt_rle_count_kmers_packed(bwt: *const MsbwtRle, kmers2bit: *const u64, k: usize, n: usize,
+                                    out_counts: *mut c_void, count_bits: c_int) -> c_int;
+    // HBM the index may hold (0 = no budget): the space / time knob, as bin_power is the reference's
+    fn msbwt_rle_set_memory_budget(bwt: *mut MsbwtRle, bytes: u64) -> c_int;
 }
 
 /// Same role as `RleBWT` (src/rle_bwt.rs:14-24); the index lives in HBM.
@@ -125,6 +133,50 @@ impl GpuRleBWT {
         let rc = unsafe { msbwt_rle_set_table_depth(self.raw, depth) };
         if rc != MSBWT_OK { panic!("set_table_depth: {}", self.last_error()); }
     }
+
+    /// `count_kmers` for k-mers over ACGT handed over as 2-bit words (`pack_2bit`): ceil(k / 32) words per k-mer.
+    pub fn count_kmers_packed(&self, words: &[u64], k: usize) -> Vec<u64> {
+        let per = if k > 32 { 2 } else { 1 };
+        assert!(k >= 1 && k <= 64 && words.len() % per == 0);
+        let n = words.len() / per;
+        let mut out = vec![0u64; n];
+        let rc = unsafe { msbwt_rle_count_kmers_packed(self.raw, words.as_ptr(), k, n, out.as_mut_ptr() as *mut c_void, 64) };
+        if rc != MSBWT_OK { panic!("count_kmers_packed: {}", self.last_error()); }
+        out
+    }
+
+    /// The same with 32-bit counts (half the bytes on the way back); panics if a count does not fit.
+    pub fn count_kmers_packed_u32(&self, words: &[u64], k: usize) -> Vec<u32> {
+        let per = if k > 32 { 2 } else { 1 };
+        assert!(k >= 1 && k <= 64 && words.len() % per == 0);
+        let n = words.len() / per;
+        let mut out = vec![0u32; n];
+        let rc = unsafe { msbwt_rle_count_kmers_packed(self.raw, words.as_ptr(), k, n, out.as_mut_ptr() as *mut c_void, 32) };
+        if rc != MSBWT_OK { panic!("count_kmers_packed: {}", self.last_error()); }
+        out
+    }
+
+    /// -1 = the library orders dense batches itself (default), 0 = never, 1 = whenever the pass applies.
+    pub fn set_batch_order(&mut self, mode: i32) {
+        let rc = unsafe { msbwt_rle_set_batch_order(self.raw, mode) };
+        if rc != MSBWT_OK { panic!("set_batch_order: {}", self.last_error()); }
+    }
+
+    /// HBM the loaded index may hold (0 = no budget): plane blocks always, then pair blocks, then the deepest table that fits.
+    pub fn set_memory_budget(&mut self, bytes: u64) {
+        let rc = unsafe { msbwt_rle_set_memory_budget(self.raw, bytes) };
+        if rc != MSBWT_OK { panic!("set_memory_budget: {}", self.last_error()); }
+    }
+}
+
+/// n k-mers of k symbol codes (A C G T = 1 2 3 5) -> 2-bit words: the k-mer as a base-4 number, first symbol most significant.
+pub fn pack_2bit(kmers: &[u8], k: usize) -> Vec<u64> {
+    assert!(k >= 1 && k <= 64 && kmers.len() % k == 0);
+    let n = kmers.len() / k;
+    let mut words = vec![0u64; n * if k > 32 { 2 } else { 1 }];
+    let rc = unsafe { msbwt_kmers_pack_2bit(kmers.as_ptr(), k, n, words.as_mut_ptr()) };
+    assert!(rc == MSBWT_OK, "msbwt_kmers_pack_2bit: a symbol outside A C G T (code {})", rc);
+    words
 }
 
 /// One index replicated on several GPUs of a node; batches are sharded over the replicas inside

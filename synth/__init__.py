@@ -32,6 +32,7 @@ def lib():
         vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
         L.synth_genome.argtypes = [u64, u64, vp]
         L.synth_reads.argtypes = [vp, u64, u64, u32, u64, u32, vp]
+        L.synth_repeat_genome.argtypes = [u64, u64, u32, vp, vp, vp, vp, vp, u64, u32, u32, u64, vp, vp]
         L.synth_random_kmers.argtypes = [u64, u32, u64, vp]
         L.synth_build_msbwt.argtypes = [vp, vp, u64, vp, C.c_int]
         L.synth_build_msbwt.restype = C.c_int
@@ -56,6 +57,48 @@ def genome(length, seed):
     out = np.empty(length, dtype=np.uint8)
     lib().synth_genome(length, seed, _p(out))
     return out
+
+
+# Repeat model of the `c4r` workload, quoted per 64 444 167 bases (config C4's genome; other sizes scale the copy numbers and
+# the tandem-repeat bases): the human genome's repeat classes at its own proportions -- Alu-like SINEs ~10 % of the bases, L1-like
+# 5'-truncated LINEs ~17 %, LTR and DNA elements ~10 %, old MIR-like copies ~4 %, recent segmental duplications ~3 %, satellite
+# arrays ~3 %, microsatellites ~1 % -- with per-copy divergence between 0 and 30 %.  Copy numbers are the human ones divided by
+# ~50 (the genome is 1/48 of a human one): what a 17-mer of a young Alu copy does to a 30x read set -- tens of thousands of
+# occurrences -- it still does here (22 000 copies x 27 covering windows x the share of copies that kept the 17-mer intact).
+REPEAT_FAMILIES = [
+    # (name, consensus length, copies per 64.4 Mbp, divergence low, high, 5'-truncated)
+    ("alu_young", 300, 6_000, 0.01, 0.05, False),
+    ("alu_old", 300, 24_000, 0.05, 0.15, False),
+    ("l1", 6000, 4_500, 0.01, 0.20, True),
+    ("ltr_a", 1000, 1_500, 0.05, 0.20, False),
+    ("ltr_b", 1200, 1_500, 0.05, 0.20, False),
+    ("ltr_c", 800, 1_500, 0.05, 0.20, False),
+    ("dna_a", 800, 1_200, 0.10, 0.20, False),
+    ("dna_b", 900, 1_200, 0.10, 0.20, False),
+    ("mir_old", 260, 10_000, 0.20, 0.30, False),
+    ("segdup", 20_000, 100, 0.00, 0.02, False),
+]
+REPEAT_SATELLITE = dict(bases=2_000_000, monomer=171, div=0.02)
+REPEAT_MICRO_BASES = 640_000
+REPEAT_REF_GENOME = 64_444_167
+
+
+def repeat_genome(length, seed, with_classes=False):
+    """A genome with interspersed repeat families, satellite arrays and microsatellites (model above, scaled to `length`)."""
+    scale = length / REPEAT_REF_GENOME
+    fams = [f for f in REPEAT_FAMILIES if f[1] < length // 4]
+    n = len(fams)
+    lens = np.array([f[1] for f in fams], dtype=np.uint32)
+    copies = np.array([max(1, int(round(f[2] * scale))) for f in fams], dtype=np.uint32)
+    dlo = np.array([int(f[3] * 1e6) for f in fams], dtype=np.uint32)
+    dhi = np.array([int(f[4] * 1e6) for f in fams], dtype=np.uint32)
+    trunc = np.array([1 if f[5] else 0 for f in fams], dtype=np.uint8)
+    out = np.empty(length, dtype=np.uint8)
+    cls = np.empty(length, dtype=np.uint8) if with_classes else None
+    lib().synth_repeat_genome(length, seed, n, _p(lens), _p(copies), _p(dlo), _p(dhi), _p(trunc),
+                              int(REPEAT_SATELLITE["bases"] * scale), REPEAT_SATELLITE["monomer"] if length > 4 * REPEAT_SATELLITE["monomer"] else 0,
+                              int(REPEAT_SATELLITE["div"] * 1e6), int(REPEAT_MICRO_BASES * scale), _p(out), _p(cls) if with_classes else None)
+    return (out, cls) if with_classes else out
 
 
 def reads(genome_codes, n, length, seed, err=0.005):
@@ -193,6 +236,10 @@ CONFIGS = {
                nq=100_000_000, qseed=23, queries="random"),
     # not a BASELINE config: three times C4 (5.84e9 symbols), the largest real MSBWT (reads with substitutions, suffix-sorted)
     # that the GPU box's host share builds within its memory cap (~205 GB) -- a size point between C4 and human scale
+    # not a BASELINE config either: C4's size and read set on a genome WITH REPEATS (repeat_genome above) -- what a human-like
+    # read set does to the search: wide ranges, high-copy 17-mers (the packed table's escape lines), early exits
+    "c4r": dict(genome=64_444_167, gseed=41, nreads=12_888_833, rlen=150, rseed=42, err=0.005, k=31,
+                nq=100_000_000, qseed=43, queries="reads", repeats=True),
     "c4x3": dict(genome=193_332_501, gseed=31, nreads=38_666_499, rlen=150, rseed=32, err=0.005, k=31,
                  nq=100_000_000, qseed=33, queries="reads"),
 }
@@ -206,7 +253,7 @@ def workload_index(name, scale=1.0, cache=True, threads=0):
     tag = "%s_g%d_n%d_l%d" % (name, g, n, cfg["rlen"])
     os.makedirs(CACHE, exist_ok=True)
     npy = os.path.join(CACHE, tag + "_comp_msbwt.npy")
-    rd = reads(genome(g, cfg["gseed"]), n, cfg["rlen"], cfg["rseed"], cfg["err"])
+    rd = reads(repeat_genome(g, cfg["gseed"]) if cfg.get("repeats") else genome(g, cfg["gseed"]), n, cfg["rlen"], cfg["rseed"], cfg["err"])
     if not (cache and os.path.exists(npy)):
         sym = build_msbwt_symbols(rd, threads)
         write_npy(npy, rle_encode(sym))

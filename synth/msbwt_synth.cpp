@@ -70,6 +70,84 @@ void synth_genome(uint64_t length, uint64_t seed, uint8_t *out) {
     });
 }
 
+// A genome WITH REPEATS (round 4; the human genome is about half repeats and the search cost of a k-mer follows its copy
+// number): a uniform i.i.d. background, onto which are pasted, in this order (later pastes overwrite earlier ones),
+//   * interspersed families: family f has a random consensus of fam_len[f] bases and fam_copies[f] copies at uniform
+//     positions; a copy is the whole consensus, or (fam_trunc[f] != 0) a 5'-truncated piece of uniform length in
+//     [fam_len/20, fam_len] (L1-like); half of the copies are reverse-complemented; every base of a copy is substituted
+//     with the copy's own divergence, drawn uniformly from [div_lo, div_hi] (parts per million) -- young and old copies;
+//   * satellite arrays: tandem repeats of a sat_monomer-base monomer (one monomer per array family of ~100 kb arrays),
+//     neighbouring monomers diverged by sat_div_ppm, sat_bases bases in all;
+//   * microsatellites / homopolymer tracts: units of 1..6 bases repeated over 20..80 bases, micro_bases bases in all.
+// out_class[i] (optional): 0 = background, 1 + f = family f, 250 = satellite, 251 = microsatellite.
+// Everything is integer arithmetic on one splitmix64 stream: the CPU box and the GPU box build the same genome.
+void synth_repeat_genome(uint64_t length, uint64_t seed, uint32_t nfam, const uint32_t *fam_len, const uint32_t *fam_copies,
+                         const uint32_t *fam_div_lo_ppm, const uint32_t *fam_div_hi_ppm, const uint8_t *fam_trunc,
+                         uint64_t sat_bases, uint32_t sat_monomer, uint32_t sat_div_ppm, uint64_t micro_bases, uint8_t *out,
+                         uint8_t *out_class) {
+    synth_genome(length, seed, out);
+    if (out_class) std::memset(out_class, 0, size_t(length));
+    uint64_t st = seed ^ 0x5EED5EED5EED5EEDull;
+    auto mutate = [&](uint8_t c, uint32_t ppm) -> uint8_t {  // substitution with probability ppm / 1e6
+        const uint64_t x = splitmix64(st);
+        if (uint32_t(x % 1000000u) >= ppm) return c;
+        uint32_t idx = 0;
+        while (kBase[idx] != c) ++idx;
+        return kBase[(idx + 1 + uint32_t(x >> 32) % 3u) & 3u];
+    };
+    auto comp = [](uint8_t c) -> uint8_t { return c == 1 ? 5 : c == 5 ? 1 : c == 2 ? 3 : 2; };
+    std::vector<uint8_t> cons;
+    for (uint32_t f = 0; f < nfam; ++f) {
+        const uint32_t L = fam_len[f];
+        if (L == 0 || L >= length) continue;
+        cons.resize(L);
+        for (uint32_t i = 0; i < L; ++i) cons[i] = kBase[splitmix64(st) & 3u];
+        for (uint32_t c = 0; c < fam_copies[f]; ++c) {
+            uint32_t piece = L;
+            if (fam_trunc[f]) piece = std::max<uint32_t>(L / 20u, 1u) + uint32_t(splitmix64(st) % (L - std::max<uint32_t>(L / 20u, 1u) + 1u));
+            const uint32_t from = L - piece;  // 5'-truncated: the 3' end is kept
+            const uint64_t at = splitmix64(st) % (length - piece + 1);
+            const bool rc = (splitmix64(st) & 1u) != 0;
+            const uint32_t span = fam_div_hi_ppm[f] - fam_div_lo_ppm[f];
+            const uint32_t div = fam_div_lo_ppm[f] + (span ? uint32_t(splitmix64(st) % (span + 1u)) : 0u);
+            for (uint32_t i = 0; i < piece; ++i) {
+                const uint8_t b = rc ? comp(cons[from + piece - 1 - i]) : cons[from + i];
+                out[at + i] = mutate(b, div);
+                if (out_class) out_class[at + i] = uint8_t(1 + f);
+            }
+        }
+    }
+    if (sat_monomer > 0 && sat_monomer < length) {
+        std::vector<uint8_t> mono(sat_monomer), cur(sat_monomer);
+        uint64_t placed = 0;
+        while (placed < sat_bases) {
+            for (uint32_t i = 0; i < sat_monomer; ++i) mono[i] = kBase[splitmix64(st) & 3u];
+            const uint64_t arr = std::min<uint64_t>(std::min<uint64_t>(sat_bases - placed, 50000 + splitmix64(st) % 100000), length / 2);
+            const uint64_t at = splitmix64(st) % (length - arr + 1);
+            cur = mono;
+            for (uint64_t i = 0; i < arr; ++i) {
+                const uint32_t j = uint32_t(i % sat_monomer);
+                if (j == 0 && i) for (uint32_t t = 0; t < sat_monomer; ++t) cur[t] = mutate(mono[t], sat_div_ppm);
+                out[at + i] = cur[j];
+                if (out_class) out_class[at + i] = 250;
+            }
+            placed += std::max<uint64_t>(arr, 1);
+        }
+    }
+    for (uint64_t placed = 0; placed < micro_bases;) {
+        const uint32_t unit = 1u + uint32_t(splitmix64(st) % 6u), tract = 20u + uint32_t(splitmix64(st) % 61u);
+        if (tract >= length) break;
+        uint8_t u[6];
+        for (uint32_t i = 0; i < unit; ++i) u[i] = kBase[splitmix64(st) & 3u];
+        const uint64_t at = splitmix64(st) % (length - tract + 1);
+        for (uint32_t i = 0; i < tract; ++i) {
+            out[at + i] = u[i % unit];
+            if (out_class) out_class[at + i] = 251;
+        }
+        placed += tract;
+    }
+}
+
 // n reads of `len` bases: uniform start, forward strand, each base substituted by one of
 // the other three with probability err_per_million / 1e6.  out: n x len codes.
 void synth_reads(const uint8_t *genome, uint64_t glen, uint64_t n, uint32_t len, uint64_t seed,

@@ -35,7 +35,7 @@ def test_bench_contract(extra):
     assert r["value"] > 0 and roof["bound"] == "hbm" and roof["kernel_ms"] > 0
     # frac is counter traffic / kernel time / peak, or null when no PMC summary matches this (shrunk) configuration
     assert roof["frac"] is None or 0 < roof["frac"] <= 1.0
-    assert roof["algorithmic"]["bytes_per_launch"] > 0 and roof["algorithmic"]["GBps"] > 0
+    assert roof["reference_algorithm"]["bytes_per_launch"] > 0 and roof["reference_algorithm"]["GBps"] > 0 and roof["layout_algorithmic"]["bytes_per_query"] > 0
     assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["cores"] == 1
     assert "workload" in r["config"] and "model" not in r["config"]
 

@@ -14,6 +14,7 @@ import pytest
 
 import rust_msbwt_amd as msbwt
 import synth
+from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
 
@@ -23,7 +24,25 @@ def c2():
     npy, reads = synth.workload_index("c2")
     b = msbwt.RleBWT()
     b.load_numpy_file(npy)
+    b.npy = npy
     return b, reads
+
+
+def test_c2_batch_against_the_oracle(c2):
+    """configs[1] on its own inputs: the full 10 M random 21-mer batch is counted on the GPU and 10^5 of its queries, sampled
+    uniformly, are checked against the oracle on the same comp_msbwt.npy -- plus 10^5 read-derived 21-mers (present ones:
+    random 21-mers on a 3.3 Mbp genome almost all count 0)."""
+    b, reads = c2
+    ref = orc.OracleRleBWT(8)
+    ref.load_numpy_file(b.npy)
+    q = synth.random_kmers(10_000_000, 21, 3)          # the C2 batch itself (synth.CONFIGS["c2"]: qseed 3)
+    got = b.count_kmers(q)
+    ids = np.sort(np.random.default_rng(21).choice(len(q), size=100_000, replace=False))
+    assert np.array_equal(got[ids], ref.count_kmers(np.ascontiguousarray(q[ids]), nthreads=8))
+    rd = synth.read_kmers(reads, 21, limit=100_000, seed=22)
+    got_rd = b.count_kmers(rd)
+    assert np.array_equal(got_rd, ref.count_kmers(rd, nthreads=8))
+    assert got_rd.min() >= 1 and int((got[ids] > 0).sum()) < 1000
 
 
 def test_all_jmers_partition_the_text(c2):

@@ -549,12 +549,60 @@ def test_packed_table_escape_lines_on_long_run_streams(search_kernel):
         b.set_table_depth(3)
         b.set_table_packed(1)
         assert b.get_table_packed() and b.get_table_depth() == 5
+        info = b.table_info()
+        assert info["lines"] == (4 ** 5 + 29) // 30 and info["side_bytes"] == 512 * info["escape_lines"]
+        if kind == "long":
+            assert info["escape_lines"] > 0
         for k in (5, 6, 9, 14):
             qs = random_kmers(k + seed, 3000, k)
             assert np.array_equal(b.count_kmers(qs), o.count_kmers(qs)), (kind, k)
-        rep = b.replicate(0)     # a replica carries the packed table along
-        assert rep.get_table_packed() and rep.get_table_depth() == 5
+        rep = b.replicate(0)     # a replica carries the packed table (and its side array) along
+        assert rep.get_table_packed() and rep.get_table_depth() == 5 and rep.table_info() == info
         assert np.array_equal(rep.count_kmers(qs), o.count_kmers(qs))
+        # the same without the side array: queries of escape lines search from scratch (the round-3 behaviour)
+        b.set_table_side(0)
+        assert b.table_info()["side_bytes"] == 0 and b.table_info()["escape_lines"] == info["escape_lines"]
+        assert np.array_equal(b.count_kmers(qs), o.count_kmers(qs))
+
+
+def test_escape_lines_of_a_real_bwt_with_repeats_cost_one_line(search_kernel):
+    """A true multi-string BWT (reads of a genome with repeat families, synth.repeat_genome) large enough that EVERY line
+    of a depth-5 packed table holds more than 2^16 positions: all table lookups go through the side array.  Counts equal
+    the oracle's for read-derived 31-mers (matrix and fused windows) and for k == table depth; the search counters say
+    that every query took the escape route, none restarted -- and that all restart once the side array is switched off."""
+    import synth
+    needs_plane_blocks(search_kernel)
+    genome = synth.repeat_genome(200_000, 5)
+    reads = synth.reads(genome, 27_000, 150, 6, 0.005)
+    rle = synth.rle_encode(synth.build_msbwt_symbols(reads))
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    b.set_pair_index(1)
+    b.set_table_depth(3)
+    b.set_table_packed(1)
+    info = b.table_info()
+    # (the 35th line holds the last 4 of the 1024 entries: it may fit 16 bits)
+    assert b.get_table_depth() == 5 and info["lines"] == 35 and info["escape_lines"] >= 33 and info["side_bytes"] == info["escape_lines"] * 512
+    q31 = synth.read_kmers(reads, 31, limit=20_000, seed=3)
+    q5 = synth.read_kmers(reads, 5, limit=5_000, seed=4)
+    b.set_search_counters(True)
+    assert np.array_equal(b.count_kmers(q31), o.count_kmers(q31))
+    c = b.search_counters()
+    if b.search_kernel_for(31) == "lanes":   # present k-mers: every one passes the filter and lands on an escape line
+        assert 0.9 * len(q31) <= c["escape_queries"] <= len(q31) and c["escape_restarts"] == 0 and c["searched"] == len(q31)
+        assert c["lane_steps"] >= 7 * len(q31) + c["escape_queries"]   # seven pair steps, and one side-array line for the escaped
+    for qs in (q5, np.concatenate([q31[:1000], random_kmers(9, 1000, 31)])):
+        assert np.array_equal(b.count_kmers(qs), o.count_kmers(qs))
+    fwd, rc = b.count_read_kmers(reads[:300], 31, ascii=False)
+    win = np.lib.stride_tricks.sliding_window_view(reads[:300], 31, axis=1).reshape(-1, 31)
+    assert np.array_equal(fwd.reshape(-1), o.count_kmers(np.ascontiguousarray(win)))
+    b.search_counters()
+    b.set_table_side(0)
+    assert np.array_equal(b.count_kmers(q31), o.count_kmers(q31))
+    c = b.search_counters()
+    if b.search_kernel_for(31) == "lanes":
+        assert c["escape_queries"] == c["escape_restarts"] >= 0.9 * len(q31)
 
 
 def test_too_large_index_is_rejected():
@@ -702,6 +750,98 @@ def test_batch_order_keys_and_ordered_batches(search_kernel):
         order = np.argsort(host_keys, kind="stable")
         exp = o.count_kmers(qs)
         assert np.array_equal(b.count_kmers(qs[order]), exp[order])
+
+
+def _numpy_pack_2bit(qs):
+    """the packed layout restated with numpy: the k-mer as a base-4 number, first symbol most significant, 32 symbols per word"""
+    n, k = qs.shape
+    code = np.where(qs == 5, 3, qs.astype(np.int64) - 1).astype(np.uint64)
+    words = np.zeros((n, 2 if k > 32 else 1), dtype=np.uint64)
+    for t in range(k):   # step t = symbol k-1-t
+        words[:, t >> 5] |= code[:, k - 1 - t] << np.uint64(2 * (t & 31))
+    return words
+
+
+@pytest.mark.parametrize("k", [1, 5, 12, 17, 21, 31, 32, 33, 48, 64])
+def test_packed_two_bit_queries_count_like_the_byte_form(k, search_kernel):
+    """msbwt_rle_count_kmers_packed[_device]: 2-bit queries give the counts of the same k-mers as symbol codes (= the oracle's),
+    with 64- and 32-bit outputs, through the host pipeline and the device entry point, at batch sizes around the tile size."""
+    torch = pytest.importorskip("torch")
+    reads, rle = _real_bwt(7, 200, 80)
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    wins = [orc.convert_stoi(r[i:i + k]) for r in reads for i in (0, 3, 16) if len(r) >= i + k]
+    qs = np.array([w for w in wins if not np.isin(w, (0, 4)).any()], dtype=np.uint8).reshape(-1, k)
+    qs = np.concatenate([qs, random_kmers(k, 2000, k)])
+    words = msbwt.rle_bwt.pack_2bit(qs)
+    assert np.array_equal(words, _numpy_pack_2bit(qs))
+    exp = o.count_kmers(qs)
+    assert np.array_equal(b.count_kmers_packed(words, k), exp)
+    got32 = b.count_kmers_packed(words, k, count_bits=32)
+    assert got32.dtype == np.uint32 and np.array_equal(got32.astype(np.uint64), exp)
+    assert exp[:50].sum() > 0
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    d_w = torch.from_numpy(words.view(np.int64)).to(dev)
+    for n in (1, 63, 64, 65, 1000, len(qs)):
+        out = torch.full((n + 1,), -7, dtype=torch.int64, device=dev)
+        b.count_kmers_packed_device(d_w.data_ptr(), k, n, out.data_ptr(), stream)
+        b.device_status(stream)
+        got = out.cpu().numpy()
+        assert got[n] == -7 and np.array_equal(got[:n].astype(np.uint64), exp[:n]), n
+    with pytest.raises(msbwt.MsbwtError):
+        msbwt.rle_bwt.pack_2bit(np.array([[1, 2, 4]], dtype=np.uint8))
+
+
+@pytest.mark.parametrize("bits", [7, 10, 13, 22, 26])
+def test_in_library_batch_order_never_changes_results(bits, search_kernel, monkeypatch):
+    """msbwt_rle_set_batch_order(1): the library packs and bucket-orders the batch on the device (one global pass of up to 10
+    key bits, then up to two passes of 12 inside the buckets), counts it in index order and writes every count to its query's own place -- the caller sees the counts of
+    the unordered run (= the oracle's), for rows of symbol codes (with '$' / 'N' rows: the exception list) and for 2-bit
+    queries, through host and device entry points."""
+    import synth
+    torch = pytest.importorskip("torch")
+    needs_plane_blocks(search_kernel)
+    monkeypatch.setenv("MSBWT_ORDER_BITS", str(bits))
+    genome = synth.repeat_genome(40_000, 9)
+    reads = synth.reads(genome, 8_000, 100, 10, 0.01)
+    rle = synth.rle_encode(synth.build_msbwt_symbols(reads))
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    b.set_pair_index(1)
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rng = np.random.default_rng(bits)
+    for k in (12, 21, 31, 32, 33, 64):
+        qs = np.concatenate([synth.read_kmers(reads, k, limit=30_000, seed=k), random_kmers(k, 10_000, k)])
+        rng.shuffle(qs)
+        other = rng.integers(0, len(qs), size=500)                      # rows that two bits cannot say
+        qs[other, rng.integers(0, k, size=500)] = rng.choice([0, 4], size=500)
+        exp = o.count_kmers(qs, nthreads=4)
+        b.set_batch_order(0)
+        assert not b.batch_order_for(k, len(qs))
+        plain = b.count_kmers(qs)
+        b.set_batch_order(1)
+        assert b.batch_order_for(k, len(qs)) == (b.search_kernel_for(k) == "lanes")
+        assert np.array_equal(plain, exp) and np.array_equal(b.count_kmers(qs), exp), k
+        d_q = torch.from_numpy(qs).to(dev)
+        out = torch.full((len(qs) + 1,), -7, dtype=torch.int64, device=dev)
+        b.count_kmers_device(d_q.data_ptr(), k, len(qs), out.data_ptr(), stream)
+        b.device_status(stream)
+        got = out.cpu().numpy()
+        assert got[-1] == -7 and np.array_equal(got[:-1].astype(np.uint64), exp), k
+        acgt = ~np.isin(qs, (0, 4)).any(axis=1)
+        words = msbwt.rle_bwt.pack_2bit(qs[acgt])
+        assert np.array_equal(b.count_kmers_packed(words, k), exp[acgt]), k
+    # an invalid code is still reported, and only its own row is affected
+    bad = qs.copy()
+    bad[17, 3] = 7
+    b.set_batch_order(1)
+    with pytest.raises(msbwt.MsbwtError) as e:
+        b.count_kmers(bad)
+    assert e.value.code == msbwt._lib.ERR_INVALID_SYMBOL
 
 
 def test_introspection(search_kernel):

@@ -344,3 +344,38 @@ def test_missing_rccl_is_an_error_code_not_a_crash():
     done = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert done.returncode == 0, done.stderr[-400:]
     assert done.stdout.split() == [str(_lib.ERR_RCCL)] * 3, done.stdout + done.stderr[-400:]
+
+
+def test_memory_budget_plans():
+    """csrc/table_policy.hpp, plan_index, through msbwt_auto_index_plan (no device): what a memory budget
+    (msbwt_rle_set_memory_budget) makes of the configs -- plane blocks always, then pair blocks, then the deepest packed table
+    that fits, then overlapping pair blocks; no budget = the automatic choices of the two tests above."""
+    GB = 10 ** 9
+    hbm = 288 * 2 ** 30
+    plan = msbwt.auto_index_plan
+
+    def free(total):
+        return hbm - 2 * GB - (total // 256 + 1) * 128
+
+    c2, c4, human = 101_000_000, 1_946_213_783, 90_000_000_000
+    p = plan(c2, free(c2), hbm, 25.0, 0)
+    assert (p["pair_index"], p["pair_stride"], p["flat_depth"], p["packed_depth"]) == (True, 96, 15, 17) and 73 * GB < p["index_bytes"] < 74 * GB
+    p = plan(c2, free(c2), hbm, 25.0, 2 * GB)                # "C2 in 2 GB": everything but a shallower table
+    assert (p["pair_index"], p["pair_stride"], p["flat_depth"], p["packed_depth"]) == (True, 96, 12, 14) and p["index_bytes"] <= 2 * GB
+    p = plan(c4, free(c4), hbm, 23.0, 8 * GB)
+    assert (p["pair_index"], p["flat_depth"], p["packed_depth"]) == (True, 13, 15) and p["index_bytes"] <= 8 * GB
+    p = plan(c4, free(c4), hbm, 23.0, 2 * GB)                # 1 GB of plane blocks: no room for 2 GB of pair blocks
+    assert (p["pair_index"], p["packed_depth"]) == (False, 0) and 0 < p["flat_depth"] <= 12 and p["index_bytes"] <= 2 * GB
+    p = plan(human, free(human), hbm, 26.0, 0)
+    assert (p["pair_index"], p["pair_stride"], p["flat_depth"], p["packed_depth"]) == (True, 96, 15, 17)
+    p = plan(human, free(human), hbm, 26.0, 150 * GB)        # 45 + 90 GB of blocks, a depth-15 packed table in what is left
+    assert (p["pair_index"], p["pair_stride"], p["packed_depth"]) == (True, 128, 15) and p["index_bytes"] <= 150 * GB
+    p = plan(human, free(human), hbm, 26.0, 100 * GB)        # no room for pair blocks: plane blocks + a flat table
+    assert (p["pair_index"], p["packed_depth"]) == (False, 0) and p["flat_depth"] == 15 and p["index_bytes"] <= 100 * GB
+    p = plan(human, free(human), hbm, 26.0, 10 * GB)         # below the plane blocks themselves: they are built all the same
+    assert (p["pair_index"], p["flat_depth"], p["packed_depth"]) == (False, 0, 0) and p["index_bytes"] > 10 * GB
+    for total in (0, 10, 10 ** 6, 10 ** 9, 2 ** 39):
+        for budget in (0, 10 ** 6, GB, 50 * GB, 300 * GB):
+            p = plan(total, free(total) if total < 2 ** 38 else 10 * GB, hbm, 5.0, budget)
+            planes = (total // 256 + 1) * 128 if total else 128
+            assert p["packed_depth"] in (0, p["flat_depth"] + 2) and (budget == 0 or p["index_bytes"] <= max(budget, planes))

@@ -18,6 +18,19 @@ for _ in range(4):
     print("host API count_kmers: %.3e 21-mers/s (%.1f ms, %.2f GB/s in+out)" % (len(q) / dt, dt * 1e3, (q.nbytes + c.nbytes) / dt / 1e9), flush=True)
 sel = np.random.default_rng(1).choice(n, size=200_000, replace=False)
 assert np.array_equal(out[sel], ref.count_kmers(q[sel], nthreads=8)), "host path differs from the oracle"
+# the compact form: 2-bit packed 31-mers, 8 bytes in and 8 or 4 bytes out per query (msbwt_rle_count_kmers_packed)
+q31 = synth.random_kmers(n, 31, 5)
+w31 = m.rle_bwt.pack_2bit(q31)
+for bits in (64, 32):
+    o31 = np.zeros(n, dtype=np.uint64 if bits == 64 else np.uint32)
+    for _ in range(4):
+        t = time.time(); c = b.count_kmers_packed(w31, 31, count_bits=bits, out=o31); dt = time.time() - t
+        print("host API count_kmers_packed, %d-bit counts: %.3e 31-mers/s (%.1f ms, %.2f GB/s in+out)" % (bits, len(w31) / dt, dt * 1e3, (w31.nbytes + c.nbytes) / dt / 1e9), flush=True)
+    assert np.array_equal(c[sel].astype(np.uint64), ref.count_kmers(q31[sel], nthreads=8)), "packed host path differs from the oracle"
+for _ in range(3):
+    t = time.time(); c = b.count_kmers(q31, out=out); dt = time.time() - t
+    print("host API count_kmers (bytes), the same 31-mers: %.3e 31-mers/s (%.1f ms)" % (len(q31) / dt, dt * 1e3), flush=True)
+del q31, w31
 reads = rd
 of = np.zeros((reads.shape[0], reads.shape[1] - 30), dtype=np.uint64)
 oc = np.zeros_like(of)
