@@ -11,9 +11,12 @@ geometric select the independent-symbol stand-ins of rounds 1-2) -- and 3e8 PRES
 (LF-walk; every query runs all 31 steps -- the read-corrector case).  Extra keys of the default run:
   c5_random_1e9  the literal configs[4] line: 1e9 random 31-mers generated in HBM, sharded over the ranks
                  and gathered when N > 1;
-  c4_real_reads  (N = 1) the REAL multi-string BWT of config C4 (12.9 M reads, 1.95e9 symbols, built on the
-                 host in this run): 1e8 read-derived 31-mers -- what searches look like on real 30x data
-                 (ranges stay ~ coverage wide), with its own roofline and parity.
+  c4_repeats     (N = 1) the REAL multi-string BWT of a C4-sized read set (12.9 M reads with 0.5 % substitutions, 1.95e9
+                 symbols, suffix-sorted on the host in this run) of a genome WITH REPEATS (synth.REPEAT_FAMILIES): 1e8
+                 read-derived 31-mers, with parity, roofline and the kernel's own counters (lines per query, second-line rate,
+                 share of queries on escape lines of the packed table); `library_ordered` = the same with the library's own
+                 batch-ordering pass forced on;
+  c4_real_reads  the same on the random genome of rounds 2-3.
 Other workloads: c2, c3 (--fused = configs[2]), c4, big.
 
 --gpus N: one rank per GPU.  Launched plainly (no torchrun) the script starts torch.distributed.run
@@ -133,6 +136,7 @@ def parse_args(argv=None):
                     help="profiling passes only: skip parity, algorithmic-byte counters and the CPU baseline (prints a lean line)")
     ap.add_argument("--no-c5", action="store_true", help="skip the extra 1e9-random-31-mer line of the default workload")
     ap.add_argument("--no-c4", action="store_true", help="skip the extra real-MSBWT (config C4, read-derived 31-mers) line of the default workload")
+    ap.add_argument("--no-c4-random", action="store_true", help="default workload: only the repeat-bearing C4 line (c4_repeats), not the random-genome one (c4_real_reads)")
     ap.add_argument("--c4-scale", type=float, default=0.0, help="tests: run the extra C4 line on a shrunk C4 (0 = full size, only with --scale 1)")
     ap.add_argument("--c4-queries", type=int, default=100_000_000)
     ap.add_argument("--no-live-pmc", action="store_true",
@@ -149,7 +153,7 @@ def parse_args(argv=None):
                     help="one extra, untimed pass with the library's search counters on (msbwt_rle_set_search_counters): steps, second lines, "
                          "escape lines per query -> `search_counters` in the JSON line")
     ap.add_argument("--no-table-side", action="store_true", help="packed table without its side array: queries of escape lines search from scratch (round 3)")
-    ap.add_argument("--parity-sample", type=int, default=200_000)
+    ap.add_argument("--parity-sample", type=int, default=2_000_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     return ap.parse_args(argv)
 
@@ -406,6 +410,59 @@ def main():
 
     human = args.workload == "human"
     big = human or args.workload == "big"
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gpu_telemetry
+
+    def telemetry():
+        """clocks / power / temperature / memory of this rank's card, now (tools/gpu_telemetry.py: sysfs) -- what tells a slow box from a regression"""
+        pci = None
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:  # noqa: BLE001
+            pass
+        snap = gpu_telemetry.snapshot(local_rank, pci)
+        try:
+            free_b, total_b = torch.cuda.mem_get_info(dev)
+            snap["hip_free_bytes"], snap["hip_total_bytes"] = int(free_b), int(total_b)
+        except Exception:  # noqa: BLE001
+            pass
+        return snap
+
+    class EarlyIndexes:
+        """The C4-sized real MSBWTs of the default run's extra lines are suffix-sorted on the HOST (about a minute each): started
+        now, on a thread of their own, they are ready by the time the GPU has finished the human-scale lines."""
+
+        def __init__(self):
+            self.done, self.thread = {}, None
+
+        def start(self, names, scale):
+            import threading
+
+            def work():
+                for nm in names:
+                    t_b = time.time()
+                    try:
+                        self.done[(nm, scale)] = synth.workload_index(nm, scale)
+                        log("background: %s index built in %.1fs" % (nm, time.time() - t_b))
+                    except Exception as e:  # noqa: BLE001
+                        self.done[(nm, scale)] = e
+            self.thread = threading.Thread(target=work, daemon=True)
+            self.thread.start()
+
+        def get(self, nm, scale):
+            while (nm, scale) not in self.done and self.thread is not None and self.thread.is_alive():
+                self.thread.join(timeout=5.0)
+            got_it = self.done.get((nm, scale))
+            if isinstance(got_it, Exception):
+                raise got_it
+            return got_it if got_it is not None else synth.workload_index(nm, scale)
+
+    early_indexes = EarlyIndexes()
+    early_scale = args.c4_scale if args.c4_scale > 0 else (1.0 if args.scale == 1.0 else 0.0)
+    if human and world == 1 and not args.force_dist and not args.no_c4 and early_scale > 0 and rank == 0:
+        early_indexes.start(["c4r"] + ([] if args.no_c4_random else ["c4"]), early_scale)
     cfg = dict(synth.CONFIGS["c3" if big else args.workload])
     k = args.k or cfg["k"]
     kind = args.query_kind or ("walk" if big else cfg["queries"])
@@ -658,7 +715,9 @@ def main():
     main_batch = Batch(bwt, d_q, 0, d_reads)
     lo, hi, cap = shard(nq)
     mine_n = hi - lo
+    telemetry_before = telemetry()
     d_out, d_all, elapsed, kernel_ms, launches, narrow = measure(main_batch, lo, hi, cap)
+    telemetry_after = telemetry()
     # cross-rank consistency: a failed check does not abort the run (a crashed rank leaves no record at all); it is
     # reported in the JSON line and voids `value`
     inconsistent = []
@@ -814,6 +873,9 @@ def main():
             result["consistency_errors"] = inconsistent or ["%d check(s) failed on other ranks (see their stderr)" % int(bad.item())]
             for msg in inconsistent:
                 log("CONSISTENCY FAILURE: " + msg)
+    result["telemetry"] = {"after_timed_region": telemetry_after, "before_timed_region": telemetry_before,
+                           "note": "sysfs (amdgpu hwmon) snapshots of this card right before and right after the timed steps of the main line; "
+                                   "the extra lines carry their own"}
     if counters is not None:
         result["search_counters"] = counters
     if sorted_batch is not None:
@@ -917,70 +979,119 @@ def main():
                               "note": "%d sampled queries, static partition over all %d hardware threads of this box's share, same un-instrumented build" % (len(queries), nproc)},
             }
 
-    # ---- the REAL 30x MSBWT (config C4: 12.9 M reads WITH substitutions, 1.95e9 symbols, suffix-sorted on the host),
-    # read-derived 31-mers, one GPU: the human-scale index is an exact BWT too, but of error-free reads; this line carries
-    # reads with errors (14 % of their 31-mers end early) into the same record.
+    # ---- REAL 30x MSBWTs at config C4's size (12.9 M reads WITH substitutions, 1.95e9 symbols, suffix-sorted on the host while
+    # the GPU was busy with the lines above), read-derived 31-mers, one GPU:
+    #   c4_repeats     genome with repeat families, satellites and microsatellites (synth.REPEAT_FAMILIES): wide ranges, high-copy
+    #                  17-mers -- the packed table's escape lines --, with the kernel's own counters (lines, second lines, escapes);
+    #   c4_real_reads  the random genome of rounds 2-3 (the series those rounds quote).
+    # `library_ordered` = the same launch with the library's own batch-ordering pass forced on (automatic = off: it does not pay).
     c4_scale = args.c4_scale if args.c4_scale > 0 else (1.0 if args.scale == 1.0 else 0.0)
     if human and world == 1 and not multi and not args.no_c4 and c4_scale > 0 and rank == 0:
         del bwt, ref, rle, queries, got
         torch.cuda.empty_cache()
-        t0 = time.time()
-        cfg4 = synth.CONFIGS["c4"]
-        npy4, reads4 = synth.workload_index("c4", c4_scale)
-        log("c4 line: real MSBWT %s ready in %.1fs" % (os.path.basename(npy4), time.time() - t0))
-        t0 = time.time()
-        bwt4 = msbwt.RleBWT(device=local_rank)
-        bwt4.load_numpy_file(npy4)
-        total4 = bwt4.get_total_size()
-        n4 = max(1000, int(args.c4_queries * min(1.0, c4_scale * 4))) if c4_scale < 1.0 else args.c4_queries
-        q4 = synth.read_kmers(reads4, 31, limit=n4, seed=cfg4["qseed"])
-        n4 = len(q4)
-        d_q4 = torch.from_numpy(q4).to(dev)
-        log("c4 line: %d symbols on the GPU (%.1f MB, table depth %d, pair stride %d, typical range width %.1f), %d read-derived 31-mers in HBM in %.1fs"
-            % (total4, bwt4.device_bytes() / 1e6, bwt4.get_table_depth(), bwt4.get_pair_stride(), bwt4.get_typical_range_width(), n4, time.time() - t0))
-        b4 = Batch(bwt4, d_q4, 0, None, 31)
-        o4, _, el4, kms4, launches4, _ = measure(b4, 0, n4, n4)
-        c4 = {"value": n4 * args.steps / el4, "unit": "queries/s", "ms_per_step": el4 / args.steps * 1e3, "steps": args.steps,
-              "config": {"workload": "c4: the REAL multi-string BWT of %d synthetic %d-bp reads (%.0fx of a %d-bp random genome, %.1f%% substitutions), "
-                                     "%d symbols, built on the host in this run; %d read-derived 31-mers per step"
-                                     % (len(reads4), reads4.shape[1], len(reads4) * reads4.shape[1] / max(1, int(cfg4["genome"] * c4_scale)),
-                                        int(cfg4["genome"] * c4_scale), cfg4["err"] * 100, total4, n4),
-                         "k": 31, "queries_per_step": n4, "bwt_symbols": total4, "index_bytes": bwt4.device_bytes(), "table_depth": bwt4.get_table_depth(),
-                         "pair_stride": bwt4.get_pair_stride(), "typical_range_width": bwt4.get_typical_range_width()}}
-        if not args.no_oracle:
-            from oracle import oracle as orc
-            ref4 = orc.OracleRleBWT(8)
-            ref4.load_numpy_file(npy4)
-            ids4 = np.sort(np.random.default_rng(6).choice(n4, size=min(n4, max(args.parity_sample, args.stats_sample)), replace=False))
-            got4 = o4[torch.from_numpy(ids4).to(dev)].cpu().numpy().astype(np.uint64)
-            qs4 = q4[ids4]
-            ns4 = min(len(qs4), args.parity_sample)
-            exp4 = ref4.count_kmers(qs4[:ns4], nthreads=ncpu)
-            m4 = int((exp4 != got4[:ns4]).sum())
-            c4["parity"] = {"checked": int(ns4), "mismatches": m4, "nonzero_counts_in_sample": int((got4 > 0).sum()),
-                            "mean_count_in_sample": float(got4.mean())}
-            if m4:
-                log("PARITY FAILURE on the c4 line: %d sampled counts differ from the oracle" % m4)
-                result["value"] = None
-                rc = 1
-            tq, tsrc, tnote, stamp = lookup_traffic("c4", 31, bwt4, "reads", total4, False, c4_scale == 1.0)
-            c4["roofline"] = roofline_block(orc, ref4, qs4, 31, ncpu, n4, kms4 / 1e3 if launches4 else el4 / args.steps, kms4, launches4, tq, tsrc,
-                                            tnote, stamp, kernel_label(bwt4, 31, False), args.stats_sample, bwt4.get_table_depth(), bwt4.get_pair_index(),
-                                            bwt4.batch_order_for(31, n4))
-            if not args.no_cpu_baseline:
-                ncs4 = min(len(qs4), args.cpu_sample // 4)
-                t0 = time.time()
-                ref4.count_kmers(qs4[:ncs4], nthreads=1)
-                c4["cpu_baseline"] = {"value": ncs4 / (time.time() - t0), "unit": "queries/s", "cores": 1, "kind": "port",
-                                      "sample": "%d of the same queries, 1 thread" % ncs4}
-        else:
-            c4["roofline"] = {"kernel_ms": kms4, "kernel_launches": launches4}
-        result["c4_real_reads"] = c4
-        log("c4 line: %.3e q/s, %.2f ms per step" % (c4["value"], c4["ms_per_step"]))
+
+        def real_msbwt_line(name, key):
+            nonlocal rc
+            t0 = time.time()
+            cfg4 = synth.CONFIGS[name]
+            npy4, reads4 = early_indexes.get(name, c4_scale)
+            log("%s: real MSBWT %s ready after %.1fs of waiting" % (key, os.path.basename(npy4), time.time() - t0))
+            t0 = time.time()
+            bwt4 = msbwt.RleBWT(device=local_rank)
+            bwt4.load_numpy_file(npy4)
+            total4 = bwt4.get_total_size()
+            n4 = max(1000, int(args.c4_queries * min(1.0, c4_scale * 4))) if c4_scale < 1.0 else args.c4_queries
+            # the queries of synth.read_kmers (same seed, same draws), gathered on the GPU instead of the host
+            per = reads4.shape[1] - 31 + 1
+            if n4 >= len(reads4) * per:
+                d_q4 = torch.from_numpy(synth.read_kmers(reads4, 31)).to(dev)
+            else:
+                rng4 = np.random.default_rng(cfg4["qseed"])
+                r4 = torch.from_numpy(rng4.integers(0, len(reads4), size=n4)).to(dev)
+                p4 = torch.from_numpy(rng4.integers(0, per, size=n4)).to(dev)
+                d_reads4 = torch.from_numpy(reads4).to(dev)
+                d_q4 = torch.empty((n4, 31), dtype=torch.uint8, device=dev)
+                for lo_s in range(0, n4, 20_000_000):
+                    sl = slice(lo_s, lo_s + 20_000_000)
+                    d_q4[sl] = d_reads4[r4[sl, None], p4[sl, None] + torch.arange(31, device=dev)[None, :]]
+                del d_reads4, r4, p4
+            n4 = d_q4.shape[0]
+            log("%s: %d symbols on the GPU (%.1f MB, table depth %d, pair stride %d, typical range width %.1f), %d read-derived 31-mers in HBM in %.1fs"
+                % (key, total4, bwt4.device_bytes() / 1e6, bwt4.get_table_depth(), bwt4.get_pair_stride(), bwt4.get_typical_range_width(), n4, time.time() - t0))
+            b4 = Batch(bwt4, d_q4, 0, None, 31)
+            ordered = bwt4.batch_order_for(31, n4)
+            o4, _, el4, kms4, launches4, _ = measure(b4, 0, n4, n4)
+            line = {"value": n4 * args.steps / el4, "unit": "queries/s", "ms_per_step": el4 / args.steps * 1e3, "steps": args.steps,
+                    "batch_ordered_by_the_library": ordered,
+                    "config": {"workload": "%s: the REAL multi-string BWT of %d synthetic %d-bp reads (%.0fx of a %d-bp %s genome, %.1f%% substitutions), "
+                                           "%d symbols, built on the host in this run; %d read-derived 31-mers per step"
+                                           % (name, len(reads4), reads4.shape[1], len(reads4) * reads4.shape[1] / max(1, int(cfg4["genome"] * c4_scale)),
+                                              int(cfg4["genome"] * c4_scale),
+                                              "repeat-bearing (synth.REPEAT_FAMILIES: SINE-, LINE-, LTR-, DNA-element-like families, segmental duplications, "
+                                              "satellite arrays, microsatellites)" if cfg4.get("repeats") else "random", cfg4["err"] * 100, total4, n4),
+                               "k": 31, "queries_per_step": n4, "bwt_symbols": total4, "index_bytes": bwt4.device_bytes(), "table_depth": bwt4.get_table_depth(),
+                               "pair_stride": bwt4.get_pair_stride(), "typical_range_width": bwt4.get_typical_range_width(), "table": bwt4.table_info()}}
+            line["search_counters"] = counted_pass(bwt4, b4, 0, n4, n4)
+            # the same launch with the library's own batch-ordering pass forced on (msbwt_rle_set_batch_order(1); automatic = off, on
+            # these very numbers): pack + two bucket passes + ordered search + counts back to the caller's order, all timed
+            if not ordered:
+                bwt4.set_batch_order(1)
+                if bwt4.batch_order_for(31, n4):
+                    saved = args.steps
+                    args.steps = min(args.steps, 10)
+                    u4, _, uel4, ukms4, _, _ = measure(b4, 0, n4, n4)
+                    line["library_ordered"] = {"value": n4 * args.steps / uel4, "ms_per_step": uel4 / args.steps * 1e3, "kernels_ms": ukms4,
+                                               "counts_equal_unordered_run": bool(torch.equal(u4, o4)),
+                                               "note": "msbwt_rle_set_batch_order(1): the batch is packed, bucket-ordered by 22 key bits, counted in index order and "
+                                                       "its counts are returned to the caller's order inside the launch; kernels_ms = all of it"}
+                    if not line["library_ordered"]["counts_equal_unordered_run"]:
+                        log("PARITY FAILURE on %s: the library-ordered batch's counts differ from the unordered run's" % key)
+                        result["value"] = None
+                        rc = 1
+                    args.steps = saved
+                    del u4
+                bwt4.set_batch_order(-1)
+            if not args.no_oracle:
+                from oracle import oracle as orc
+                ref4 = orc.OracleRleBWT(8)
+                ref4.load_numpy_file(npy4)
+                ids4 = torch.from_numpy(np.sort(np.random.default_rng(6).choice(n4, size=min(n4, max(args.parity_sample, args.stats_sample)), replace=False))).to(dev)
+                got4 = o4[ids4].cpu().numpy().astype(np.uint64)
+                qs4 = d_q4[ids4].cpu().numpy()
+                ns4 = min(len(qs4), args.parity_sample)
+                exp4 = ref4.count_kmers(qs4[:ns4], nthreads=ncpu)
+                m4 = int((exp4 != got4[:ns4]).sum())
+                line["parity"] = {"checked": int(ns4), "mismatches": m4, "nonzero_counts_in_sample": int((got4 > 0).sum()),
+                                  "mean_count_in_sample": float(got4.mean()), "max_count_in_sample": int(got4.max())}
+                if m4:
+                    log("PARITY FAILURE on %s: %d sampled counts differ from the oracle" % (key, m4))
+                    result["value"] = None
+                    rc = 1
+                tq, tsrc, tnote, stamp = lookup_traffic(name, 31, bwt4, "reads", total4, False, c4_scale == 1.0)
+                line["roofline"] = roofline_block(orc, ref4, qs4, 31, ncpu, n4, kms4 / 1e3 if launches4 else el4 / args.steps, kms4, launches4, tq, tsrc,
+                                                  tnote, stamp, kernel_label(bwt4, 31, False), args.stats_sample, bwt4.get_table_depth(), bwt4.get_pair_index(), ordered)
+                if not args.no_cpu_baseline:
+                    ncs4 = min(len(qs4), args.cpu_sample // 4)
+                    t0 = time.time()
+                    ref4.count_kmers(qs4[:ncs4], nthreads=1)
+                    line["cpu_baseline"] = {"value": ncs4 / (time.time() - t0), "unit": "queries/s", "cores": 1, "kind": "port",
+                                            "sample": "%d of the same queries, 1 thread" % ncs4}
+            else:
+                line["roofline"] = {"kernel_ms": kms4, "kernel_launches": launches4}
+            line["telemetry"] = telemetry()
+            result[key] = line
+            log("%s: %.3e q/s, %.2f ms per step%s" % (key, line["value"], line["ms_per_step"],
+                                                      " (library-ordered: %.3e)" % line["library_ordered"]["value"] if "library_ordered" in line else ""))
+
+        real_msbwt_line("c4r", "c4_repeats")
+        torch.cuda.empty_cache()
+        if not args.no_c4_random:
+            real_msbwt_line("c4", "c4_real_reads")
+            torch.cuda.empty_cache()
     # ---- the default line's HBM traffic, measured in THIS run (the committed summary stays beside it) ---------------------
     if (human and rank == 0 and world == 1 and not multi and args.scale == 1.0 and not args.no_oracle and not args.no_live_pmc
             and args.stream == "reads" and not args.queries and "roofline" in result and result.get("value")):
-        bwt = bwt4 = ref = ref4 = b4 = d_q4 = o4 = None   # hand the GPU (and 30 GB of host memory) to the child passes
+        bwt = ref = None   # hand the GPU (and 30 GB of host memory) to the child passes
         import gc
         gc.collect()
         torch.cuda.empty_cache()

@@ -190,14 +190,16 @@ int msbwt_rle_allgather_counts(const msbwt_rle *bwt, void *comm, const void *d_m
  * 64-bit key to sort by (ascending), for callers that hold a sorted k-mer list anyway or count a batch more than once.
  * kmers: n x k symbol codes; a '$' / 'N' / invalid symbol among the (at most 31) symbols the key reads gives UINT64_MAX. */
 int msbwt_kmer_order_keys(const uint8_t *kmers, size_t k, size_t n, uint64_t *out_keys);
-/* Since round 4 the library orders DENSE batches itself, inside the launch: a bucket pass on the device by the top 22 key bits
- * (MSBWT_ORDER_BITS), the queries packed to two bits per symbol on the way; the search kernel counts the ordered batch and
- * writes every count to its query's own place in the caller's buffer -- the caller sees its order, only sooner.  mode -1 =
- * automatic (default): batches of at least 2^22 queries with at least two queries per 128 BWT positions, on an index large
- * enough to have no presence filter -- 10^8 read-derived 31-mers over a 2 x 10^9-symbol BWT: yes; 3 x 10^8 over 9 x 10^10: no
- * (the pass costs more than the order saves there); 0 = never, 1 = whenever the pass applies (pair index, 12 <= k <= 64,
- * 4096 <= n < 2^32).  MSBWT_ORDER=0|1|auto in the environment sets the initial mode.  Applies to msbwt_rle_count_kmers[_device]
- * and the packed forms.  msbwt_rle_batch_order_for: 1 if a batch of n k-symbol queries would be ordered now.  Results never change. */
+/* Since round 4 the library CAN order a batch itself, inside the launch: the queries are packed to two bits per symbol,
+ * bucket-ordered on the device by the top 22 key bits (MSBWT_ORDER_BITS) in two passes, counted in index order, and every count
+ * is returned to its query's own place in the caller's buffer -- the caller sees its order.  mode 1 = whenever the passes apply
+ * (pair index, 12 <= k <= 64, 4096 <= n < 2^32); 0 = never; -1 = automatic (default), which today means never: measured on one box,
+ * pass off / on, the densest batches gain a few per cent (10^8 read-derived 31-mers over a 2 x 10^9-symbol BWT 16.8 -> 16.1 ms, C3
+ * 3.13 -> 2.97) while sparse or random batches lose much more (human scale 55.7 -> 79.9 ms, random 31-mers 3.4 -> 9.3 ms): ordering
+ * 10^8 queries and un-ordering their counts costs about 6 ms of the 8 ms the ordered search saves.  A caller that
+ * holds its batch sorted anyway still gets the 2x (the keys above).  MSBWT_ORDER=0|1|auto in the environment sets the initial mode.
+ * Applies to msbwt_rle_count_kmers[_device] and the packed forms.  msbwt_rle_batch_order_for: 1 if a batch of n k-symbol queries
+ * would be ordered now.  Results never change. */
 int msbwt_rle_set_batch_order(msbwt_rle *bwt, int mode);
 int msbwt_rle_get_batch_order(const msbwt_rle *bwt);
 int msbwt_rle_batch_order_for(const msbwt_rle *bwt, size_t k, size_t n);

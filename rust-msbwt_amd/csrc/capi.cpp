@@ -76,7 +76,7 @@ struct msbwt_rle {
     uint64_t memory_budget = 0;  // bytes of HBM the index may hold (0 = no budget): msbwt_rle_set_memory_budget
     bool planned = false;        // a budget is in force: `plan` (table_policy.hpp, plan_index) decides the optional structures
     IndexPlan plan{};
-    int wanted_order = -1;   // batch order: -1 = automatic (dense batches on large indexes), 0 = never, 1 = whenever possible
+    int wanted_order = -1;   // batch order: 1 = whenever the passes apply; 0 and -1 (automatic: see order_pays) = never
     int order_bits = 22;     // key bits the bucket pass orders by (10 in the global pass + 12 inside each bucket)
     std::vector<TicketSlot> tickets;
     // device status block (128 bytes): word 0 = flags of the host-pointer entry points (handle
@@ -734,16 +734,18 @@ int timed_launch(msbwt_rle *h, hipStream_t stream, Launch &&launch) {
     return MSBWT_OK;
 }
 
-// Batch order (order.hip): is this launch worth a bucket pass?  Mode 1: whenever the pass applies (lanes kernel on a pair
-// index, 12 <= k <= 64, 4096 <= n < 2^32).  Automatic: a DENSE batch -- at least two queries per 128 positions of the BWT, so
-// that queries ordered next to each other share index lines -- of at least 2^22 queries, on an index without a presence
-// filter (with one, the index is small and most random queries end in the filter: nothing to order for).  Measured: C4,
-// 10^8 read-derived 31-mers (6.6 per 128 positions) pays; the human-scale default batch (0.4) does not.
+// Batch order (order.hip): is this launch to be put through the ordering passes?  Mode 1: whenever they apply (lanes kernel
+// on a pair index, 12 <= k <= 64, 4096 <= n < 2^32).  Automatic (-1, the default) is NEVER, on the measurements of round 4
+// (profiles/r04_lab/library_batch_order.log, one box, pass off / on): 10^8 read-derived 31-mers over the C4 index 16.8 ->
+// 16.1 ms, with repeats 18.9 -> 18.7, C3 3.13 -> 2.97 -- a few per cent where the batch is dense -- against 3.4 -> 9.3 ms on
+// random 31-mers (which end in the table: nothing to order for), 5.5 -> 6.6 on 3 x 10^7 queries and 55.7 -> 79.9 at human
+// scale.  The ordered search itself is worth 2x (8.4 ms when the caller hands the batch over sorted, msbwt_kmer_order_keys),
+// but packing, two bucket passes and returning the counts to the caller's order cost 6 ms of it for 10^8 queries, and the
+// search pays 1.7 ms more for a 22-bit order and placed count stores.  Nothing a launch knows beforehand tells the first
+// case from the others by a margin that would justify the risk, so the pass stays a switch.
 bool order_pays(msbwt_rle *h, const IndexView &v, size_t k, size_t n) {
-    if (h->wanted_order == 0 || v.block_format != kBlocksPlanes || v.pair_blocks == nullptr) return false;
-    if (k < 12 || k > 64 || n < 4096 || n > 0xFFFFFFFFull || !lanes_serves(v, uint32_t(k))) return false;
-    if (h->wanted_order > 0) return true;
-    return n >= (size_t(1) << 22) && double(n) * 128.0 >= 2.0 * double(v.total) && v.table.filter == nullptr;
+    if (h->wanted_order <= 0 || v.block_format != kBlocksPlanes || v.pair_blocks == nullptr) return false;
+    return k >= 12 && k <= 64 && n >= 4096 && n <= 0xFFFFFFFFull && lanes_serves(v, uint32_t(k));
 }
 
 // grows the slot's ordering scratch; false = no memory for it (the launch then runs unordered)
@@ -774,9 +776,11 @@ int launch_count(msbwt_rle *h, const uint8_t *d_kmers, size_t k, size_t n, uint6
                 const OrderPlan plan = plan_order(n, uint32_t(k), order_reach(v, k), uint32_t(h->order_bits), true);
                 if (ensure_order_scratch(slot, plan.scratch_bytes)) {
                     const uint64_t *ordered = nullptr;
-                    const uint32_t *index = nullptr;
-                    hipError_t e = launch_order_batch(plan, d_kmers, nullptr, slot.order_scratch, stream, &ordered, &index);
-                    if (e == hipSuccess) e = launch_count_packed(v, ordered, uint32_t(k), n, d_out, index, h->d_flags + which, stream);
+                    bool inline_place = false;
+                    uint64_t *counts = nullptr;
+                    hipError_t e = launch_order_batch(plan, d_kmers, nullptr, slot.order_scratch, stream, &ordered, &inline_place, &counts);
+                    if (e == hipSuccess) e = launch_count_packed(v, ordered, uint32_t(k), n, counts, nullptr, h->d_flags + which, stream, plan.words + 1, inline_place);
+                    if (e == hipSuccess) e = launch_order_finish(plan, slot.order_scratch, d_out, stream);
                     if (e == hipSuccess) e = launch_count_exceptions(plan, v.blocks, v.total, d_kmers, slot.order_scratch, d_out, h->d_flags + which, stream);
                     return e;
                 }
@@ -804,9 +808,11 @@ int launch_count_2bit(msbwt_rle *h, const uint64_t *d_packed, size_t k, size_t n
                 const OrderPlan plan = plan_order(n, uint32_t(k), order_reach(v, k), uint32_t(h->order_bits), false);
                 if (ensure_order_scratch(slot, plan.scratch_bytes)) {
                     const uint64_t *ordered = nullptr;
-                    const uint32_t *index = nullptr;
-                    hipError_t e = launch_order_batch(plan, nullptr, d_packed, slot.order_scratch, stream, &ordered, &index);
-                    if (e == hipSuccess) e = launch_count_packed(v, ordered, uint32_t(k), n, d_out, index, h->d_flags + which, stream);
+                    bool inline_place = false;
+                    uint64_t *counts = nullptr;
+                    hipError_t e = launch_order_batch(plan, nullptr, d_packed, slot.order_scratch, stream, &ordered, &inline_place, &counts);
+                    if (e == hipSuccess) e = launch_count_packed(v, ordered, uint32_t(k), n, counts, nullptr, h->d_flags + which, stream, plan.words + 1, inline_place);
+                    if (e == hipSuccess) e = launch_order_finish(plan, slot.order_scratch, d_out, stream);
                     return e;
                 }
             }

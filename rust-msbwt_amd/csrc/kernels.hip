@@ -494,8 +494,9 @@ hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_
 }
 
 hipError_t launch_count_packed(const IndexView &ix, const uint64_t *packed, uint32_t k, uint64_t n, uint64_t *counts,
-                               const uint32_t *out_index, uint32_t *flags, hipStream_t stream) {
-    if (k < 1 || k > uint32_t(kMaxTiledK) || ix.block_format != kBlocksPlanes || (out_index != nullptr && n > 0xFFFFFFFFull)) return hipErrorInvalidValue;
+                               const uint32_t *out_index, uint32_t *flags, hipStream_t stream, uint32_t stride_words, bool place_inline) {
+    if (k < 1 || k > uint32_t(kMaxTiledK) || ix.block_format != kBlocksPlanes || ((out_index != nullptr || place_inline) && n > 0xFFFFFFFFull))
+        return hipErrorInvalidValue;
     if (n == 0) return hipSuccess;
     QuerySource src{};
     src.data = reinterpret_cast<const uint8_t *>(packed);
@@ -504,10 +505,8 @@ hipError_t launch_count_packed(const IndexView &ix, const uint64_t *packed, uint
     src.out_fwd = counts;
     src.packed = 1;
     src.out_index = out_index;
-    if (out_index != nullptr) {
-        static const uint32_t mode = [] { const char *e = std::getenv("MSBWT_PLACED_STORE"); return e ? uint32_t(std::atoi(e)) : 0u; }();
-        src.placed_store = mode;
-    }
+    src.packed_stride = stride_words;
+    src.place_inline = place_inline ? 1u : 0u;
     return launch_lanes(ix, src, false, true, flags, stream);
 }
 

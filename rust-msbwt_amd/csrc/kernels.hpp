@@ -89,8 +89,10 @@ hipError_t launch_count_kmers(const IndexView &ix, const uint8_t *kmers, uint32_
 // The same for queries handed over as 2-bit words (n x ceil(k / 32) u64: the k-mer as a base-4 number, first symbol most
 // significant, A C G T -> 0..3; search_common.hpp, QuerySource::packed), 1 <= k <= 64, plane blocks: always the lanes
 // kernel.  out_index (optional, n < 2^32): query v's count goes to counts[out_index[v]] -- an ordered batch (order.hip).
+// stride_words (0 = ceil(k / 32)): u64 words from one query to the next; place_inline: the word after a query's own holds
+// the place of its count (low 32 bits) instead of out_index[] -- the elements the ordering passes produce.
 hipError_t launch_count_packed(const IndexView &ix, const uint64_t *packed, uint32_t k, uint64_t n, uint64_t *counts,
-                               const uint32_t *out_index, uint32_t *flags, hipStream_t stream);
+                               const uint32_t *out_index, uint32_t *flags, hipStream_t stream, uint32_t stride_words = 0, bool place_inline = false);
 // true when a count_kmers launch for k-symbol queries runs the lanes kernel (the only one that knows ix.done / inline queries)
 bool lanes_serves(const IndexView &ix, uint32_t k);
 

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     const double inv_windows = kReads ? 1.0 / double(src.windows) : 0.0;
     uint32_t staged_n0 = 0;  // wave-uniform
     uint32_t staged_out = 0, prep_out = 0;  // QuerySource::out_index: the output place of this lane's query of the fetched / the prepared tile
-    const bool placed = !kReads && src.out_index != nullptr;  // launch-uniform
+    const bool placed = !kReads && (src.out_index != nullptr || src.place_inline != 0u);  // launch-uniform
     auto place_of = [&](uint64_t v, uint32_t out) -> uint64_t { return placed ? uint64_t(out) : v; };
     auto fetch_tile_bytes = [&](uint64_t tile) {
         if (tile >= ntiles) return;
@@ -288,14 +288,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             if (src.out_index != nullptr && q0 + lane < n) staged_out = src.out_index[q0 + lane];
             if (src.packed != 0u) {  // this lane's own query: one or two u64 words, a tile is one coalesced load
                 if (q0 + lane < n) {
-                    const uint64_t *words = reinterpret_cast<const uint64_t *>(kmers) + (q0 + lane) * (kWords == 3 ? 1u : 2u);
-                    const uint2 a = *reinterpret_cast<const uint2 *>(words);
-                    staged_next[0].x = a.x;
-                    staged_next[0].y = a.y;
-                    if constexpr (kWords == 6) {
-                        const uint2 b = *reinterpret_cast<const uint2 *>(words + 1);
-                        staged_next[0].z = b.x;
-                        staged_next[0].w = b.y;
+                    constexpr uint32_t kOwn = kWords == 3 ? 1u : 2u;
+                    const uint32_t stride = src.packed_stride ? src.packed_stride : kOwn;
+                    const uint64_t *words = reinterpret_cast<const uint64_t *>(kmers) + (q0 + lane) * stride;
+                    if (kWords == 3 && src.place_inline != 0u) {  // {query, place}: one 16-byte load
+                        const uint4 e = *reinterpret_cast<const uint4 *>(words);
+                        staged_next[0].x = e.x;
+                        staged_next[0].y = e.y;
+                        staged_out = e.z;
+                    } else {
+                        const uint2 a = *reinterpret_cast<const uint2 *>(words);
+                        staged_next[0].x = a.x;
+                        staged_next[0].y = a.y;
+                        if constexpr (kWords == 6) {
+                            const uint2 b = *reinterpret_cast<const uint2 *>(words + 1);
+                            staged_next[0].z = b.x;
+                            staged_next[0].w = b.y;
+                        }
+                        if (src.place_inline != 0u) staged_out = *reinterpret_cast<const uint32_t *>(words + kOwn);
                     }
                 }
                 return;
@@ -693,7 +703,7 @@ hipError_t launch_shape(bool pair, bool longk, hipStream_t stream, const IndexVi
 hipError_t launch_lanes(const IndexView &ix, const QuerySource &src, bool reads, bool pair, uint32_t *flags,
                         hipStream_t stream) {
     if (src.k < 1 || src.k > uint32_t(kMaxTiledK)) return hipErrorInvalidValue;
-    if (!reads && (reinterpret_cast<uintptr_t>(src.data) & (src.packed ? 7u : 15u)) != 0) return hipErrorInvalidValue;
+    if (!reads && (reinterpret_cast<uintptr_t>(src.data) & ((src.packed && !src.place_inline) ? 7u : 15u)) != 0) return hipErrorInvalidValue;
     if (src.n == 0) return hipSuccess;
     pair = pair && ix.pair_blocks != nullptr;
     const bool longk = src.k > uint32_t(kMaxShortK);

@@ -13,23 +13,29 @@
 //     | the next up to 14 symbols to the left, kmer[k-18] most significant, in the low 28 bits;
 // a '$' / 'N' / invalid symbol among the symbols used gives UINT64_MAX (such queries sort last).
 //
-// The ordering pass (launch_order_batch) is a bucket sort by the top bits of that key, not a radix sort of all of it
-// (measured, C4, batch ordered outside the timed region by the top B bits only: 16.7 ms unordered, B = 12 14.4, 16 13.5,
-// 20 9.6, 24 and more 8.4):
-//   k_order_pack   rows of symbol codes -> 2-bit packed queries (8 bytes per 31-mer; the search kernel reads those directly,
-//                  QuerySource::packed) + per-workgroup histograms of the coarse bucket in LDS; a query that cannot be
-//                  packed ('$', 'N', an invalid code) goes onto an exception list and is counted from its row afterwards
-//                  (k_count_listed), in stream order, so its result is the one that stays;
-//   k_order_offsets / k_order_starts   histogram -> where each workgroup's share of each bucket starts;
-//   k_order_scatter   every query to its coarse bucket (LDS cursors), with its index in the caller's batch;
-//   k_order_level  one workgroup per bucket of the level before: a further bucket pass on the next bits, inside a window that
-//                  stays in L2 / the Infinity Cache.
-// The search kernel then counts the packed, ordered batch and writes every count to its query's own place in the
-// caller's buffer (QuerySource::out_index): nothing is moved back.
+// The ordering pass (launch_order_batch / launch_order_finish) is a two-level bucket sort by the top bits of that key, not a
+// radix sort of all of it (measured, C4, batch ordered outside the timed region by the top B bits only: 16.7 ms unordered,
+// B = 12 14.4, 16 13.5, 20 9.6, 24 and more 8.4).  Every pass is shaped so that what it scatters stays inside a window the L2
+// holds -- scattered 8-byte writes over the whole batch cost as much as the search saves (3.6 ms for 10^8 counts):
+//   k_order_pack     rows of symbol codes -> 2-bit packed queries (8 bytes per 31-mer; the search kernel reads those directly,
+//                    QuerySource::packed) + per-chunk histograms of the level-0 bucket; a query that cannot be packed ('$',
+//                    'N', an invalid code) goes onto an exception list and is counted from its row afterwards (k_count_listed),
+//                    in stream order, so its result is the one that stays;
+//   k_order_offsets / k_order_starts   histogram -> where each chunk's share of each bucket starts;
+//   k_order_scatter  level 0, the one global pass: a FEW persistent workgroups take the chunks in turn and send every query
+//                    to its bucket (LDS cursors) -- few, so that the lines being filled (one per bucket and array) stay in L2
+//                    until they are whole; with every workgroup of the chip at it they were written back in pieces;
+//   k_order_level    level 1: one workgroup per level-0 bucket splits it by the next key bits inside the bucket's own window,
+//                    and notes for every query WHERE IT CAME FROM in that window;
+//   (search)         the lanes kernel counts the packed, ordered batch and writes every count to that place: neighbouring
+//                    queries write into one window, not all over the batch;
+//   k_order_unsort   level 0 backwards, chunk by chunk: the counts of a chunk's queries are read from the buckets it sent
+//                    them to (runs of consecutive places) and written to the caller's buffer inside the chunk's own window.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 #include "order.hpp"
 #include "rank_ops.hpp"
@@ -111,11 +117,13 @@ __device__ __forceinline__ bool pack_row(const uint8_t *__restrict__ row, uint32
     return bad == 0u;
 }
 
-constexpr int kUnroll = 4;  // queries a thread has in flight per loop iteration (the passes are latency-bound otherwise)
+constexpr int kUnroll = 4;       // queries a thread of k_order_pack has in flight per loop iteration
+constexpr int kPassUnroll = 8;   // ... of the scatter passes (they are latency-bound otherwise)
+constexpr uint32_t kPassThreads = 1024;
 
-// Workgroup w owns the queries [w * chunk, min(n, (w + 1) * chunk)); hist[w * nbuckets + b] = how many of them fall into
-// level-0 bucket b.  With rows != nullptr the queries are packed here first (packed_out receives them); a row that cannot
-// be packed is appended to the exception list and travels on as an all-'A' query.
+// Chunk c = the queries [c * chunk, min(n, (c + 1) * chunk)), one workgroup each; hist[c * nbuckets + b] = how many of them
+// fall into level-0 bucket b.  With rows != nullptr the queries are packed here first (packed_out receives them); a row that
+// cannot be packed is appended to the exception list and travels on as an all-'A' query.
 template <int kWordsPerQuery>
 __global__ __launch_bounds__(256) void k_order_pack(const uint8_t *__restrict__ rows, const uint64_t *__restrict__ packed_in,
                                                     uint64_t *__restrict__ packed_out, uint32_t k, uint64_t n, uint32_t chunk, uint32_t reach,
@@ -158,12 +166,12 @@ __global__ __launch_bounds__(256) void k_order_pack(const uint8_t *__restrict__ 
     for (uint32_t b = threadIdx.x; b < nbuckets; b += kOrderThreads) hist[uint64_t(blockIdx.x) * nbuckets + b] = lds_hist[b];
 }
 
-// hist[w][b] -> the number of bucket-b queries in workgroups before w (in place); totals[b] = the bucket's size.  One workgroup
-// per bucket: its threads take the workgroups' counts in turn (a column of the histogram), scanned through LDS.
-__global__ __launch_bounds__(256) void k_order_offsets(uint32_t *__restrict__ hist, uint32_t nwg, uint32_t nbuckets, uint32_t *__restrict__ totals) {
+// hist[c][b] -> the number of bucket-b queries in chunks before c (in place); totals[b] = the bucket's size.  One workgroup
+// per bucket: its threads take the chunks' counts in turn (a column of the histogram), scanned through LDS.
+__global__ __launch_bounds__(256) void k_order_offsets(uint32_t *__restrict__ hist, uint32_t nchunks, uint32_t nbuckets, uint32_t *__restrict__ totals) {
     __shared__ uint32_t part[kOrderThreads];
     const uint32_t b = blockIdx.x;
-    const uint32_t per = (nwg + kOrderThreads - 1) / kOrderThreads, first = threadIdx.x * per, last = min(nwg, first + per);
+    const uint32_t per = (nchunks + kOrderThreads - 1) / kOrderThreads, first = threadIdx.x * per, last = min(nchunks, first + per);
     uint32_t sum = 0;
     for (uint32_t w = first; w < last; ++w) sum += hist[uint64_t(w) * nbuckets + b];
     part[threadIdx.x] = sum;
@@ -211,108 +219,201 @@ __global__ __launch_bounds__(256) void k_order_starts(const uint32_t *__restrict
     }
 }
 
-// Level 0, the one global pass: every query of workgroup w's chunk (the chunks of k_order_pack) to its place in its bucket.
-// Few buckets (2^10 at most), so that a workgroup's share of a bucket is a run of whole lines.
+// An ELEMENT of the ordered batch: the query's kWordsPerQuery words + one more word -- after level 0 its index in the caller's
+// batch, after level 1 its place after level 0 (where its count goes).  One array, one store per element: the passes are
+// bound by how many separate stores they issue (about 10^8 per millisecond), not by bytes.
 template <int kWordsPerQuery>
-__global__ __launch_bounds__(256) void k_order_scatter(const uint64_t *__restrict__ packed_in, uint64_t n, uint32_t chunk, uint32_t reach,
-                                                       uint32_t bits0, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ starts,
-                                                       uint64_t *__restrict__ packed_out, uint32_t *__restrict__ index_out) {
+__device__ __forceinline__ void store_element(uint64_t *__restrict__ out, uint64_t at, const uint64_t (&words)[kWordsPerQuery], uint32_t tag) {
+    if constexpr (kWordsPerQuery == 1) {
+        *reinterpret_cast<uint4 *>(out + at * 2) = make_uint4(uint32_t(words[0]), uint32_t(words[0] >> 32), tag, 0u);
+    } else {
+        out[at * 3] = words[0];
+        out[at * 3 + 1] = words[1];
+        out[at * 3 + 2] = tag;
+    }
+}
+
+// Level 0, the one global pass: the workgroups take the chunks of k_order_pack in turn; every query of a chunk goes to its
+// place in its bucket (LDS cursors), as an element that carries its index in the caller's batch.
+template <int kWordsPerQuery>
+__global__ __launch_bounds__(1024) void k_order_scatter(const uint64_t *__restrict__ packed_in, uint64_t n, uint32_t chunk, uint32_t nchunks,
+                                                        uint32_t reach, uint32_t bits0, const uint32_t *__restrict__ offsets,
+                                                        const uint32_t *__restrict__ starts, uint64_t *__restrict__ elems_out) {
     extern __shared__ uint32_t cursor[];
     const uint32_t nbuckets = 1u << bits0;
-    for (uint32_t b = threadIdx.x; b < nbuckets; b += kOrderThreads) cursor[b] = starts[b] + offsets[uint64_t(blockIdx.x) * nbuckets + b];
-    __syncthreads();
-    const uint64_t lo = uint64_t(blockIdx.x) * chunk, hi = min(n, lo + chunk);
-    for (uint64_t base = lo + threadIdx.x; base < hi; base += kOrderThreads * kUnroll) {
-        uint64_t words[kUnroll][kWordsPerQuery];
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        __syncthreads();  // (the previous chunk's cursors are no longer used)
+        for (uint32_t b = threadIdx.x; b < nbuckets; b += kPassThreads) cursor[b] = starts[b] + offsets[uint64_t(c) * nbuckets + b];
+        __syncthreads();
+        const uint64_t lo = uint64_t(c) * chunk, hi = min(n, lo + chunk);
+        for (uint64_t base = lo + threadIdx.x; base < hi; base += kPassThreads * kPassUnroll) {
+            uint64_t words[kPassUnroll][kWordsPerQuery];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            const uint64_t q = base + uint64_t(u) * kOrderThreads;
+            for (int u = 0; u < kPassUnroll; ++u) {
+                const uint64_t q = base + uint64_t(u) * kPassThreads;
 #pragma unroll
-            for (int w = 0; w < kWordsPerQuery; ++w) words[u][w] = q < hi ? packed_in[q * kWordsPerQuery + w] : 0ull;
-        }
+                for (int w = 0; w < kWordsPerQuery; ++w) words[u][w] = q < hi ? packed_in[q * kWordsPerQuery + w] : 0ull;
+            }
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            const uint64_t q = base + uint64_t(u) * kOrderThreads;
-            if (q >= hi) continue;
-            const uint32_t at = atomicAdd(&cursor[bucket_of(words[u][0], reach, 0u, bits0)], 1u);
-#pragma unroll
-            for (int w = 0; w < kWordsPerQuery; ++w) packed_out[uint64_t(at) * kWordsPerQuery + w] = words[u][w];
-            index_out[at] = uint32_t(q);
+            for (int u = 0; u < kPassUnroll; ++u) {
+                const uint64_t q = base + uint64_t(u) * kPassThreads;
+                if (q >= hi) continue;
+                const uint32_t at = atomicAdd(&cursor[bucket_of(words[u][0], reach, 0u, bits0)], 1u);
+                store_element<kWordsPerQuery>(elems_out, at, words[u], uint32_t(q));
+            }
         }
     }
 }
 
-// A further level: every bucket of the level before (`nparents` of them, parent_starts) is split once more by the NEXT `bits`
-// key bits -- count, scan, scatter, by ONE workgroup inside the bucket's own window (L2- or Infinity-Cache-resident), however
-// large the bucket is.  child_starts (optional): the starts of the nparents x 2^bits buckets of this level, + the end.
+// part[0 .. 1024) -> exclusive prefix sums + `base`, by the workgroup's first wave (16 values per lane, then across the lanes);
+// the caller synchronises before and after
+__device__ __forceinline__ void scan_1024(uint32_t *part, uint32_t base) {
+    if (threadIdx.x < 64u) {
+        uint32_t mine[16], total = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            mine[i] = total;
+            total += part[threadIdx.x * 16u + i];
+        }
+        uint32_t incl = total;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (int(threadIdx.x) >= d) incl += up;
+        }
+        const uint32_t before = base + incl - total;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part[threadIdx.x * 16u + i] = before + mine[i];
+    }
+}
+
+// Level 1: every level-0 bucket (`nparents` of them, parent_starts) is split once more by the NEXT `bits` key bits -- count,
+// scan, scatter, by ONE workgroup inside the bucket's own window, however large the bucket is.  The element written carries
+// the level-0 place the query came from: the search writes its count THERE (inside the same window), k_order_unsort takes
+// it from there.
 template <int kWordsPerQuery>
-__global__ __launch_bounds__(256) void k_order_level(const uint64_t *__restrict__ packed_in, const uint32_t *__restrict__ index_in,
-                                                     const uint32_t *__restrict__ parent_starts, uint32_t nparents, uint32_t reach, uint32_t drop,
-                                                     uint32_t bits, uint64_t *__restrict__ packed_out, uint32_t *__restrict__ index_out,
-                                                     uint32_t *__restrict__ child_starts) {
+__global__ __launch_bounds__(1024) void k_order_level(const uint64_t *__restrict__ elems_in, const uint32_t *__restrict__ parent_starts,
+                                                      uint32_t nparents, uint32_t reach, uint32_t drop, uint32_t bits,
+                                                      uint64_t *__restrict__ elems_out) {
+    constexpr uint32_t kStride = kWordsPerQuery + 1;
     extern __shared__ uint32_t fine[];  // 2^bits counters, then cursors
-    __shared__ uint32_t part[kOrderThreads];
+    __shared__ uint32_t part[kPassThreads];
     const uint32_t nfine = 1u << bits;
     for (uint32_t parent = blockIdx.x; parent < nparents; parent += gridDim.x) {
         const uint32_t lo = parent_starts[parent], hi = parent_starts[parent + 1];
         __syncthreads();  // (the previous parent's cursors are no longer read)
-        for (uint32_t b = threadIdx.x; b < nfine; b += kOrderThreads) fine[b] = 0u;
+        for (uint32_t b = threadIdx.x; b < nfine; b += kPassThreads) fine[b] = 0u;
         __syncthreads();
-        for (uint32_t base = lo + threadIdx.x; base < hi; base += kOrderThreads * kUnroll) {
-            uint64_t w0[kUnroll];
+        for (uint32_t base = lo + threadIdx.x; base < hi; base += kPassThreads * kPassUnroll) {
+            uint64_t w0[kPassUnroll];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                const uint32_t q = base + uint32_t(u) * kOrderThreads;
-                w0[u] = q < hi ? packed_in[uint64_t(q) * kWordsPerQuery] : 0ull;
+            for (int u = 0; u < kPassUnroll; ++u) {
+                const uint32_t q = base + uint32_t(u) * kPassThreads;
+                w0[u] = q < hi ? elems_in[uint64_t(q) * kStride] : 0ull;
             }
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
-                if (base + uint32_t(u) * kOrderThreads < hi) atomicAdd(&fine[bucket_of(w0[u], reach, drop, bits)], 1u);
+            for (int u = 0; u < kPassUnroll; ++u)
+                if (base + uint32_t(u) * kPassThreads < hi) atomicAdd(&fine[bucket_of(w0[u], reach, drop, bits)], 1u);
         }
         __syncthreads();
-        const uint32_t per = nfine / kOrderThreads > 0 ? nfine / kOrderThreads : 1u, first = threadIdx.x * per;
+        const uint32_t per = (nfine + kPassThreads - 1) / kPassThreads, first = threadIdx.x * per;
         uint32_t sum = 0;
         for (uint32_t i = first; i < min(nfine, first + per); ++i) sum += fine[i];
         part[threadIdx.x] = sum;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t acc = lo;
-            for (uint32_t t = 0; t < kOrderThreads; ++t) {
-                const uint32_t c = part[t];
-                part[t] = acc;
-                acc += c;
-            }
-        }
+        scan_1024(part, lo);
         __syncthreads();
         uint32_t acc = part[threadIdx.x];
         for (uint32_t i = first; i < min(nfine, first + per); ++i) {
             const uint32_t c = fine[i];
             fine[i] = acc;
-            if (child_starts != nullptr) child_starts[uint64_t(parent) * nfine + i] = acc;
             acc += c;
         }
-        if (child_starts != nullptr && parent + 1u == nparents && threadIdx.x == 0u) child_starts[uint64_t(nparents) * nfine] = hi;
         __syncthreads();
-        for (uint32_t base = lo + threadIdx.x; base < hi; base += kOrderThreads * kUnroll) {
-            uint64_t words[kUnroll][kWordsPerQuery];
-            uint32_t idx[kUnroll];
+        for (uint32_t base = lo + threadIdx.x; base < hi; base += kPassThreads * kPassUnroll) {
+            uint64_t words[kPassUnroll][kWordsPerQuery];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                const uint32_t q = base + uint32_t(u) * kOrderThreads;
+            for (int u = 0; u < kPassUnroll; ++u) {
+                const uint32_t q = base + uint32_t(u) * kPassThreads;
 #pragma unroll
-                for (int w = 0; w < kWordsPerQuery; ++w) words[u][w] = q < hi ? packed_in[uint64_t(q) * kWordsPerQuery + w] : 0ull;
-                idx[u] = q < hi ? index_in[q] : 0u;
+                for (int w = 0; w < kWordsPerQuery; ++w) words[u][w] = q < hi ? elems_in[uint64_t(q) * kStride + w] : 0ull;
             }
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                if (base + uint32_t(u) * kOrderThreads >= hi) continue;
+            for (int u = 0; u < kPassUnroll; ++u) {
+                const uint32_t q = base + uint32_t(u) * kPassThreads;
+                if (q >= hi) continue;
                 const uint32_t at = atomicAdd(&fine[bucket_of(words[u][0], reach, drop, bits)], 1u);
-#pragma unroll
-                for (int w = 0; w < kWordsPerQuery; ++w) packed_out[uint64_t(at) * kWordsPerQuery + w] = words[u][w];
-                index_out[at] = idx[u];
+                store_element<kWordsPerQuery>(elems_out, at, words[u], q);
             }
         }
     }
+}
+
+// Level 0 backwards, one workgroup per chunk: chunk c's queries sit in the buckets as runs of consecutive places -- bucket b:
+// from offsets[c][b] into the bucket, as many as the next chunk's offset says -- where the level-0 element names each one's
+// index in the caller's batch (inside the chunk's own window) and counts[] holds its count.  The runs are laid end to end
+// (their lengths scanned in LDS) and the threads walk that sequence, a wave reading neighbouring places; the counts are
+// gathered into the chunk's window IN LDS and leave for the caller's buffer as whole lines.
+__global__ __launch_bounds__(1024) void k_order_unsort(const uint64_t *__restrict__ counts, const uint64_t *__restrict__ elems0, uint32_t stride,
+                                                       const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ totals,
+                                                       const uint32_t *__restrict__ starts, uint64_t n, uint32_t chunk, uint32_t nchunks,
+                                                       uint32_t nbuckets, uint64_t *__restrict__ out) {
+    extern __shared__ uint64_t window[];  // chunk counts, then run_start[nbuckets], prefix[nbuckets + 1]
+    __shared__ uint32_t part[kPassThreads];
+    uint32_t *run_start = reinterpret_cast<uint32_t *>(window + chunk), *prefix = run_start + nbuckets;
+    const uint32_t c = blockIdx.x;
+    const uint64_t first_query = uint64_t(c) * chunk;
+    const uint32_t per = (nbuckets + kPassThreads - 1) / kPassThreads, first = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (uint32_t b = first; b < min(nbuckets, first + per); ++b) {
+        const uint32_t off = offsets[uint64_t(c) * nbuckets + b];
+        const uint32_t next = c + 1u < nchunks ? offsets[uint64_t(c + 1u) * nbuckets + b] : totals[b];
+        run_start[b] = starts[b] + off;
+        prefix[b] = next - off;  // the run's length, for now
+        sum += next - off;
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    scan_1024(part, 0u);
+    __syncthreads();
+    uint32_t acc = part[threadIdx.x];
+    for (uint32_t b = first; b < min(nbuckets, first + per); ++b) {
+        const uint32_t len = prefix[b];
+        prefix[b] = acc;
+        acc += len;
+    }
+    if (threadIdx.x == kPassThreads - 1u) prefix[nbuckets] = acc;
+    __syncthreads();
+    const uint32_t total = prefix[nbuckets];  // = the chunk's queries
+    for (uint32_t base = threadIdx.x; base < total; base += kPassThreads * kPassUnroll) {
+        uint32_t j[kPassUnroll], to[kPassUnroll];
+        uint64_t value[kPassUnroll];
+#pragma unroll
+        for (int u = 0; u < kPassUnroll; ++u) {
+            const uint32_t e = base + uint32_t(u) * kPassThreads;
+            j[u] = 0u;
+            if (e < total) {  // the run that holds element e: the last one that starts at or before it
+                uint32_t lo = 0, hi = nbuckets;
+                while (hi - lo > 1u) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (prefix[mid] <= e) lo = mid; else hi = mid;
+                }
+                j[u] = run_start[lo] + (e - prefix[lo]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kPassUnroll; ++u) {
+            const bool live = base + uint32_t(u) * kPassThreads < total;
+            to[u] = live ? uint32_t(elems0[uint64_t(j[u]) * stride + (stride - 1u)]) : 0u;
+            value[u] = live ? counts[j[u]] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < kPassUnroll; ++u)
+            if (base + uint32_t(u) * kPassThreads < total) window[to[u] - uint32_t(first_query)] = value[u];
+    }
+    __syncthreads();
+    const uint32_t mine = uint32_t(min(uint64_t(chunk), n - first_query));
+    for (uint32_t i = threadIdx.x; i < mine; i += kPassThreads) out[first_query + i] = window[i];
 }
 
 // counts[list[i]] = count_kmer(row list[i]) for the *nlist queries of the exception list (rows that two bits cannot say):
@@ -370,39 +471,41 @@ hipError_t launch_order_keys(const uint8_t *d_kmers, uint32_t k, uint64_t n, uin
     return hipGetLastError();
 }
 
+namespace {
+uint32_t env_or(const char *name, uint32_t fallback) {
+    const char *e = std::getenv(name);
+    return e && std::atoi(e) > 0 ? uint32_t(std::atoi(e)) : fallback;
+}
+}  // namespace
+
 OrderPlan plan_order(uint64_t n, uint32_t k, uint32_t reach, uint32_t bits, bool from_rows) {
     OrderPlan p{};
     p.n = n;
     p.k = k;
     p.words = k > 32u ? 2u : 1u;
     p.reach = std::min(std::max(reach, 1u), std::min(k, 32u));
-    bits = std::max(1u, std::min(std::min(bits, 2u * p.reach), 34u));
-    // Level 0 is the one GLOBAL pass: at most 10 bits, so that what a workgroup adds to a bucket is a run of whole lines
-    // (4096 buckets made 64-byte runs: 4.5 ms for 10^8 queries against 1 ms); the remaining bits follow in passes of at
-    // most 12 (LDS counters), each inside its parent bucket's window.
-    p.nlevels = 0;
-    for (uint32_t left = bits; left > 0 && p.nlevels < 3;) {
-        const uint32_t cap = p.nlevels == 0 ? 10u : 12u, take = std::min(left, cap);
-        p.level_bits[p.nlevels++] = take;
-        left -= take;
-    }
-    // chunks of about 64 Ki queries, at most 2048 workgroups, a multiple of the workgroup size
-    const uint64_t want = std::max<uint64_t>(1, std::min<uint64_t>(2048, (n + 65535) / 65536));
-    p.chunk = uint32_t(round_up((n + want - 1) / want, kOrderThreads));
-    p.nwg = uint32_t((n + p.chunk - 1) / p.chunk);
-    const uint64_t nb0 = 1ull << p.level_bits[0];
+    bits = std::max(1u, std::min(std::min(bits, 2u * p.reach), 23u));
+    // chunks of 16 Ki queries: a chunk's counts (128 KiB) fit the LDS of the workgroup that returns them to the caller's order
+    p.chunk = 16384;
+    p.nchunks = uint32_t((n + p.chunk - 1) / p.chunk);
+    // Level 0 is the one GLOBAL pass, at most 2^11 buckets: what a chunk adds to a bucket is then a run of about 8 elements,
+    // a whole line; the remaining bits (at most 12: LDS counters) follow in level 1, inside each bucket's window.
+    uint32_t b0 = 3;
+    while (b0 < 11u && (uint64_t(8) << (b0 + 1)) <= std::min<uint64_t>(p.chunk, n)) ++b0;
+    p.bits0 = std::min(b0, bits);
+    p.bits1 = std::min(bits - p.bits0, 12u);
+    p.wg0 = std::min(p.nchunks, env_or("MSBWT_ORDER_WG0", 1024));
+    p.wg1 = std::min(1u << p.bits0, env_or("MSBWT_ORDER_WG1", 128));
+    const uint64_t nb0 = 1ull << p.bits0;
     uint64_t at = 0;
     auto take = [&](uint64_t bytes) { const uint64_t here = at; at += round_up(bytes, 256); return here; };
-    // two (packed, index) buffers to ping-pong between the levels, + the packed batch in the caller's order when it arrives as rows
-    p.off_packed_rows = from_rows ? take(n * p.words * 8) : 0;
-    p.off_packed[0] = take(n * p.words * 8);
-    p.off_index[0] = take(n * 4);
-    p.off_packed[1] = p.nlevels > 1 ? take(n * p.words * 8) : p.off_packed[0];
-    p.off_index[1] = p.nlevels > 1 ? take(n * 4) : p.off_index[0];
-    p.off_hist = take(uint64_t(p.nwg) * nb0 * 4);
+    p.off_packed_rows = from_rows ? take(n * p.words * 8) : 0;   // the packed batch in the caller's order, when it arrives as rows
+    p.off_elems0 = take(n * (p.words + 1) * 8);                  // after level 0: {query, index in the caller's batch}
+    p.off_elems1 = p.bits1 ? take(n * (p.words + 1) * 8) : p.off_elems0;   // after level 1: {query, place after level 0}
+    p.off_counts = take(n * 8);                                  // the counts, by place after level 0
+    p.off_hist = take(uint64_t(p.nchunks) * nb0 * 4);
     p.off_totals = take(nb0 * 4);
-    p.off_starts[0] = take((nb0 + 1) * 4);
-    p.off_starts[1] = p.nlevels > 2 ? take(((nb0 << p.level_bits[1]) + 1) * 4) : 0;
+    p.off_starts = take((nb0 + 1) * 4);
     p.off_exceptions = take(from_rows ? n * 4 : 4);
     p.off_nexceptions = take(8);
     p.scratch_bytes = at;
@@ -411,52 +514,53 @@ OrderPlan plan_order(uint64_t n, uint32_t k, uint32_t reach, uint32_t bits, bool
 }
 
 hipError_t launch_order_batch(const OrderPlan &p, const uint8_t *d_rows, const uint64_t *d_packed, void *d_scratch, hipStream_t stream,
-                              const uint64_t **ordered, const uint32_t **out_index) {
-    if (p.n == 0 || p.n > 0xFFFFFFFFull || p.nlevels < 1 || (p.from_rows ? d_rows == nullptr : d_packed == nullptr)) return hipErrorInvalidValue;
+                              const uint64_t **ordered, bool *place_inline, uint64_t **counts) {
+    if (p.n == 0 || p.n > 0xFFFFFFFFull || (p.from_rows ? d_rows == nullptr : d_packed == nullptr)) return hipErrorInvalidValue;
     char *s = static_cast<char *>(d_scratch);
-    uint64_t *rows_packed = reinterpret_cast<uint64_t *>(s + p.off_packed_rows);
-    uint64_t *pk[2] = {reinterpret_cast<uint64_t *>(s + p.off_packed[0]), reinterpret_cast<uint64_t *>(s + p.off_packed[1])};
-    uint32_t *ix[2] = {reinterpret_cast<uint32_t *>(s + p.off_index[0]), reinterpret_cast<uint32_t *>(s + p.off_index[1])};
-    uint32_t *hist = reinterpret_cast<uint32_t *>(s + p.off_hist), *totals = reinterpret_cast<uint32_t *>(s + p.off_totals);
-    uint32_t *starts[2] = {reinterpret_cast<uint32_t *>(s + p.off_starts[0]), reinterpret_cast<uint32_t *>(s + p.off_starts[1])};
-    uint32_t *exceptions = reinterpret_cast<uint32_t *>(s + p.off_exceptions);
+    uint64_t *rows_packed = reinterpret_cast<uint64_t *>(s + p.off_packed_rows), *e0 = reinterpret_cast<uint64_t *>(s + p.off_elems0),
+             *e1 = reinterpret_cast<uint64_t *>(s + p.off_elems1);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(s + p.off_hist), *totals = reinterpret_cast<uint32_t *>(s + p.off_totals),
+             *starts = reinterpret_cast<uint32_t *>(s + p.off_starts), *exceptions = reinterpret_cast<uint32_t *>(s + p.off_exceptions);
     unsigned long long *nexc = reinterpret_cast<unsigned long long *>(s + p.off_nexceptions);
-    const uint32_t b0 = p.level_bits[0], nb0 = 1u << b0;
+    const uint32_t b0 = p.bits0, nb0 = 1u << b0;
     hipError_t e = hipMemsetAsync(nexc, 0, 8, stream);
     if (e != hipSuccess) return e;
     const uint64_t *src_packed = p.from_rows ? rows_packed : d_packed;
     if (p.words == 1)
-        hipLaunchKernelGGL((k_order_pack<1>), dim3(p.nwg), dim3(kOrderThreads), nb0 * 4, stream, p.from_rows ? d_rows : nullptr, d_packed, rows_packed, p.k, p.n,
-                           p.chunk, p.reach, b0, hist, exceptions, nexc);
+        hipLaunchKernelGGL((k_order_pack<1>), dim3(p.nchunks), dim3(kOrderThreads), nb0 * 4, stream, p.from_rows ? d_rows : nullptr, d_packed, rows_packed, p.k,
+                           p.n, p.chunk, p.reach, b0, hist, exceptions, nexc);
     else
-        hipLaunchKernelGGL((k_order_pack<2>), dim3(p.nwg), dim3(kOrderThreads), nb0 * 4, stream, p.from_rows ? d_rows : nullptr, d_packed, rows_packed, p.k, p.n,
-                           p.chunk, p.reach, b0, hist, exceptions, nexc);
-    hipLaunchKernelGGL(k_order_offsets, dim3(nb0), dim3(kOrderThreads), 0, stream, hist, p.nwg, nb0, totals);
-    hipLaunchKernelGGL(k_order_starts, dim3(1), dim3(kOrderThreads), 0, stream, totals, nb0, starts[0]);
+        hipLaunchKernelGGL((k_order_pack<2>), dim3(p.nchunks), dim3(kOrderThreads), nb0 * 4, stream, p.from_rows ? d_rows : nullptr, d_packed, rows_packed, p.k,
+                           p.n, p.chunk, p.reach, b0, hist, exceptions, nexc);
+    hipLaunchKernelGGL(k_order_offsets, dim3(nb0), dim3(kOrderThreads), 0, stream, hist, p.nchunks, nb0, totals);
+    hipLaunchKernelGGL(k_order_starts, dim3(1), dim3(kOrderThreads), 0, stream, totals, nb0, starts);
     if (p.words == 1)
-        hipLaunchKernelGGL((k_order_scatter<1>), dim3(p.nwg), dim3(kOrderThreads), nb0 * 4, stream, src_packed, p.n, p.chunk, p.reach, b0, hist, starts[0], pk[0], ix[0]);
+        hipLaunchKernelGGL((k_order_scatter<1>), dim3(p.wg0), dim3(kPassThreads), nb0 * 4, stream, src_packed, p.n, p.chunk, p.nchunks, p.reach, b0, hist, starts, e0);
     else
-        hipLaunchKernelGGL((k_order_scatter<2>), dim3(p.nwg), dim3(kOrderThreads), nb0 * 4, stream, src_packed, p.n, p.chunk, p.reach, b0, hist, starts[0], pk[0], ix[0]);
-    int cur = 0;
-    uint32_t drop = b0, nparents = nb0;
-    for (uint32_t level = 1; level < p.nlevels; ++level) {
-        const uint32_t bits = p.level_bits[level];
-        const bool more = level + 1 < p.nlevels;
-        const uint32_t *parents = starts[(level - 1) & 1];
-        uint32_t *children = more ? starts[level & 1] : nullptr;
-        const uint32_t grid = std::min<uint32_t>(nparents, 256u * 64u);
+        hipLaunchKernelGGL((k_order_scatter<2>), dim3(p.wg0), dim3(kPassThreads), nb0 * 4, stream, src_packed, p.n, p.chunk, p.nchunks, p.reach, b0, hist, starts, e0);
+    *ordered = e0;
+    *place_inline = false;  // one level only: the search counts in level-0 order and its counts are in place already
+    if (p.bits1) {
         if (p.words == 1)
-            hipLaunchKernelGGL((k_order_level<1>), dim3(grid), dim3(kOrderThreads), (1u << bits) * 4, stream, pk[cur], ix[cur], parents, nparents, p.reach, drop, bits,
-                               pk[cur ^ 1], ix[cur ^ 1], children);
+            hipLaunchKernelGGL((k_order_level<1>), dim3(p.wg1), dim3(kPassThreads), (1u << p.bits1) * 4, stream, e0, starts, nb0, p.reach, b0, p.bits1, e1);
         else
-            hipLaunchKernelGGL((k_order_level<2>), dim3(grid), dim3(kOrderThreads), (1u << bits) * 4, stream, pk[cur], ix[cur], parents, nparents, p.reach, drop, bits,
-                               pk[cur ^ 1], ix[cur ^ 1], children);
-        cur ^= 1;
-        drop += bits;
-        nparents <<= bits;
+            hipLaunchKernelGGL((k_order_level<2>), dim3(p.wg1), dim3(kPassThreads), (1u << p.bits1) * 4, stream, e0, starts, nb0, p.reach, b0, p.bits1, e1);
+        *ordered = e1;
+        *place_inline = true;
     }
-    *ordered = pk[cur];
-    *out_index = ix[cur];
+    *counts = reinterpret_cast<uint64_t *>(s + p.off_counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_order_finish(const OrderPlan &p, void *d_scratch, uint64_t *d_out, hipStream_t stream) {
+    char *s = static_cast<char *>(d_scratch);
+    const uint32_t nb0 = 1u << p.bits0;
+    const size_t lds = size_t(p.chunk) * 8 + (size_t(2) * nb0 + 1) * 4;
+    static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(k_order_unsort), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096 - 64);
+    if (raised != hipSuccess) return raised;
+    hipLaunchKernelGGL(k_order_unsort, dim3(p.nchunks), dim3(kPassThreads), lds, stream, reinterpret_cast<const uint64_t *>(s + p.off_counts),
+                       reinterpret_cast<const uint64_t *>(s + p.off_elems0), p.words + 1u, reinterpret_cast<const uint32_t *>(s + p.off_hist),
+                       reinterpret_cast<const uint32_t *>(s + p.off_totals), reinterpret_cast<const uint32_t *>(s + p.off_starts), p.n, p.chunk, p.nchunks, nb0, d_out);
     return hipGetLastError();
 }
 

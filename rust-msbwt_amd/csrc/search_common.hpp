@@ -43,7 +43,10 @@ struct QuerySource {
     // where query v's count goes: out_fwd[out_index[v]] (an ordered batch is counted in index order and its counts return to
     // the caller's order, order.hip); nullptr = out_fwd[v].  Matrix mode, lanes kernel; n <= 2^32.
     const uint32_t *out_index;
-    uint32_t placed_store;  // how the counts of a placed batch are stored (store_count)
+    // packed queries as ELEMENTS of packed_stride u64 words each (0 = just the ceil(k / 32) words); with place_inline the word
+    // after the query's own holds the place its count goes to (low 32 bits) -- one 16-byte load per 31-mer brings both
+    // (what the ordering passes of order.hip hand over: one store per element instead of two)
+    uint32_t packed_stride, place_inline;
 };
 
 namespace {
@@ -156,11 +159,9 @@ __device__ __forceinline__ uint4 load_piece(const uint8_t *__restrict__ src_byte
 template <bool kReads>
 __device__ __forceinline__ void store_count(const QuerySource &src, uint64_t v, uint64_t value) {
     if (!kReads) {
-        // counts that go to their queries' own places (an ordered batch) are scattered 8-byte writes: experiment switch
-        // 1 = non-temporal, 2 = write-through past the L2 (sc1), so that they do not push index lines out of it
-        if (src.placed_store == 2u) __hip_atomic_store(&src.out_fwd[v], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else if (src.placed_store == 1u) __builtin_nontemporal_store(value, &src.out_fwd[v]);
-        else src.out_fwd[v] = value;
+        // (the counts of a placed batch -- order.hip -- are scattered 8-byte stores; tried for them in round 4: non-temporal
+        // stores 18.1 ms against 18.5 ms plain on C4, write-through past the L2 (sc1) 18.7: not what they cost)
+        src.out_fwd[v] = value;
     } else if (src.strands == 3u) {
         ((v & 1u) ? src.out_rc : src.out_fwd)[v >> 1] = value;
     } else {

@@ -50,6 +50,14 @@ def test_bench_default_run_carries_the_real_msbwt_line():
     assert c4["roofline"]["kernel_ms"] > 0 and c4["config"]["k"] == 31 and "REAL" in c4["config"]["workload"]
     assert "EXACT multi-string BWT" in r["config"]["workload"] and r["parity"]["mismatches"] == 0
     assert r["config"]["typical_range_width"] > 8        # ... and so does the human-scale index's read set
+    # round 4: the repeat-bearing C4 line, with the kernel's own counters and the library's batch order before / after
+    rep = r["c4_repeats"]
+    assert rep["value"] > 0 and rep["parity"]["mismatches"] == 0 and "repeat-bearing" in rep["config"]["workload"]
+    counters = rep["search_counters"]
+    assert counters["lines_per_query"] > 1 and 0 <= counters["escape_query_fraction"] <= 1 and 0 <= counters["second_line_rate"] <= 1
+    assert rep["parity"]["max_count_in_sample"] > 4 * rep["parity"]["mean_count_in_sample"]   # repeats: some k-mers occur far more often than the coverage
+    assert not rep["batch_ordered_by_the_library"] and rep["library_ordered"]["counts_equal_unordered_run"] and rep["library_ordered"]["value"] > 0
+    assert r["roofline"]["layout_algorithmic"]["lines_per_query"] > 1 and "telemetry" in r
 
 
 def test_bench_default_is_the_metric_config():
