@@ -50,7 +50,7 @@ HUMAN_SYMBOLS = 9e10
 # everything that decides which bytes a query makes the kernel move: the kernels, the block layouts and their
 # builders, and the policies that pick table depth and pair spacing
 KERNEL_SOURCES = ["kernels.hip", "lanes.hip", "search_common.hpp", "rank_ops.hpp", "kernels.hpp", "plane_index.hpp",
-                  "pair_index.hip", "device_build.hip", "table_policy.hpp"]
+                  "pair_index.hip", "device_build.hip", "table_policy.hpp", "order.hip"]
 NARROW_MAX = 32767
 
 
@@ -414,15 +414,16 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gpu_telemetry
 
+    card_pci = None
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        card_pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except Exception:  # noqa: BLE001
+        pass
+
     def telemetry():
         """clocks / power / temperature / memory of this rank's card, now (tools/gpu_telemetry.py: sysfs) -- what tells a slow box from a regression"""
-        pci = None
-        try:
-            pr = torch.cuda.get_device_properties(dev)
-            pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
-        except Exception:  # noqa: BLE001
-            pass
-        snap = gpu_telemetry.snapshot(local_rank, pci)
+        snap = gpu_telemetry.snapshot(local_rank, card_pci)
         try:
             free_b, total_b = torch.cuda.mem_get_info(dev)
             snap["hip_free_bytes"], snap["hip_total_bytes"] = int(free_b), int(total_b)
@@ -668,9 +669,14 @@ def main():
             return d_mine, d_everything, float(flag[1].item()), k_ms, n_launch, flag[0].item() > 0
         return d_mine, d_everything, dt, k_ms, n_launch, False
 
+    last_sampled = {}
+
     def measure(batch, a, b, per_rank, native=None, exchange=True):
         narrow = multi and args.payload == "auto"
-        res = timed(batch, narrow, a, b, per_rank, native, exchange)
+        with gpu_telemetry.Sampler(local_rank, card_pci) as sampler:   # what the card did DURING these steps (warm-up included)
+            res = timed(batch, narrow, a, b, per_rank, native, exchange)
+        last_sampled.clear()
+        last_sampled.update(sampler.summary())
         if res[5]:  # some count did not fit int16: measure again with u64 payloads (always exact)
             log("counts exceed int16: re-running with 64-bit payloads")
             narrow = False
@@ -717,7 +723,7 @@ def main():
     mine_n = hi - lo
     telemetry_before = telemetry()
     d_out, d_all, elapsed, kernel_ms, launches, narrow = measure(main_batch, lo, hi, cap)
-    telemetry_after = telemetry()
+    telemetry_after, telemetry_during = telemetry(), dict(last_sampled)
     # cross-rank consistency: a failed check does not abort the run (a crashed rank leaves no record at all); it is
     # reported in the JSON line and voids `value`
     inconsistent = []
@@ -873,9 +879,9 @@ def main():
             result["consistency_errors"] = inconsistent or ["%d check(s) failed on other ranks (see their stderr)" % int(bad.item())]
             for msg in inconsistent:
                 log("CONSISTENCY FAILURE: " + msg)
-    result["telemetry"] = {"after_timed_region": telemetry_after, "before_timed_region": telemetry_before,
-                           "note": "sysfs (amdgpu hwmon) snapshots of this card right before and right after the timed steps of the main line; "
-                                   "the extra lines carry their own"}
+    result["telemetry"] = {"during_timed_region": telemetry_during, "after_timed_region": telemetry_after, "before_timed_region": telemetry_before,
+                           "note": "this card's clocks / power / temperatures from sysfs (amdgpu hwmon): sampled every 20 ms while the warm-up and timed steps "
+                                   "of the main line ran, and snapshots right before and after; the extra lines carry their own"}
     if counters is not None:
         result["search_counters"] = counters
     if sorted_batch is not None:
@@ -1021,6 +1027,7 @@ def main():
             b4 = Batch(bwt4, d_q4, 0, None, 31)
             ordered = bwt4.batch_order_for(31, n4)
             o4, _, el4, kms4, launches4, _ = measure(b4, 0, n4, n4)
+            sampled4 = dict(last_sampled)
             line = {"value": n4 * args.steps / el4, "unit": "queries/s", "ms_per_step": el4 / args.steps * 1e3, "steps": args.steps,
                     "batch_ordered_by_the_library": ordered,
                     "config": {"workload": "%s: the REAL multi-string BWT of %d synthetic %d-bp reads (%.0fx of a %d-bp %s genome, %.1f%% substitutions), "
@@ -1078,7 +1085,7 @@ def main():
                                             "sample": "%d of the same queries, 1 thread" % ncs4}
             else:
                 line["roofline"] = {"kernel_ms": kms4, "kernel_launches": launches4}
-            line["telemetry"] = telemetry()
+            line["telemetry"] = {"during_timed_region": dict(sampled4), "after": telemetry()}
             result[key] = line
             log("%s: %.3e q/s, %.2f ms per step%s" % (key, line["value"], line["ms_per_step"],
                                                       " (library-ordered: %.3e)" % line["library_ordered"]["value"] if "library_ordered" in line else ""))

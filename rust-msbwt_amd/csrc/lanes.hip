@@ -140,6 +140,77 @@ __device__ __forceinline__ uint64_t plane_line_bound(const PlaneLine &L, uint32_
     return ((uint64_t(hi) << 32) | lo) + cnt;
 }
 
+// ---- rank of one bound from a staged RUN-block line (run_index.hpp: header + 96 one-byte runs for 512 positions) ----------
+// The lane decodes its own line: per dword of four runs, the lengths (x >> 3 & 31 per byte), a byte mask of the runs whose
+// symbol is s, and two sums of absolute differences -- all four lengths, and the matching ones.  A dword that ends at or
+// before the position adds its matching lengths whole; the ONE dword that straddles the position is kept and finished run
+// by run afterwards.  An OVERFLOW block (more than 96 pieces) holds no runs: *need receives the 1-based number of the plane
+// block, in the side array, that holds the position (the caller fetches that line in its next iteration).
+// Measured at human scale on one box (tools/build_variant.sh, 10^8 present 31-mers): one decode per bound 1.79 x 10^9 q/s
+// (chunk loop unrolled by three: 1.77), ONE decode for both bounds of a range inside one block 1.59-1.60 whatever the
+// unrolling -- fully unrolled it spills, and the lane-varying "both" costs more than the second decode saves.
+#ifndef MSBWT_RUNS_FUSED  // 1 = one decode for both bounds of a range inside one block, 0 = one per bound
+#define MSBWT_RUNS_FUSED 0
+#endif
+#ifndef MSBWT_RUNS_UNROLL  // 16-byte chunks of runs per loop iteration (6 = all at once)
+#define MSBWT_RUNS_UNROLL 6
+#endif
+// Both bounds of a range at once when they lie in ONE run block (`both`; most ranges do: 512 positions per block): lengths,
+// match masks and sums are computed once per dword, only the comparisons with the two positions are done twice.
+__device__ __forceinline__ void run_line_bounds(const uint4 *lines, uint32_t slot, uint32_t s, uint64_t pos_l, uint64_t pos_h, bool both,
+                                                uint64_t &out_l, uint64_t &out_h, uint32_t &need_l, uint32_t &need_h) {
+    const uint32_t base = line_base(slot), g = slot & 7u;
+    const uint4 c0 = lines[base + (0u ^ g)], c1 = lines[base + (1u ^ g)];
+    if ((c1.w & 0x80000000u) != 0u) {
+        const uint32_t first = lines[base + (2u ^ g)].x * 2u + 1u;
+        need_l = first + ((uint32_t(pos_l) & 511u) >> 8);
+        if (both) need_h = first + ((uint32_t(pos_h) & 511u) >> 8);
+        return;
+    }
+    const uint32_t lo = s == 0u ? c0.x : s == 1u ? c0.y : s == 2u ? c0.z : s == 3u ? c0.w : s == 4u ? c1.x : c1.y;
+    const uint32_t hi = (((s >> 2) ? c1.w : c1.z) >> ((s & 3u) * 8u)) & 0xFFu;
+    const uint32_t r0 = uint32_t(pos_l) & 511u, r1 = uint32_t(pos_h) & 511u, sx = s * 0x01010101u;
+    uint32_t cnt0 = 0, cnt1 = 0, cur = 0, str0 = 0, at0 = 0, str1 = 0, at1 = 0;
+#pragma unroll MSBWT_RUNS_UNROLL  // (fully unrolled, the six 16-byte LDS reads are all hoisted to the top: with both bounds in one pass the kernel spills)
+    for (uint32_t j = 2; j < 8; ++j) {
+        const uint4 c = lines[base + (j ^ g)];
+        const uint32_t word[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t x = word[i], lens = (x >> 3) & 0x1F1F1F1Fu, t = (x & 0x07070707u) ^ sx;
+            const uint32_t other = ((t + 0x7F7F7F7Fu) | t) & 0x80808080u;        // bit 7 of a byte: its run's symbol is NOT s
+            const uint32_t match = ((other ^ 0x80808080u) >> 7) * 0xFFu;          // 0xFF in the bytes of the runs of s
+            const uint32_t all = __builtin_amdgcn_sad_u8(lens, 0u, 0u), mine = __builtin_amdgcn_sad_u8(lens & match, 0u, 0u);
+            const uint32_t end = cur + all;
+            cnt0 += end <= r0 ? mine : 0u;
+            const bool across0 = cur < r0 && end > r0;
+            str0 = across0 ? x : str0;
+            at0 = across0 ? cur : at0;
+            if (both) {
+                cnt1 += end <= r1 ? mine : 0u;
+                const bool across1 = cur < r1 && end > r1;
+                str1 = across1 ? x : str1;
+                at1 = across1 ? cur : at1;
+            }
+            cur = end;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {  // (a straddler of 0 when no dword straddles the position: four empty runs)
+        const uint32_t run0 = (str0 >> (8 * b)) & 0xFFu, len0 = run0 >> 3;
+        cnt0 += (run0 & 7u) == s ? uint32_t(min(max(int(r0) - int(at0), 0), int(len0))) : 0u;
+        at0 += len0;
+        if (both) {
+            const uint32_t run1 = (str1 >> (8 * b)) & 0xFFu, len1 = run1 >> 3;
+            cnt1 += (run1 & 7u) == s ? uint32_t(min(max(int(r1) - int(at1), 0), int(len1))) : 0u;
+            at1 += len1;
+        }
+    }
+    const uint64_t a = (uint64_t(hi) << 32) | lo;
+    out_l = a + cnt0;
+    if (both) out_h = a + cnt1;
+}
+
 // ---- rank of one bound from a staged pair-block line (two-symbol step, rank_ops.hpp layout) -----
 struct PairLine {
     uint32_t m[4];   // per 32 positions: 1 where (S, S2) == (a, b)
@@ -183,8 +254,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                                                           const uint64_t *__restrict__ pair_super, const QuerySource src,
                                                           uint32_t *__restrict__ flags, uint64_t *__restrict__ debug,
                                                           unsigned long long *__restrict__ tile_counter, uint32_t grain,
-                                                          uint64_t *__restrict__ done, uint64_t done_seq, uint64_t *__restrict__ counters) {
+                                                          uint64_t *__restrict__ done, uint64_t done_seq, uint64_t *__restrict__ counters,
+                                                          uint32_t format, const uint4 *__restrict__ run_overflow) {
     using Scratch = LaneScratchT<kWords>;
+    // run blocks (run_index.hpp; launch-uniform): `blocks` are 128-byte lines of 512 positions with 96 one-byte runs, decoded
+    // by the lane that owns the query; single-symbol steps only (the kPair instantiations never see them)
+    const bool runs = !kPair && kWords == 3 && format != 0u;  // (k <= 32 only: the long instantiation has no registers to spare)
     using RingItem = RingItemT<kWords>;
     constexpr int kPieces = Scratch::kMaxK / 16;  // 16-byte pieces of a tile per lane: 2 or 4
     constexpr int kRegions = Scratch::kRegions, kLineSlots = Scratch::kLineSlots;
@@ -249,6 +324,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     // the lane's running query
     bool have = false;
     bool esc = false;  // the query's range is still in the side array of the packed table: l = index of its entry there
+    uint32_t ovf_l = 0, ovf_h = 0;  // run blocks: 1 + the overflow plane block this bound is to be ranked from (0: its run block)
     uint64_t l = 0, h = 0;
     uint32_t w[kWords], rem = 0;
     uint64_t qid = 0;  // where the count of the lane's query goes (its global index, or its place by QuerySource::out_index)
@@ -405,6 +481,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 rem = (it.meta >> 16) & 0xFFu;
                 qid = place_of(ring_tile * kTile + ((it.meta >> 24) & 0x7Fu), it.out);
                 esc = (it.meta >> 31) != 0u;
+                ovf_l = ovf_h = 0u;
                 have = true;
             }
             const uint32_t taken = min(ring_count, uint32_t(__popcll(idle)));
@@ -543,7 +620,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
         const bool same = esc || (pair ? (h - start_l) < 128u : (h >> 8) == bl);
         const uint64_t bh = same ? bl : (pair ? pair_block_of(h, s96) : h >> 8);
         const uint32_t r_l = uint32_t(l - start_l), r_h = uint32_t(h - (same ? start_l : (pair ? pair_block_start(bh, s96) : bh << 8)));
-        const bool second = have && !same;
+        uint64_t line_l = base + bl * 128u, line_h = base + bh * 128u;
+        bool one_line = same;
+        if (!kPair && kWords == 3 && runs && !esc) {  // a bound's line: its run block, or -- found out in the iteration before -- its overflow plane block
+            line_l = ovf_l != 0u ? reinterpret_cast<uint64_t>(run_overflow) + uint64_t(ovf_l - 1u) * 128u : reinterpret_cast<uint64_t>(blocks) + (l >> 9) * 128u;
+            line_h = ovf_h != 0u ? reinterpret_cast<uint64_t>(run_overflow) + uint64_t(ovf_h - 1u) * 128u : reinterpret_cast<uint64_t>(blocks) + (h >> 9) * 128u;
+            one_line = line_l == line_h;
+        }
+        const bool second = have && !one_line;
         const uint64_t second_mask = __ballot(second);
         const uint32_t second_rank = __builtin_amdgcn_mbcnt_hi(uint32_t(second_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(second_mask), 0u));
         const uint32_t nsecond = min(uint32_t(__popcll(second_mask)), kMaxSecond);
@@ -551,8 +635,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
         // takes the step in the next iteration)
         const bool act = have && !(second && second_rank >= kMaxSecond);
         const uint32_t slot_l = lane, slot_h = second ? 64u + second_rank : lane;
-        list[lane] = act ? base + bl * 128u : dummy;
-        if (second && act) list[slot_h] = base + bh * 128u;
+        list[lane] = act ? line_l : dummy;
+        if (second && act) list[slot_h] = line_h;
         if (lane < 8u && 64u + nsecond + lane < uint32_t(kLineSlots)) list[64u + nsecond + lane] = dummy;  // the ragged end of the last second-bound region
         // pair steps: K[a][b] + occ2 at the superblock start (L2-resident table).  One 8-byte load per lane
         // is a separate L2 request each (64 per wave): the second bound's base is fetched only in the rare
@@ -592,6 +676,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
         }
         if (act) {
             uint64_t nl, nh;
+            bool step_done = true;
             if (esc) {  // the flat {l, h} entry of this query's table index: no symbol is consumed
                 const uint4 e = ws.lines[line_base(slot_l) + ((uint32_t(l) & 7u) ^ (slot_l & 7u))];
                 nl = (uint64_t(e.y) << 32) | e.x;
@@ -606,6 +691,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 nh = pair_line_bound(L, far != 0u ? super_far : super_l, r_h);
                 consume_symbols<kWords>(w, 6);
                 rem -= 2u;
+            } else if (!kPair && kWords == 3 && runs) {
+                uint32_t need_l = 0, need_h = 0;
+                PlaneLine L;
+                nl = nh = 0;
+                const bool together = MSBWT_RUNS_FUSED != 0 && one_line && ovf_l == 0u && ovf_h == 0u;  // both bounds from one run block: one decode
+                if (ovf_l != 0u) {
+                    read_plane_line(ws.lines, slot_l, s1, L);
+                    nl = plane_line_bound(L, s1, l);
+                } else {
+                    run_line_bounds(ws.lines, slot_l, s1, l, h, together, nl, nh, need_l, need_h);
+                }
+                if (ovf_h != 0u) {
+                    read_plane_line(ws.lines, slot_h, s1, L);
+                    nh = plane_line_bound(L, s1, h);
+                } else if (!together) {
+                    uint64_t unused = 0;
+                    uint32_t unused_need = 0;
+                    run_line_bounds(ws.lines, slot_h, s1, h, h, false, nh, unused, need_h, unused_need);
+                }
+                if ((need_l | need_h) != 0u) {  // an overflow block: the step is taken again with that bound's plane block fetched
+                    ovf_l = ovf_l != 0u ? ovf_l : need_l;
+                    ovf_h = ovf_h != 0u ? ovf_h : need_h;
+                    step_done = false;
+                } else {
+                    ovf_l = ovf_h = 0u;
+                    consume_symbols<kWords>(w, 3);
+                    --rem;
+                }
             } else {
                 PlaneLine L;
                 read_plane_line(ws.lines, slot_l, s1, L);
@@ -615,11 +728,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 consume_symbols<kWords>(w, 3);
                 --rem;
             }
-            l = nl;
-            h = nh;
-            if (rem == 0u || l == h) {
-                store_count<kReads>(src, qid, h - l);
-                have = false;
+            if (step_done) {
+                l = nl;
+                h = nh;
+                if (rem == 0u || l == h) {
+                    store_count<kReads>(src, qid, h - l);
+                    have = false;
+                }
             }
         }
         wave_lds_sync();  // the next iteration overwrites the lines
@@ -687,7 +802,8 @@ hipError_t launch_variant(hipStream_t stream, const IndexView &ix, const QuerySo
     hipLaunchKernelGGL((k_count_kmers_lanes<kReads, kPair, kWords, kStride96>), dim3(uint32_t(waves)), dim3(64), 0, stream,
                        static_cast<const uint4 *>(ix.blocks), ix.total, table, uint32_t(ix.table.depth), ix.table.packed ? 1u : 0u, filter, filter_mask,
                        table ? static_cast<const uint4 *>(ix.table.side) : nullptr, static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags, ix.debug,
-                       tickets ? static_cast<unsigned long long *>(ix.tile_counter) : nullptr, grain, waves == 1 ? ix.done : nullptr, ix.done_seq, ix.counters);
+                       tickets ? static_cast<unsigned long long *>(ix.tile_counter) : nullptr, grain, waves == 1 ? ix.done : nullptr, ix.done_seq, ix.counters,
+                       uint32_t(ix.block_format), static_cast<const uint4 *>(ix.overflow));
     return hipGetLastError();
 }
 
@@ -705,7 +821,8 @@ hipError_t launch_lanes(const IndexView &ix, const QuerySource &src, bool reads,
     if (src.k < 1 || src.k > uint32_t(kMaxTiledK)) return hipErrorInvalidValue;
     if (!reads && (reinterpret_cast<uintptr_t>(src.data) & ((src.packed && !src.place_inline) ? 7u : 15u)) != 0) return hipErrorInvalidValue;
     if (src.n == 0) return hipSuccess;
-    pair = pair && ix.pair_blocks != nullptr;
+    pair = pair && ix.pair_blocks != nullptr && ix.block_format == kBlocksPlanes;
+    if (ix.block_format != kBlocksPlanes && src.packed) return hipErrorInvalidValue;  // (packed queries on run blocks are unpacked by the caller)
     const bool longk = src.k > uint32_t(kMaxShortK);
     return reads ? launch_shape<true>(pair, longk, stream, ix, src, flags) : launch_shape<false>(pair, longk, stream, ix, src, flags);
 }

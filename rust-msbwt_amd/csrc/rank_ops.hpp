@@ -79,17 +79,11 @@ __device__ __forceinline__ Range rank_runs_group(const uint4 *__restrict__ block
     const uint32_t hi03 = uint32_t(__shfl(int(c.z), int(group_base + 1))), hi45 = uint32_t(__shfl(int(c.w), int(group_base + 1)));
     const uint32_t hi = (((s >> 2) ? hi45 : hi03) >> ((s & 3u) * 8u)) & 0xFFu;
     uint32_t cnt = 0;  // matches before r0 in the low half, before r1 in the high half (each <= 512)
-    if (hi45 & kRunOverflowFlag) {  // group-uniform
+    if (hi45 & kRunOverflowFlag) {  // group-uniform: the block's symbols live in two plane blocks of the side array, each
+                                    // with its own header -- the plane rank of the line that holds each bound
         const uint4 *two = overflow + uint64_t(uint32_t(__shfl(int(c.x), int(group_base + 2)))) * 16;
-        const uint32_t x0 = (s & 1u) ? 0u : ~0u, x1 = (s & 2u) ? 0u : ~0u, x2 = (s & 4u) ? 0u : ~0u;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const uint4 p = two[half * 8 + sub];
-            const uint32_t m = (p.x ^ x0) & (p.y ^ x1) & (p.z ^ x2);
-            const int first = half * 256 + int(sub) * 32;
-            cnt += uint32_t(__popc(m & low_bits(min(max(r0 - first, 0), 32))));
-            if (both) cnt += uint32_t(__popc(m & low_bits(min(max(r1 - first, 0), 32)))) << 16;
-        }
+        const uint64_t q0 = uint64_t(r0), q1 = both ? uint64_t(r1) : uint64_t(r0);  // positions inside the pair of plane blocks
+        return constrain(two, s, q0, q1, sub);
     } else {
         const uint32_t word[4] = {c.x, c.y, c.z, c.w};
         uint32_t mine = 0;  // symbols my 16 runs cover (lanes 0,1: none)

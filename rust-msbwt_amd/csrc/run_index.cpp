@@ -90,15 +90,25 @@ void build_range(const uint8_t *rle, size_t n, const Totals &t, const Segment &s
         write_header(w, t, at_start, overflow);
         if (!overflow) {
             std::memcpy(reinterpret_cast<uint8_t *>(w) + 32, pieces, np);
-        } else {  // the block's symbols as planes: 2 x (8 chunks of {plane0, plane1, plane2, unused}) for 512 positions
+        } else {  // the block's symbols as TWO plane blocks (plane_index.hpp): 8 chunks of {plane0, plane1, plane2, meta} each,
+                  // the meta words holding A[s] at the block's own first position -- 512 b and 512 b + 256
             const size_t base = out->overflow.size();
             out->overflow.resize(base + 64, 0);
             uint32_t *o = out->overflow.data() + base;
+            uint64_t at_half[kAlphabet];
+            std::memcpy(at_half, at_start, sizeof at_half);
             unsigned i = 0;
             for (size_t p = 0; p < np; ++p)
-                for (unsigned c = 0; c < unsigned(pieces[p] >> 3); ++c, ++i)
+                for (unsigned c = 0; c < unsigned(pieces[p] >> 3); ++c, ++i) {
+                    if (i < 256u) ++at_half[pieces[p] & 7u];
                     for (int pl = 0; pl < 3; ++pl)
                         if ((pieces[p] >> pl) & 1u) o[(i >> 8) * 32 + ((i & 255u) >> 5) * 4 + pl] |= 1u << (i & 31u);
+                }
+            for (int half = 0; half < 2; ++half) {
+                uint32_t meta[8];
+                write_header(meta, t, half ? at_half : at_start, false);
+                for (int j = 0; j < 8; ++j) o[half * 32 + j * 4 + 3] = meta[j];
+            }
             out->overflow_block.push_back(b);
         }
     }

@@ -9,10 +9,13 @@
 //   bytes 32..127  96 one-byte runs, byte = sym | len << 3 with len 1..31 (0 = unused slot); a BWT
 //                run is cut at block borders and into pieces of at most 31
 //   overflow     a block that needs more than 96 pieces keeps, instead of runs, the index (word 8) of
-//                two plane-block-shaped lines (256 B, planes of 512 positions) in a side array: a
-//                second, dependent fetch for the rare low-run-length block
+//                TWO PLANE BLOCKS in a side array (plane_index.hpp layout, each with its own header: the
+//                counts at 512 b and at 512 b + 256), so that any rank inside it is ONE more line: a
+//                second, dependent fetch for the rare low-run-length block.  (Until round 3 the two lines
+//                shared the run block's header and a rank could need both.)
 // About 0.30 bytes per symbol on 30x short-read BWTs (plane blocks: 0.50), 1.4x the work per rank
-// (DESIGN.md section 2).  No pair index and no lane-per-query kernel in this format.
+// (DESIGN.md section 2).  No pair index in this format; since round 4 the lane-per-query kernel
+// (lanes.hip) reads it for 6 <= k <= 32.
 #pragma once
 #include <cstddef>
 #include <cstdint>

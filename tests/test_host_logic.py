@@ -198,6 +198,13 @@ def test_run_blocks_decode_back_to_the_bwt(kind):
         want = sym[512 * b:512 * b + 512]
         if is_over[b]:
             o = over[int(w[8])]
+            for half in range(2):   # each of the two lines is a plane block of its own: A[s] at 512 b + 256 half in its meta words
+                at = min(512 * b + 256 * half, total)
+                a = start + np.bincount(sym[:at], minlength=6).astype(np.uint64)
+                meta = o[half, :, 3].astype(np.uint64)
+                got_a = [(((meta[6] >> np.uint64(8 * s)) & np.uint64(0xFF)) << np.uint64(32)) | meta[s] for s in range(4)] + \
+                        [(((meta[7] >> np.uint64(8 * (s - 4))) & np.uint64(0xFF)) << np.uint64(32)) | meta[s] for s in (4, 5)]
+                assert [int(x) for x in got_a] == [int(x) for x in a], (b, half)
             i = np.arange(len(want))
             words = o[i >> 8, (i & 255) >> 5]                      # (len, 4)
             got = (((words[:, 0] >> (i & 31)) & 1) | (((words[:, 1] >> (i & 31)) & 1) << 1) | (((words[:, 2] >> (i & 31)) & 1) << 2)).astype(np.uint8)

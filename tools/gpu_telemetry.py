@@ -75,6 +75,45 @@ def snapshot(index=0, pci=None):
     return snap
 
 
+class Sampler:
+    """Samples a card's clocks / power / temperature on a thread of its own while a measurement runs (every `period` seconds;
+    a handful of small sysfs reads each): what the card did DURING the timed steps, not before or after."""
+
+    FIELDS = ("sclk_mhz", "hwmon_sclk_mhz", "mclk_mhz", "fclk_mhz", "power_w", "temp_junction_c", "temp_mem_c", "busy_percent", "mem_busy_percent")
+
+    def __init__(self, index=0, pci=None, period=0.02):
+        import threading
+        self.index, self.pci, self.period = index, pci, period
+        self.rows, self._stop, self._thread = [], threading.Event(), None
+
+    def __enter__(self):
+        import threading
+        self._stop.clear()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+        return self
+
+    def _run(self):
+        while not self._stop.is_set():
+            snap = snapshot(self.index, self.pci)
+            self.rows.append({k: snap[k] for k in self.FIELDS if isinstance(snap.get(k), (int, float))})
+            self._stop.wait(self.period)
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=2.0)
+        return False
+
+    def summary(self):
+        out = {"samples": len(self.rows), "period_s": self.period}
+        for k in self.FIELDS:
+            vals = [r[k] for r in self.rows if k in r]
+            if vals:
+                out[k] = {"min": min(vals), "mean": round(sum(vals) / len(vals), 2), "max": max(vals)}
+        return out
+
+
 if __name__ == "__main__":
     import json
     print(json.dumps({"cards": cards(), "snapshot": snapshot()}, indent=1))
