@@ -59,6 +59,12 @@ def main():
             b.set_presence_filter(int(rng.integers(0, 2)))
             b.set_table_packed(int(rng.integers(-1, 2)))           # packed table when a pair index exists
             b.set_search_kernel(str(rng.choice(["auto", "groups", "lanes", "lanes"])))
+            b.set_table_side(int(rng.integers(0, 2)))              # round 4: escape lines from the side array, or restarted
+            b.set_batch_order(int(rng.choice([-1, 0, 1, 1])))      # ... the library's own ordering pass forced on half the time
+            if rng.random() < 0.15:                                # ... and a memory budget now and then (rebuilds the optional structures)
+                b.set_memory_budget(int(b.device_bytes() * float(rng.choice([0.2, 0.5, 0.9]))) + 1)
+            elif b.get_memory_budget():
+                b.set_memory_budget(0)
             k = int(rng.integers(1, 72))
             # mostly small batches, sometimes many tiles per wave (ring refill, setup running ahead)
             n = int(rng.integers(1, 700)) if rng.random() < 0.8 else int(rng.integers(5000, 60000))
@@ -70,6 +76,14 @@ def main():
             got, exp = b.count_kmers(q), o.count_kmers(q)
             assert np.array_equal(got, exp), (kind, depth, k, len(rle))
             checks += len(q)
+            if k <= 64:                                            # round 4: the same k-mers as 2-bit words (ACGT rows only)
+                acgt = ~np.isin(q, (0, 4)).any(axis=1)
+                if acgt.any():
+                    words = msbwt.rle_bwt.pack_2bit(q[acgt])
+                    bits = int(rng.choice([64, 32]))
+                    if bits == 64 or int(exp[acgt].max()) < 2 ** 32:
+                        assert np.array_equal(b.count_kmers_packed(words, k, count_bits=bits).astype(np.uint64), exp[acgt]), (kind, depth, k, "packed")
+                        checks += int(acgt.sum())
             # the trait's own shape: single calls and tiny batches (kernel-argument / mailbox path, polled completion)
             for i in rng.integers(0, len(q), size=4):
                 assert b.count_kmer(q[int(i)]) == int(exp[int(i)]), (kind, depth, k)
