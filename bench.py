@@ -97,7 +97,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="human", choices=["human", "c2", "c3", "c4", "c4r", "c4x3", "big"])
+    ap.add_argument("--workload", default="human", choices=["human", "c2", "c3", "c4", "c4r", "c4x3", "c4x3r", "big"])
     ap.add_argument("--big-symbols", type=float, default=2.0**33, help="workload big: BWT length")
     ap.add_argument("--big-mean-run", type=float, default=6.0)
     ap.add_argument("--stream", default="reads", choices=["reads", "histogram", "geometric"],

@@ -129,6 +129,31 @@ class RleBWT final : public BWT {
         return {std::move(fwd), std::move(rc)};
     }
 
+    /// k-mers over ACGT as 2-bit words (pack_2bit): ceil(k / 32) words each, 8 bytes per 31-mer across PCIe instead of 31.
+    std::vector<std::uint64_t> count_kmers_packed(const std::vector<std::uint64_t> &words, std::size_t k) const {
+        const std::size_t per = k > 32 ? 2 : 1;
+        if (k < 1 || k > 64 || words.size() % per) throw std::invalid_argument("bad k / words");
+        std::vector<std::uint64_t> out(words.size() / per);
+        check(msbwt_rle_count_kmers_packed(raw_, words.data(), k, out.size(), out.data(), 64));
+        return out;
+    }
+    /// ... with 32-bit counts (half the bytes on the way back; Panic(MSBWT_ERR_OVERFLOW) if a count does not fit)
+    std::vector<std::uint32_t> count_kmers_packed_u32(const std::vector<std::uint64_t> &words, std::size_t k) const {
+        const std::size_t per = k > 32 ? 2 : 1;
+        if (k < 1 || k > 64 || words.size() % per) throw std::invalid_argument("bad k / words");
+        std::vector<std::uint32_t> out(words.size() / per);
+        check(msbwt_rle_count_kmers_packed(raw_, words.data(), k, out.size(), out.data(), 32));
+        return out;
+    }
+    /// n x k symbol codes (A C G T = 1 2 3 5) -> 2-bit words: the k-mer as a base-4 number, first symbol most significant
+    static std::vector<std::uint64_t> pack_2bit(const std::vector<std::uint8_t> &kmers, std::size_t k) {
+        if (k < 1 || k > 64 || kmers.size() % k) throw std::invalid_argument("bad k / kmers");
+        std::vector<std::uint64_t> words(kmers.size() / k * (k > 32 ? 2 : 1));
+        if (msbwt_kmers_pack_2bit(kmers.data(), k, kmers.size() / k, words.data()) != MSBWT_OK)
+            throw std::invalid_argument("a symbol outside A C G T cannot be packed into two bits");
+        return words;
+    }
+
     /// Device batch (pointers on this handle's GPU), asynchronous on `hip_stream`; device_status() reports bad input.
     void count_kmers_device(const void *d_kmers, std::size_t k, std::size_t n, void *d_out, void *hip_stream = nullptr) const {
         check(msbwt_rle_count_kmers_device(raw_, d_kmers, k, n, d_out, hip_stream));
@@ -145,6 +170,12 @@ class RleBWT final : public BWT {
     void set_table_packed(int mode) { check(msbwt_rle_set_table_packed(raw_, mode)); }
     void set_pair_index(int mode) { check(msbwt_rle_set_pair_index(raw_, mode)); }
     void set_search_kernel(int mode) { check(msbwt_rle_set_search_kernel(raw_, mode)); }
+    /// HBM the loaded index may hold (0 = no budget): the space / time knob, as bin_power is the reference's (rle_bwt.rs:309-322)
+    void set_memory_budget(std::uint64_t bytes) { check(msbwt_rle_set_memory_budget(raw_, bytes)); }
+    /// -1 = automatic (today: never), 0 = never, 1 = the library orders every batch it can before counting it
+    void set_batch_order(int mode) { check(msbwt_rle_set_batch_order(raw_, mode)); }
+    void set_table_side(int mode) { check(msbwt_rle_set_table_side(raw_, mode)); }
+    std::uint64_t device_bytes() const { return msbwt_rle_device_bytes(raw_); }
     int search_kernel_for(size_t k) const { return msbwt_rle_search_kernel_for(raw_, k); }
     msbwt_rle *raw() const { return raw_; }
 

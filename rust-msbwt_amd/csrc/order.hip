@@ -556,7 +556,8 @@ hipError_t launch_order_finish(const OrderPlan &p, void *d_scratch, uint64_t *d_
     char *s = static_cast<char *>(d_scratch);
     const uint32_t nb0 = 1u << p.bits0;
     const size_t lds = size_t(p.chunk) * 8 + (size_t(2) * nb0 + 1) * 4;
-    static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(k_order_unsort), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096 - 64);
+    // (per call, not once per process: the attribute belongs to the current device, and replicas live on several)
+    const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(k_order_unsort), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096 - 64);
     if (raised != hipSuccess) return raised;
     hipLaunchKernelGGL(k_order_unsort, dim3(p.nchunks), dim3(kPassThreads), lds, stream, reinterpret_cast<const uint64_t *>(s + p.off_counts),
                        reinterpret_cast<const uint64_t *>(s + p.off_elems0), p.words + 1u, reinterpret_cast<const uint32_t *>(s + p.off_hist),

@@ -240,6 +240,9 @@ CONFIGS = {
     # read set does to the search: wide ranges, high-copy 17-mers (the packed table's escape lines), early exits
     "c4r": dict(genome=64_444_167, gseed=41, nreads=12_888_833, rlen=150, rseed=42, err=0.005, k=31,
                 nq=100_000_000, qseed=43, queries="reads", repeats=True),
+    # ... and three times that (the size of c4x3): copy numbers three times higher -- more of the packed table's lines escape
+    "c4x3r": dict(genome=193_332_501, gseed=51, nreads=38_666_499, rlen=150, rseed=52, err=0.005, k=31,
+                  nq=100_000_000, qseed=53, queries="reads", repeats=True),
     "c4x3": dict(genome=193_332_501, gseed=31, nreads=38_666_499, rlen=150, rseed=32, err=0.005, k=31,
                  nq=100_000_000, qseed=33, queries="reads"),
 }

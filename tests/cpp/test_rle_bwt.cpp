@@ -121,6 +121,20 @@ static void error_behaviour(const std::string &dir) {
     CHECK(copy.get_total_size() == three.get_total_size() && copy.count_kmer(convert_stoi("ACG")) == 4);
     const std::vector<uint64_t> sharded = RleBWT::count_kmers_multi({&three, &copy}, flat, 3);
     CHECK(sharded == counts);
+    // round 4: the same k-mers as 2-bit words (no '$' there: the middle one is replaced), 64- and 32-bit counts; a memory
+    // budget and the library's own batch order change nothing
+    const std::vector<uint8_t> acgt = {1, 2, 3, 2, 2, 3, 5, 1, 2};  // ACG CCG TAC
+    const std::vector<uint64_t> words = RleBWT::pack_2bit(acgt, 3);
+    CHECK(words.size() == 3 && words[0] == ((0ull << 4) | (1ull << 2) | 2ull));  // ACG = 0 1 2 base 4, first symbol most significant
+    const std::vector<uint64_t> packed = three.count_kmers_packed(words, 3);
+    const std::vector<uint32_t> packed32 = three.count_kmers_packed_u32(words, 3);
+    CHECK(packed == three.count_kmers(acgt, 3) && packed[0] == 4 && packed[2] == 2);
+    CHECK(packed32.size() == 3 && packed32[0] == 4 && packed32[1] == packed[1] && packed32[2] == 2);
+    three.set_memory_budget(1 << 20);
+    three.set_batch_order(1);
+    CHECK(three.count_kmers(acgt, 3) == packed && three.device_bytes() > 0);
+    three.set_memory_budget(0);
+    three.set_batch_order(-1);
     const auto both = three.count_read_kmers("CCGTACGTAGGTACAGTA", 9, 3);
     CHECK(both.first.size() == 14 && both.first[2] == three.count_kmer(convert_stoi("GTA")));
     CHECK(both.second[0] == three.count_kmer(reverse_complement_i(convert_stoi("CCG"))));

@@ -951,6 +951,39 @@ def test_replicas_and_sharded_batches_match_a_single_handle(monkeypatch):
     assert err.value.code == msbwt._lib.ERR_INVALID_SYMBOL
 
 
+@pytest.mark.parametrize("kind", ["ones", "short", "long", "mixed", "raw", "edges"])
+def test_run_blocks_built_on_the_device_equal_the_host_built_ones(kind, monkeypatch):
+    """The run-block index is made on the device from plane blocks (csrc/run_build.hip; MSBWT_BUILD=host keeps the host builder):
+    both answer every rank alike -- constrain_ranges at random positions, at every multiple of 256 and at T itself, on streams of
+    single-symbol runs (every block overflows), long runs, zero-length runs, totals that are exact multiples of the block sizes."""
+    monkeypatch.setenv("MSBWT_BLOCKS", "runs")
+    streams = {"ones": [random_stream(3, 4000, "ones")], "short": [random_stream(4, 6000, "short")], "long": [random_stream(5, 60, "long")],
+               "mixed": [random_stream(6, 400, "mixed")], "raw": [raw_byte_stream(7, 3000)],
+               "edges": [runs_to_bytes([1, 2], [256, 256]), runs_to_bytes([3], [512]), runs_to_bytes([0, 5], [1, 1023]), runs_to_bytes([2] * 1, [1]),
+                         runs_to_bytes(list(range(1, 6)) * 120, [1] * 600), np.zeros(0, dtype=np.uint8)]}[kind]
+    for rle in streams:
+        o = orc.OracleRleBWT()
+        o.load_vector(rle)
+        total = o.get_total_size()
+        monkeypatch.setenv("MSBWT_BUILD", "device")
+        dev_built = gpu_bwt(rle)
+        monkeypatch.setenv("MSBWT_BUILD", "host")
+        host_built = gpu_bwt(rle)
+        assert dev_built.get_block_format() == host_built.get_block_format() == "runs" and dev_built.get_total_size() == total
+        rng = np.random.default_rng(len(rle))
+        pos = np.unique(np.concatenate([rng.integers(0, total + 1, size=3000), np.arange(0, total + 1, 256)[:4000], [0, total]]))
+        l, h = rng.choice(pos, size=6000), rng.choice(pos, size=6000)
+        l, h = np.minimum(l, h).astype(np.uint64), np.maximum(l, h).astype(np.uint64)
+        sy = rng.integers(0, 6, size=6000).astype(np.uint8)
+        exp = o.constrain_ranges(sy, l, h)
+        for b in (dev_built, host_built):
+            got = b.constrain_ranges(sy, l, h)
+            assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1])
+        if total:
+            qs = random_kmers(5, 3000, 9, alphabet=(0, 1, 2, 3, 4, 5))
+            assert np.array_equal(dev_built.count_kmers(qs), o.count_kmers(qs)) and np.array_equal(host_built.count_kmers(qs), o.count_kmers(qs))
+
+
 def test_run_block_format_is_selectable_and_lean():
     """msbwt_rle_set_block_format: the same handle loads the same stream as plane blocks and as run
     blocks; identical answers, about 0.3 instead of 0.5 bytes per symbol, no pair index in run mode."""
