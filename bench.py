@@ -49,8 +49,9 @@ RANDOM_LINE_PEAK = 4.86e10  # random 128-byte lines/s, measured: independent gat
 HUMAN_SYMBOLS = 9e10
 # everything that decides which bytes a query makes the kernel move: the kernels, the block layouts and their
 # builders, and the policies that pick table depth and pair spacing
+# (order.hip -- the library's batch-ordering passes -- is not among them: they are off unless forced, and no default line runs them)
 KERNEL_SOURCES = ["kernels.hip", "lanes.hip", "search_common.hpp", "rank_ops.hpp", "kernels.hpp", "plane_index.hpp",
-                  "pair_index.hip", "device_build.hip", "table_policy.hpp", "order.hip"]
+                  "pair_index.hip", "device_build.hip", "table_policy.hpp"]
 NARROW_MAX = 32767
 
 

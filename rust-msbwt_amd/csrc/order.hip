@@ -233,38 +233,6 @@ __device__ __forceinline__ void store_element(uint64_t *__restrict__ out, uint64
     }
 }
 
-// Level 0, the one global pass: the workgroups take the chunks of k_order_pack in turn; every query of a chunk goes to its
-// place in its bucket (LDS cursors), as an element that carries its index in the caller's batch.
-template <int kWordsPerQuery>
-__global__ __launch_bounds__(1024) void k_order_scatter(const uint64_t *__restrict__ packed_in, uint64_t n, uint32_t chunk, uint32_t nchunks,
-                                                        uint32_t reach, uint32_t bits0, const uint32_t *__restrict__ offsets,
-                                                        const uint32_t *__restrict__ starts, uint64_t *__restrict__ elems_out) {
-    extern __shared__ uint32_t cursor[];
-    const uint32_t nbuckets = 1u << bits0;
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        __syncthreads();  // (the previous chunk's cursors are no longer used)
-        for (uint32_t b = threadIdx.x; b < nbuckets; b += kPassThreads) cursor[b] = starts[b] + offsets[uint64_t(c) * nbuckets + b];
-        __syncthreads();
-        const uint64_t lo = uint64_t(c) * chunk, hi = min(n, lo + chunk);
-        for (uint64_t base = lo + threadIdx.x; base < hi; base += kPassThreads * kPassUnroll) {
-            uint64_t words[kPassUnroll][kWordsPerQuery];
-#pragma unroll
-            for (int u = 0; u < kPassUnroll; ++u) {
-                const uint64_t q = base + uint64_t(u) * kPassThreads;
-#pragma unroll
-                for (int w = 0; w < kWordsPerQuery; ++w) words[u][w] = q < hi ? packed_in[q * kWordsPerQuery + w] : 0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < kPassUnroll; ++u) {
-                const uint64_t q = base + uint64_t(u) * kPassThreads;
-                if (q >= hi) continue;
-                const uint32_t at = atomicAdd(&cursor[bucket_of(words[u][0], reach, 0u, bits0)], 1u);
-                store_element<kWordsPerQuery>(elems_out, at, words[u], uint32_t(q));
-            }
-        }
-    }
-}
-
 // part[0 .. 1024) -> exclusive prefix sums + `base`, by the workgroup's first wave (16 values per lane, then across the lanes);
 // the caller synchronises before and after
 __device__ __forceinline__ void scan_1024(uint32_t *part, uint32_t base) {
@@ -287,22 +255,138 @@ __device__ __forceinline__ void scan_1024(uint32_t *part, uint32_t base) {
     }
 }
 
-// Level 1: every level-0 bucket (`nparents` of them, parent_starts) is split once more by the NEXT `bits` key bits -- count,
-// scan, scatter, by ONE workgroup inside the bucket's own window, however large the bucket is.  The element written carries
-// the level-0 place the query came from: the search writes its count THERE (inside the same window), k_order_unsort takes
-// it from there.
+// counters[0 .. n) (LDS) -> their exclusive prefix sums + `base`, in place, by the whole workgroup (n <= 4096)
+__device__ __forceinline__ void scan_in_place(uint32_t *counters, uint32_t n, uint32_t *part, uint32_t base) {
+    const uint32_t per = (n + kPassThreads - 1) / kPassThreads, first = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (uint32_t i = first; i < min(n, first + per); ++i) sum += counters[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    scan_1024(part, base);
+    __syncthreads();
+    uint32_t acc = part[threadIdx.x];
+    for (uint32_t i = first; i < min(n, first + per); ++i) {
+        const uint32_t c = counters[i];
+        counters[i] = acc;
+        acc += c;
+    }
+    __syncthreads();
+}
+
+// A TILE of elements goes out in RUNS (round 4, last shape of the passes).  The passes cost about a millisecond per 10^8
+// separate stores whatever their size, so a workgroup first sorts the tile it holds in registers by bucket INSIDE LDS -- a
+// counting sort: LDS atomics give every element its rank in its bucket, a scan the bucket's place in the tile -- and then
+// stores the tile in sorted order: neighbouring lanes hold neighbouring elements of one bucket and their stores go to
+// neighbouring addresses (one request per run instead of one per element).
+//   kPer elements per thread (words, tag, bucket, live); nb buckets; cursor[b] (LDS) = where bucket b's next element goes
+//   in `out`, advanced by what the tile adds; tile_start (LDS, nb) and stage (LDS, kPer x 1024 elements) are scratch.
+template <int kWordsPerQuery>
+struct OrderTile {
+    static constexpr int kPer = kWordsPerQuery == 1 ? 8 : 4;            // 8192 16-byte or 4096 24-byte elements: 128 / 96 KiB of LDS
+    static constexpr uint32_t kElems = uint32_t(kPer) * kPassThreads;
+    static constexpr uint32_t kStride = kWordsPerQuery + 1;
+};
+
+template <int kWordsPerQuery>
+__device__ __forceinline__ void scatter_tile_in_runs(const uint64_t (&words)[OrderTile<kWordsPerQuery>::kPer][kWordsPerQuery],
+                                                     const uint32_t (&tag)[OrderTile<kWordsPerQuery>::kPer],
+                                                     const uint32_t (&bucket)[OrderTile<kWordsPerQuery>::kPer], uint32_t live_mask, uint32_t ntile,
+                                                     uint32_t nb, uint32_t reach, uint32_t drop, uint32_t bits, uint32_t *tile_start, uint32_t *cursor,
+                                                     uint32_t *part, uint64_t *stage, uint64_t *__restrict__ out) {
+    constexpr int kPer = OrderTile<kWordsPerQuery>::kPer;
+    constexpr uint32_t kStride = OrderTile<kWordsPerQuery>::kStride;
+    for (uint32_t b = threadIdx.x; b < nb; b += kPassThreads) tile_start[b] = 0u;
+    __syncthreads();
+    uint32_t rank[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) rank[u] = (live_mask >> u) & 1u ? atomicAdd(&tile_start[bucket[u]], 1u) : 0u;
+    __syncthreads();
+    // what each bucket gets from this tile (kept by the thread that owns the bucket), then the buckets' places in the tile
+    const uint32_t per = (nb + kPassThreads - 1) / kPassThreads, first = threadIdx.x * per;
+    uint32_t added[4];  // nb <= 4096
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; ++i) added[i] = (i < per && first + i < nb) ? tile_start[first + i] : 0u;
+    scan_in_place(tile_start, nb, part, 0u);
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        if (((live_mask >> u) & 1u) == 0u) continue;
+        const uint32_t at = tile_start[bucket[u]] + rank[u];
+#pragma unroll
+        for (int w = 0; w < kWordsPerQuery; ++w) stage[at * kStride + w] = words[u][w];
+        stage[at * kStride + kWordsPerQuery] = tag[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const uint32_t at = threadIdx.x + uint32_t(u) * kPassThreads;  // neighbouring lanes, neighbouring places of the sorted tile
+        if (at >= ntile) continue;
+        uint64_t e[kWordsPerQuery];
+#pragma unroll
+        for (int w = 0; w < kWordsPerQuery; ++w) e[w] = stage[at * kStride + w];
+        const uint32_t b = bucket_of(e[0], reach, drop, bits);
+        store_element<kWordsPerQuery>(out, cursor[b] + (at - tile_start[b]), e, uint32_t(stage[at * kStride + kWordsPerQuery]));
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; ++i)
+        if (i < per && first + i < nb) cursor[first + i] += added[i];
+    __syncthreads();
+}
+
+// Level 0, the one global pass: the workgroups take the chunks of k_order_pack in turn; every query of a chunk goes to its
+// place in its bucket, tile by tile (scatter_tile_in_runs), as an element that carries its index in the caller's batch.
+template <int kWordsPerQuery>
+__global__ __launch_bounds__(1024) void k_order_scatter(const uint64_t *__restrict__ packed_in, uint64_t n, uint32_t chunk, uint32_t nchunks,
+                                                        uint32_t reach, uint32_t bits0, const uint32_t *__restrict__ offsets,
+                                                        const uint32_t *__restrict__ starts, uint64_t *__restrict__ elems_out) {
+    using Tile = OrderTile<kWordsPerQuery>;
+    extern __shared__ uint64_t order_lds[];  // stage, then tile_start[nb], cursor[nb]
+    __shared__ uint32_t part[kPassThreads];
+    const uint32_t nb = 1u << bits0;
+    uint64_t *stage = order_lds;
+    uint32_t *tile_start = reinterpret_cast<uint32_t *>(order_lds + size_t(Tile::kElems) * Tile::kStride), *cursor = tile_start + nb;
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < nb; b += kPassThreads) cursor[b] = starts[b] + offsets[uint64_t(c) * nb + b];
+        __syncthreads();
+        const uint64_t lo = uint64_t(c) * chunk, hi = min(n, lo + chunk);
+        for (uint64_t tile = lo; tile < hi; tile += Tile::kElems) {
+            uint64_t words[Tile::kPer][kWordsPerQuery];
+            uint32_t tag[Tile::kPer], bucket[Tile::kPer], live = 0;
+#pragma unroll
+            for (int u = 0; u < Tile::kPer; ++u) {
+                const uint64_t q = tile + uint64_t(u) * kPassThreads + threadIdx.x;
+#pragma unroll
+                for (int w = 0; w < kWordsPerQuery; ++w) words[u][w] = q < hi ? packed_in[q * kWordsPerQuery + w] : 0ull;
+                tag[u] = uint32_t(q);
+                bucket[u] = bucket_of(words[u][0], reach, 0u, bits0);
+                live |= q < hi ? 1u << u : 0u;
+            }
+            scatter_tile_in_runs<kWordsPerQuery>(words, tag, bucket, live, uint32_t(min(uint64_t(Tile::kElems), hi - tile)), nb, reach, 0u, bits0, tile_start,
+                                                 cursor, part, stage, elems_out);
+        }
+    }
+}
+
+// Level 1: every level-0 bucket (`nparents` of them, parent_starts) is split once more by the NEXT `bits` key bits by ONE
+// workgroup, inside the bucket's own window, however large the bucket is: a counting pass over the bucket gives every
+// sub-bucket its place, then the bucket goes out tile by tile in runs.  The element written carries the level-0 place the
+// query came from: the search writes its count THERE (inside the same window), k_order_unsort takes it from there.
 template <int kWordsPerQuery>
 __global__ __launch_bounds__(1024) void k_order_level(const uint64_t *__restrict__ elems_in, const uint32_t *__restrict__ parent_starts,
                                                       uint32_t nparents, uint32_t reach, uint32_t drop, uint32_t bits,
                                                       uint64_t *__restrict__ elems_out) {
-    constexpr uint32_t kStride = kWordsPerQuery + 1;
-    extern __shared__ uint32_t fine[];  // 2^bits counters, then cursors
+    using Tile = OrderTile<kWordsPerQuery>;
+    constexpr uint32_t kStride = Tile::kStride;
+    extern __shared__ uint64_t order_lds[];  // stage, then tile_start[nb], cursor[nb]
     __shared__ uint32_t part[kPassThreads];
-    const uint32_t nfine = 1u << bits;
+    const uint32_t nb = 1u << bits;
+    uint64_t *stage = order_lds;
+    uint32_t *tile_start = reinterpret_cast<uint32_t *>(order_lds + size_t(Tile::kElems) * kStride), *cursor = tile_start + nb;
     for (uint32_t parent = blockIdx.x; parent < nparents; parent += gridDim.x) {
         const uint32_t lo = parent_starts[parent], hi = parent_starts[parent + 1];
-        __syncthreads();  // (the previous parent's cursors are no longer read)
-        for (uint32_t b = threadIdx.x; b < nfine; b += kPassThreads) fine[b] = 0u;
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < nb; b += kPassThreads) cursor[b] = 0u;
         __syncthreads();
         for (uint32_t base = lo + threadIdx.x; base < hi; base += kPassThreads * kPassUnroll) {
             uint64_t w0[kPassUnroll];
@@ -313,38 +397,24 @@ __global__ __launch_bounds__(1024) void k_order_level(const uint64_t *__restrict
             }
 #pragma unroll
             for (int u = 0; u < kPassUnroll; ++u)
-                if (base + uint32_t(u) * kPassThreads < hi) atomicAdd(&fine[bucket_of(w0[u], reach, drop, bits)], 1u);
+                if (base + uint32_t(u) * kPassThreads < hi) atomicAdd(&cursor[bucket_of(w0[u], reach, drop, bits)], 1u);
         }
         __syncthreads();
-        const uint32_t per = (nfine + kPassThreads - 1) / kPassThreads, first = threadIdx.x * per;
-        uint32_t sum = 0;
-        for (uint32_t i = first; i < min(nfine, first + per); ++i) sum += fine[i];
-        part[threadIdx.x] = sum;
-        __syncthreads();
-        scan_1024(part, lo);
-        __syncthreads();
-        uint32_t acc = part[threadIdx.x];
-        for (uint32_t i = first; i < min(nfine, first + per); ++i) {
-            const uint32_t c = fine[i];
-            fine[i] = acc;
-            acc += c;
-        }
-        __syncthreads();
-        for (uint32_t base = lo + threadIdx.x; base < hi; base += kPassThreads * kPassUnroll) {
-            uint64_t words[kPassUnroll][kWordsPerQuery];
+        scan_in_place(cursor, nb, part, lo);
+        for (uint32_t tile = lo; tile < hi; tile += Tile::kElems) {
+            uint64_t words[Tile::kPer][kWordsPerQuery];
+            uint32_t tag[Tile::kPer], bucket[Tile::kPer], live = 0;
 #pragma unroll
-            for (int u = 0; u < kPassUnroll; ++u) {
-                const uint32_t q = base + uint32_t(u) * kPassThreads;
+            for (int u = 0; u < Tile::kPer; ++u) {
+                const uint32_t q = tile + uint32_t(u) * kPassThreads + threadIdx.x;
 #pragma unroll
                 for (int w = 0; w < kWordsPerQuery; ++w) words[u][w] = q < hi ? elems_in[uint64_t(q) * kStride + w] : 0ull;
+                tag[u] = q;
+                bucket[u] = bucket_of(words[u][0], reach, drop, bits);
+                live |= q < hi ? 1u << u : 0u;
             }
-#pragma unroll
-            for (int u = 0; u < kPassUnroll; ++u) {
-                const uint32_t q = base + uint32_t(u) * kPassThreads;
-                if (q >= hi) continue;
-                const uint32_t at = atomicAdd(&fine[bucket_of(words[u][0], reach, drop, bits)], 1u);
-                store_element<kWordsPerQuery>(elems_out, at, words[u], q);
-            }
+            scatter_tile_in_runs<kWordsPerQuery>(words, tag, bucket, live, min(Tile::kElems, hi - tile), nb, reach, drop, bits, tile_start, cursor, part, stage,
+                                                 elems_out);
         }
     }
 }
@@ -493,9 +563,9 @@ OrderPlan plan_order(uint64_t n, uint32_t k, uint32_t reach, uint32_t bits, bool
     uint32_t b0 = 3;
     while (b0 < 11u && (uint64_t(8) << (b0 + 1)) <= std::min<uint64_t>(p.chunk, n)) ++b0;
     p.bits0 = std::min(b0, bits);
-    p.bits1 = std::min(bits - p.bits0, 12u);
+    p.bits1 = std::min(bits - p.bits0, 11u);
     p.wg0 = std::min(p.nchunks, env_or("MSBWT_ORDER_WG0", 1024));
-    p.wg1 = std::min(1u << p.bits0, env_or("MSBWT_ORDER_WG1", 128));
+    p.wg1 = std::min(1u << p.bits0, env_or("MSBWT_ORDER_WG1", 1024));
     const uint64_t nb0 = 1ull << p.bits0;
     uint64_t at = 0;
     auto take = [&](uint64_t bytes) { const uint64_t here = at; at += round_up(bytes, 256); return here; };
@@ -534,17 +604,24 @@ hipError_t launch_order_batch(const OrderPlan &p, const uint8_t *d_rows, const u
                            p.n, p.chunk, p.reach, b0, hist, exceptions, nexc);
     hipLaunchKernelGGL(k_order_offsets, dim3(nb0), dim3(kOrderThreads), 0, stream, hist, p.nchunks, nb0, totals);
     hipLaunchKernelGGL(k_order_starts, dim3(1), dim3(kOrderThreads), 0, stream, totals, nb0, starts);
+    // the tiles are staged in LDS: 128 KiB (96 KiB for two-word queries) + two arrays of one u32 per bucket -- one workgroup per CU
+    const auto lds_for = [&](uint32_t nbuckets) { return size_t(p.words == 1 ? OrderTile<1>::kElems * 16u : OrderTile<2>::kElems * 24u) + size_t(nbuckets) * 8; };
+    const int lds_cap = 160 * 1024 - 4096 - 64;  // (per call: the attribute belongs to the current device)
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_order_scatter<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_cap)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_order_scatter<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_cap)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_order_level<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_cap)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_order_level<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_cap)) != hipSuccess) return e;
     if (p.words == 1)
-        hipLaunchKernelGGL((k_order_scatter<1>), dim3(p.wg0), dim3(kPassThreads), nb0 * 4, stream, src_packed, p.n, p.chunk, p.nchunks, p.reach, b0, hist, starts, e0);
+        hipLaunchKernelGGL((k_order_scatter<1>), dim3(p.wg0), dim3(kPassThreads), lds_for(nb0), stream, src_packed, p.n, p.chunk, p.nchunks, p.reach, b0, hist, starts, e0);
     else
-        hipLaunchKernelGGL((k_order_scatter<2>), dim3(p.wg0), dim3(kPassThreads), nb0 * 4, stream, src_packed, p.n, p.chunk, p.nchunks, p.reach, b0, hist, starts, e0);
+        hipLaunchKernelGGL((k_order_scatter<2>), dim3(p.wg0), dim3(kPassThreads), lds_for(nb0), stream, src_packed, p.n, p.chunk, p.nchunks, p.reach, b0, hist, starts, e0);
     *ordered = e0;
     *place_inline = false;  // one level only: the search counts in level-0 order and its counts are in place already
     if (p.bits1) {
         if (p.words == 1)
-            hipLaunchKernelGGL((k_order_level<1>), dim3(p.wg1), dim3(kPassThreads), (1u << p.bits1) * 4, stream, e0, starts, nb0, p.reach, b0, p.bits1, e1);
+            hipLaunchKernelGGL((k_order_level<1>), dim3(p.wg1), dim3(kPassThreads), lds_for(1u << p.bits1), stream, e0, starts, nb0, p.reach, b0, p.bits1, e1);
         else
-            hipLaunchKernelGGL((k_order_level<2>), dim3(p.wg1), dim3(kPassThreads), (1u << p.bits1) * 4, stream, e0, starts, nb0, p.reach, b0, p.bits1, e1);
+            hipLaunchKernelGGL((k_order_level<2>), dim3(p.wg1), dim3(kPassThreads), lds_for(1u << p.bits1), stream, e0, starts, nb0, p.reach, b0, p.bits1, e1);
         *ordered = e1;
         *place_inline = true;
     }
