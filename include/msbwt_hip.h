@@ -288,15 +288,17 @@ int msbwt_auto_index_plan(uint64_t total_symbols, uint64_t free_hbm_bytes, uint6
                           int *pair_index, int *pair_stride, int *flat_depth, int *packed_depth, uint64_t *index_bytes);
 /* Block format of the index, chosen BEFORE a load (MSBWT_BLOCKS=runs in the environment sets the
  * initial choice): 0 = bit-plane blocks (default: 0.5 byte per symbol, fastest, the only format the
- * pair index and the lane-per-query kernel work on), 1 = run blocks -- the layout of the reference's
- * run_block_av_flat (src/run_block_av_flat.rs:43-56,97-125): 128-byte blocks of 512 positions with
- * per-block counts and 96 one-byte runs, ~0.3 byte per symbol on 30x short-read BWTs, single-symbol
- * steps only (no pair index), ~1.4x the work per rank.  For replicas that must leave HBM to others.
- * Results never change. */
+ * pair index, the packed table and the batch-ordering pass work on), 1 = run blocks -- the layout of the
+ * reference's run_block_av_flat (src/run_block_av_flat.rs:43-56,97-125): 128-byte blocks of 512 positions
+ * with per-block counts and 96 one-byte runs, ~0.3 byte per symbol on 30x short-read BWTs, single-symbol
+ * steps only (no pair index).  Built on the device from the RLE bytes like the default format; for
+ * 6 <= k <= 32 the lane-per-query kernel serves it too (each lane decodes its own block's runs from LDS):
+ * a 30x human-scale BWT in 44 GB at 1.8 x 10^9 present 31-mers/s (bit planes + pair blocks + table:
+ * 238 GB, 5.4 x 10^9).  For replicas that must leave HBM to others.  Results never change. */
 int msbwt_rle_set_block_format(msbwt_rle *bwt, int format);
 int msbwt_rle_get_block_format(const msbwt_rle *bwt);
-/* Search kernel for 1 <= k <= 64: 0 = automatic (default: 2 whenever a pair index exists and k >= 6),
- * 1 = 8 lanes per query, lines in registers (kernels.hip; one symbol per step; needs no pair index),
+/* Search kernel for 1 <= k <= 64: 0 = automatic (default: 2 whenever a pair index exists and k >= 6, and on run
+ * blocks for 6 <= k <= 32), 1 = 8 lanes per query, lines in registers (kernels.hip; one symbol per step; needs no pair index),
  * 2 = one query per lane, lines staged through LDS by LDS-DMA (lanes.hip; two symbols per step,
  * 8x more random lines in flight per wave).  MSBWT_SEARCH=groups|lanes in the environment
  * sets the initial mode.  Results never change. */

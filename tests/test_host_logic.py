@@ -386,3 +386,23 @@ def test_memory_budget_plans():
             p = plan(total, free(total) if total < 2 ** 38 else 10 * GB, hbm, 5.0, budget)
             planes = (total // 256 + 1) * 128 if total else 128
             assert p["packed_depth"] in (0, p["flat_depth"] + 2) and (budget == 0 or p["index_bytes"] <= max(budget, planes))
+
+
+def test_two_bit_packing_layout():
+    """msbwt_kmers_pack_2bit (host, no device): the k-mer as a base-4 number, A C G T -> 0 1 2 3, first symbol most significant,
+    32 symbols per u64 -- the last symbol in bits 0-1 of word 0, symbol k-33 in bits 0-1 of word 1 -- checked against a
+    restatement with Python integers; '$', 'N' and invalid codes are refused."""
+    rng = np.random.default_rng(3)
+    for k in (1, 2, 17, 31, 32, 33, 47, 64):
+        qs = np.array([1, 2, 3, 5], dtype=np.uint8)[rng.integers(0, 4, size=(300, k))]
+        words = msbwt.rle_bwt.pack_2bit(qs)
+        assert words.shape == (300, 2 if k > 32 else 1)
+        for row, w in zip(qs, words):
+            value = 0
+            for s in row:                      # first symbol most significant
+                value = value * 4 + {1: 0, 2: 1, 3: 2, 5: 3}[int(s)]
+            assert int(w[0]) == value & (2 ** 64 - 1) and (k <= 32 or int(w[1]) == value >> 64)
+    for bad in (0, 4, 6, 255):
+        q = np.array([[1, 2, bad, 3]], dtype=np.uint8)
+        with pytest.raises(msbwt.MsbwtError):
+            msbwt.rle_bwt.pack_2bit(q)
