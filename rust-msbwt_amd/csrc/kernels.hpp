@@ -65,7 +65,7 @@ struct IndexView {
 // indices into IndexView::counters
 enum SearchCounter {
     kCntWaveSteps = 0,     // search steps of a wave (each costs the same whether 5 or 64 lanes take it)
-    kCntLaneSteps,         // steps taken by a lane's query (pair, single-symbol or side-array fetch)
+    kCntLaneSteps,         // steps taken by a lane's query (pair or single-symbol)
     kCntPairSteps,         // ... of which consumed two symbols
     kCntSecondLines,       // steps whose range needed a second line (l and h in different blocks)
     kCntSatOut,            // lane-steps lost because the step's second-line slots were taken
@@ -73,7 +73,7 @@ enum SearchCounter {
     kCntEscapeRestarts,    // ... that searched from [0, total) because the table has no side array
     kCntTableDecided,      // queries decided by the table or the presence filter alone
     kCntSearched,          // queries that entered the search
-    kCntFirstLines,        // first-bound lines fetched (one per lane-step)
+    kCntFirstLines,        // first-bound lines fetched (one per lane-step) + side-array entries fetched for escape-line queries
     kSearchCounters = 16
 };
 

@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.hpp"
 #include "rank_ops.hpp"
@@ -65,19 +66,35 @@ template <int kWords> constexpr int kRegionsFor = 10;
 #ifndef MSBWT_LANES_WAVE_CAP
 #define MSBWT_LANES_WAVE_CAP 12
 #endif
+// experiments (tools/build_variant.sh): what the side-array fetch and the optional counters cost the kernels that never see either
+#ifdef MSBWT_LANES_NO_SIDE_FETCH
+constexpr bool kSideFetch = false;
+#else
+constexpr bool kSideFetch = true;
+#endif
+#ifdef MSBWT_LANES_NO_COUNTERS
+constexpr bool kCounting = false;
+#else
+constexpr bool kCounting = true;
+#endif
 
 // One undecided query waiting in the ring: 24 bytes (k <= 32) or 36 (k <= 64).  The ring only ever holds
 // queries of ONE tile (it is refilled when empty), so the tile index is a wave-uniform register, not a field.
-template <int kWords>
+// kPlaced (the instantiations for packed queries, which may come with a place for every count): 4 bytes more.
+template <int kWords, bool kPlaced>
 struct RingItemT {
     uint32_t l_lo, h_lo;
-    uint32_t meta;        // l >> 32 (8 bits) | h >> 32 (8 bits) << 8 | remaining steps << 16 | lane in the tile << 24 | escape << 31
-                          // (escape: the range is still to be fetched from the packed table's side array; l = its entry index)
+    uint32_t meta;        // l >> 32 (8 bits) | h >> 32 (8 bits) << 8 | remaining steps << 16 | lane in the tile << 24
     uint32_t w[kWords];   // remaining symbols, 3 bits each, next step in the low bits
-    uint32_t out;         // QuerySource::out_index given: where the count goes (else unused: tile and lane say it)
+};
+template <int kWords>
+struct RingItemT<kWords, true> {
+    uint32_t l_lo, h_lo, meta;
+    uint32_t w[kWords];
+    uint32_t out;         // QuerySource::out_index / place_inline: where the count goes (else unused: tile and lane say it)
 };
 
-template <int kWords>
+template <int kWords, bool kPlaced>
 struct LaneScratchT {
     static constexpr int kMaxK = kWords * 32 / 3;  // 32 or 64
     static constexpr int kRegions = kRegionsFor<kWords>;
@@ -92,10 +109,10 @@ struct LaneScratchT {
     // symbol codes), and at the start of a step its first 640 bytes hold the step's line addresses: they
     // are in registers (s_waitcnt lgkmcnt(0)) before the first LDS-DMA load is issued.
     uint4 lines[(kRegions / 2) * 136];   // 10.6 KiB
-    RingItemT<kWords> ring[kRing];       // 1.75 or 2.5 KiB
+    RingItemT<kWords, kPlaced> ring[kRing];  // 1.5 or 2.25 KiB (+ 256 bytes when kPlaced)
     uint32_t cnt[kSearchCounters];       // optional search counters of this wave (kernels.hpp): in LDS, so that they cost no registers
 };
-static_assert(sizeof(LaneScratchT<6>) <= 160 * 1024 / 12, "12 one-wave workgroups per CU");
+static_assert(sizeof(LaneScratchT<6, true>) <= 160 * 1024 / 12, "12 one-wave workgroups per CU");
 
 // uint4 index of the first of region i's 64 sixteen-byte pieces: pairs of regions take 136 pieces,
 // the odd one starting 72 in (64 + 8 of padding)
@@ -246,7 +263,11 @@ __device__ __forceinline__ uint64_t pair_line_bound(const PairLine &L, uint64_t 
     return super_base + L.field + pair_line_count(L, r);
 }
 
-template <bool kReads, bool kPair, int kWords, bool kStride96>
+// kPacked (matrix mode only): the queries come as 2-bit words (QuerySource::packed), possibly with a place for each count.
+// A compile-time switch, not a launch-uniform branch: with both ways of fetching a tile in one kernel the compiler merged
+// their results through register copies, i.e. WAITED for the tile's bytes right after asking for them -- setup no longer
+// ran ahead of memory (same box, C2 random 21-mers: 0.253 ms per 10^7 against 0.225 ms before packed queries existed).
+template <bool kReads, bool kPair, int kWords, bool kStride96, bool kPacked>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_count_kmers_lanes(const uint4 *__restrict__ blocks, uint64_t total,
                                                           const uint4 *__restrict__ table, uint32_t depth, uint32_t table_packed,
                                                           const uint32_t *__restrict__ filter, uint32_t filter_mask,
@@ -256,11 +277,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                                                           unsigned long long *__restrict__ tile_counter, uint32_t grain,
                                                           uint64_t *__restrict__ done, uint64_t done_seq, uint64_t *__restrict__ counters,
                                                           uint32_t format, const uint4 *__restrict__ run_overflow) {
-    using Scratch = LaneScratchT<kWords>;
+    static_assert(!(kReads && kPacked), "packed queries are a matrix-mode input");
+    using Scratch = LaneScratchT<kWords, kPacked>;
     // run blocks (run_index.hpp; launch-uniform): `blocks` are 128-byte lines of 512 positions with 96 one-byte runs, decoded
     // by the lane that owns the query; single-symbol steps only (the kPair instantiations never see them)
-    const bool runs = !kPair && kWords == 3 && format != 0u;  // (k <= 32 only: the long instantiation has no registers to spare)
-    using RingItem = RingItemT<kWords>;
+    const bool runs = !kPair && !kPacked && kWords == 3 && format != 0u;  // (k <= 32 only: the long instantiation has no registers to spare)
+    using RingItem = RingItemT<kWords, kPacked>;
     constexpr int kPieces = Scratch::kMaxK / 16;  // 16-byte pieces of a tile per lane: 2 or 4
     constexpr int kRegions = Scratch::kRegions, kLineSlots = Scratch::kLineSlots;
     constexpr uint32_t kMaxSecond = Scratch::kMaxSecond;
@@ -274,7 +296,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     const bool use_table = table != nullptr && depth > 0 && k >= depth;
     const TableEnv env{table, depth, use_table, table_packed != 0u, filter, filter_mask, total, table_side};
     // optional search counters (kernels.hpp, SearchCounter): wave sums kept in LDS, added to the caller's block at the end
-    if (counters != nullptr && lane < uint32_t(kSearchCounters)) ws.cnt[lane] = 0u;
+    const bool counting = kCounting && counters != nullptr;
+    if (counting && lane < uint32_t(kSearchCounters)) ws.cnt[lane] = 0u;
     auto count = [&](int which, uint64_t ballot) {
         if (lane == 0u) ws.cnt[which] += uint32_t(__popcll(ballot));
     };
@@ -323,7 +346,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
 
     // the lane's running query
     bool have = false;
-    bool esc = false;  // the query's range is still in the side array of the packed table: l = index of its entry there
     uint32_t ovf_l = 0, ovf_h = 0;  // run blocks: 1 + the overflow plane block this bound is to be ranked from (0: its run block)
     uint64_t l = 0, h = 0;
     uint32_t w[kWords], rem = 0;
@@ -351,39 +373,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     const double inv_windows = kReads ? 1.0 / double(src.windows) : 0.0;
     uint32_t staged_n0 = 0;  // wave-uniform
     uint32_t staged_out = 0, prep_out = 0;  // QuerySource::out_index: the output place of this lane's query of the fetched / the prepared tile
-    const bool placed = !kReads && (src.out_index != nullptr || src.place_inline != 0u);  // launch-uniform
+    const bool placed = kPacked && (src.out_index != nullptr || src.place_inline != 0u);  // launch-uniform
     auto place_of = [&](uint64_t v, uint32_t out) -> uint64_t { return placed ? uint64_t(out) : v; };
-    auto fetch_tile_bytes = [&](uint64_t tile) {
-        if (tile >= ntiles) return;
+    // (`first`: the call in front of the loop -- the only one that can meet the single query that came with the kernel
+    // arguments; the call inside the loop is compiled without that case, so that it has ONE way of loading a tile and
+    // nothing to merge after the loads)
+    auto fetch_tile_bytes = [&](uint64_t tile, auto first) {
+        if (!kPacked && tile >= ntiles) return;  // (packed queries: loaded unconditionally, see below; n > 0)
         if (!kReads) {
-            if (src.inline_n != 0u) {  // the one query came with the kernel arguments: pieces 0..3 belong to lanes 0..3
+            if (decltype(first)::value && !kPacked && src.inline_n != 0u) {  // pieces 0..3 belong to lanes 0..3
                 staged_next[0] = lane == 0u ? src.inline_kmer[0] : lane == 1u ? src.inline_kmer[1] : lane == 2u ? src.inline_kmer[2] : lane == 3u ? src.inline_kmer[3] : make_uint4(0, 0, 0, 0);
                 return;
             }
             const uint64_t q0 = tile * kTile;
-            if (src.out_index != nullptr && q0 + lane < n) staged_out = src.out_index[q0 + lane];
-            if (src.packed != 0u) {  // this lane's own query: one or two u64 words, a tile is one coalesced load
-                if (q0 + lane < n) {
-                    constexpr uint32_t kOwn = kWords == 3 ? 1u : 2u;
-                    const uint32_t stride = src.packed_stride ? src.packed_stride : kOwn;
-                    const uint64_t *words = reinterpret_cast<const uint64_t *>(kmers) + (q0 + lane) * stride;
-                    if (kWords == 3 && src.place_inline != 0u) {  // {query, place}: one 16-byte load
-                        const uint4 e = *reinterpret_cast<const uint4 *>(words);
-                        staged_next[0].x = e.x;
-                        staged_next[0].y = e.y;
-                        staged_out = e.z;
-                    } else {
-                        const uint2 a = *reinterpret_cast<const uint2 *>(words);
-                        staged_next[0].x = a.x;
-                        staged_next[0].y = a.y;
-                        if constexpr (kWords == 6) {
-                            const uint2 b = *reinterpret_cast<const uint2 *>(words + 1);
-                            staged_next[0].z = b.x;
-                            staged_next[0].w = b.y;
-                        }
-                        if (src.place_inline != 0u) staged_out = *reinterpret_cast<const uint32_t *>(words + kOwn);
-                    }
+            if constexpr (kPacked) {  // this lane's own query: one or two u64 words, a tile is one coalesced load
+                // One shape of loads whatever the element layout and no branch around them: every result lands in ITS register
+                // and nothing is merged afterwards (a merge is a register copy, and a copy waits for the load).  Lanes beyond
+                // the batch -- or a tile beyond it, once per wave -- read its last query again (never used); a {query, place} element is read as
+                // 8 + 4 bytes of the same 16; without places the 4 bytes are the query's own low word (not used either).
+                constexpr uint32_t kOwn = kWords == 3 ? 1u : 2u;
+                const uint32_t stride = src.packed_stride ? src.packed_stride : kOwn;
+                const uint64_t qi = min(q0 + lane, n - 1u);
+                const uint64_t *words = reinterpret_cast<const uint64_t *>(kmers) + qi * stride;
+                const uint2 a = *reinterpret_cast<const uint2 *>(words);
+                staged_next[0].x = a.x;
+                staged_next[0].y = a.y;
+                if constexpr (kWords == 6) {
+                    const uint2 b = *reinterpret_cast<const uint2 *>(words + 1);
+                    staged_next[0].z = b.x;
+                    staged_next[0].w = b.y;
                 }
+                const uint32_t *place = src.place_inline != 0u ? reinterpret_cast<const uint32_t *>(words + kOwn)
+                                        : src.out_index != nullptr ? src.out_index + qi : reinterpret_cast<const uint32_t *>(words);
+                staged_out = *place;
                 return;
             }
             const uint32_t nbytes = uint32_t(min(uint64_t(kTile), n - q0)) * k;
@@ -409,7 +431,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             staged_next[0].x = d;
         }
     };
-    fetch_tile_bytes(next_tile);
+    fetch_tile_bytes(next_tile, std::true_type{});
     bool prepared = false;  // wave-uniform
     uint32_t prep_kind = 0;
     uint64_t prep_tile = 0;
@@ -423,14 +445,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
         if (prepared && ring_count == 0u) {
             uint64_t pl = 0, ph = total;
             uint32_t skip = 0;
+            // An entry of an escape line (the suffixes of a high-copy repeat; none at all on most indexes) names its flat {l, h}
+            // entry in the side array: fetched HERE and waited for, by the few tiles that hold such a query.  Round 4 first
+            // carried these queries into the search with a flag and fetched the entry as their first step, beside the other
+            // lanes' lines -- nothing waits, but the flag's bookkeeping in every step cost C3 fused, an index without a single
+            // escape line, 2.3 % (18.55 against 18.12 ms, same box); the wait costs only the tiles that meet one.
             bool escaped = false, restart = false;
             if (prep_kind == 1u) {
-                if (table_decode(env, prep_entry, pl, ph)) {
-                    skip = depth;
-                } else if (table_side != nullptr) {  // an escape line: the range comes from the side array, as this query's first step
-                    escaped = true;
-                    skip = depth;
-                } else {  // no side array: from scratch
+                if (table_decode(env, prep_entry, pl, ph)) skip = depth;
+                else escaped = true;
+            }
+            if (__ballot(escaped) != 0ull) {  // wave-uniform, rare
+                if (kSideFetch && table_side != nullptr) {
+                    if (escaped) {
+                        const uint4 e = table_side[pl];
+                        pl = (uint64_t(e.y) << 32) | e.x;
+                        ph = (uint64_t(e.w) << 32) | e.z;
+                        skip = depth;
+                    }
+                } else if (escaped) {  // no side array: from scratch
                     restart = true;
                     pl = 0;
                     ph = total;
@@ -440,13 +473,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             uint32_t prep_w[kWords];
             unpack_words<kWords>(prep_q, skip, prep_w);
             bool pending = prep_kind != 0u;
-            if (pending && !escaped && (prep_rem == 0u || pl == ph)) {  // decided by the table (or an empty index)
+            if (pending && (prep_rem == 0u || pl == ph)) {  // decided by the table (or an empty index)
                 store_count<kReads>(src, place_of(prep_tile * kTile + lane, prep_out), ph - pl);
                 pending = false;
             }
             const uint64_t pend_mask = __ballot(pending);
-            if (counters != nullptr) {
-                count(kCntEscapeQueries, __ballot(escaped || restart));
+            if (counting) {
+                count(kCntEscapeQueries, __ballot(escaped));
+                count(kCntFirstLines, __ballot(escaped && !restart));  // (side-array entries fetched: lines like any other)
                 count(kCntEscapeRestarts, __ballot(restart));
                 count(kCntTableDecided, __ballot(prep_kind != 0u && !pending));
                 count(kCntSearched, pend_mask);
@@ -456,10 +490,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 RingItem it;
                 it.l_lo = uint32_t(pl);
                 it.h_lo = uint32_t(ph);
-                it.meta = uint32_t(pl >> 32) | (uint32_t(ph >> 32) << 8) | (prep_rem << 16) | (lane << 24) | (escaped ? 0x80000000u : 0u);  // l, h < 2^40; rem <= 64
+                it.meta = uint32_t(pl >> 32) | (uint32_t(ph >> 32) << 8) | (prep_rem << 16) | (lane << 24);  // l, h < 2^40; rem <= 64
 #pragma unroll
                 for (int i = 0; i < kWords; ++i) it.w[i] = prep_w[i];
-                it.out = prep_out;
+                if constexpr (kPacked) it.out = prep_out;
                 ws.ring[(ring_head + ring_count + at) & (kRing - 1)] = it;
             }
             ring_tile = prep_tile;  // the ring was empty: everything in it belongs to this tile
@@ -479,8 +513,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
 #pragma unroll
                 for (int i = 0; i < kWords; ++i) w[i] = it.w[i];
                 rem = (it.meta >> 16) & 0xFFu;
-                qid = place_of(ring_tile * kTile + ((it.meta >> 24) & 0x7Fu), it.out);
-                esc = (it.meta >> 31) != 0u;
+                qid = ring_tile * kTile + (it.meta >> 24);
+                if constexpr (kPacked) qid = place_of(qid, it.out);
                 ovf_l = ovf_h = 0u;
                 have = true;
             }
@@ -490,7 +524,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
         }
         // a range outside the index would turn into a wild line address: end such a query with
         // u64::MAX and a status flag instead (never seen on a well-formed index; cheap insurance)
-        const bool broken = have && !esc && (h > total || l > h);
+        const bool broken = have && (h > total || l > h);
         if (broken) {
             atomicOr(flags, kFlagInternal);
             if (debug != nullptr && atomicCAS(reinterpret_cast<unsigned long long *>(debug), 0ull, 1ull) == 0ull) {
@@ -515,8 +549,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             bool looked_up = false, passed = false, filtered = false;
             const uint32_t tile_n0 = staged_n0;  // (fetch_tile_bytes below replaces it with the next tile's)
             const uint4 packed_words = staged_next[0];
-            prep_out = staged_out;
-            if (!kReads && src.packed != 0u) {
+            // (an explicit copy HERE, where the fetched tile has arrived anyway: left to the compiler, the copy moved behind the
+            // next tile's load -- into a scratch register, waited for and copied back: setup stood still for a memory round trip)
+            if constexpr (kPacked) asm volatile("v_mov_b32 %0, %1" : "=v"(prep_out) : "v"(staged_out));
+            if (kPacked) {
                 // (packed queries sit in this lane's registers already)
             } else if (!kReads) {  // the tile's bytes go through LDS (the line area is free between two steps)
 #pragma unroll
@@ -542,7 +578,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             prep_tile = tile;
             if (lane < in_tile) {
                 PackedQuery<kWords> pq;
-                if (!kReads && src.packed != 0u) {
+                if (kPacked) {
                     pack_two_bit<kWords>(k, depth, (uint64_t(packed_words.y) << 32) | packed_words.x, (uint64_t(packed_words.w) << 32) | packed_words.z, pq);
                 } else if (!kReads) {
                     pack_query<false, kWords>(src, depth, stage_bytes + lane * k, q0 + lane, pq);
@@ -588,10 +624,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                     --filter_pause;
                 }
             }
-            if (counters != nullptr) count(kCntTableDecided, __ballot(filtered));
+            if (counting) count(kCntTableDecided, __ballot(filtered));
             prepared = true;
             wave_lds_sync();         // every lane has read its staged bytes: the line area may be overwritten
-            fetch_tile_bytes(next_tile);  // the following tile's bytes start their trip now
+            fetch_tile_bytes(next_tile, std::false_type{});  // the following tile's bytes start their trip now
         }
         // A search step costs the same whether 5 or 64 lanes take it: while lanes are idle and another
         // tile is on its way (prepared; the ring is empty then), fetch that tile's survivors first.  When
@@ -604,25 +640,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
 
         // ---- D: one search step of every busy lane ----
         const uint32_t s1 = w[0] & 7u, s2 = (w[0] >> 3) & 7u;
-        const bool pair = kPair && have && !esc && rem >= 2u && (acgt_bit(s1) & acgt_bit(s2)) != 0u;
+        const bool pair = kPair && have && rem >= 2u && (acgt_bit(s1) & acgt_bit(s2)) != 0u;
         const uint32_t a2 = acgt_code(s1) & 3u, b2 = acgt_code(s2) & 3u;
         constexpr bool s96 = kStride96;  // compile-time: the stride-128 kernel carries no division
-        const uint64_t base = esc ? reinterpret_cast<uint64_t>(table_side) : pair ? reinterpret_cast<uint64_t>(pair_blocks) : reinterpret_cast<uint64_t>(blocks);
+        const uint64_t base = pair ? reinterpret_cast<uint64_t>(pair_blocks) : reinterpret_cast<uint64_t>(blocks);
         // an idle slot names the index's first block (an L2 hit) instead of masking its eight DMA lanes
         // off: one branch-free load instruction per region is cheaper than the exec-mask dance
         const uint64_t dummy = reinterpret_cast<uint64_t>(blocks);
         uint64_t *list = reinterpret_cast<uint64_t *>(ws.lines);  // this step's line addresses: read back before the first line lands
         // the block of l -- and h's own block only when h does not fit the same line (overlapping pair
         // blocks hold 32 positions beyond their own 96)
-        // (a query whose range is still in the side array fetches the line of its 16-byte entry there: eight entries per line)
-        const uint64_t bl = esc ? l >> 3 : pair ? pair_block_of(l, s96) : l >> 8;
+        const uint64_t bl = pair ? pair_block_of(l, s96) : l >> 8;
         const uint64_t start_l = pair ? pair_block_start(bl, s96) : bl << 8;
-        const bool same = esc || (pair ? (h - start_l) < 128u : (h >> 8) == bl);
+        const bool same = pair ? (h - start_l) < 128u : (h >> 8) == bl;
         const uint64_t bh = same ? bl : (pair ? pair_block_of(h, s96) : h >> 8);
         const uint32_t r_l = uint32_t(l - start_l), r_h = uint32_t(h - (same ? start_l : (pair ? pair_block_start(bh, s96) : bh << 8)));
         uint64_t line_l = base + bl * 128u, line_h = base + bh * 128u;
         bool one_line = same;
-        if (!kPair && kWords == 3 && runs && !esc) {  // a bound's line: its run block, or -- found out in the iteration before -- its overflow plane block
+        if (!kPair && !kPacked && kWords == 3 && runs) {  // a bound's line: its run block, or -- found out in the iteration before -- its overflow plane block
             line_l = ovf_l != 0u ? reinterpret_cast<uint64_t>(run_overflow) + uint64_t(ovf_l - 1u) * 128u : reinterpret_cast<uint64_t>(blocks) + (l >> 9) * 128u;
             line_h = ovf_h != 0u ? reinterpret_cast<uint64_t>(run_overflow) + uint64_t(ovf_h - 1u) * 128u : reinterpret_cast<uint64_t>(blocks) + (h >> 9) * 128u;
             one_line = line_l == line_h;
@@ -667,7 +702,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
         }
         __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): every line has landed in LDS (and the table entries of step C are here)
         wave_lds_sync();
-        if (counters != nullptr) {
+        if (counting) {
             count(kCntWaveSteps, 1ull);
             count(kCntLaneSteps, __ballot(act));
             count(kCntPairSteps, __ballot(act && pair));
@@ -677,12 +712,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
         if (act) {
             uint64_t nl, nh;
             bool step_done = true;
-            if (esc) {  // the flat {l, h} entry of this query's table index: no symbol is consumed
-                const uint4 e = ws.lines[line_base(slot_l) + ((uint32_t(l) & 7u) ^ (slot_l & 7u))];
-                nl = (uint64_t(e.y) << 32) | e.x;
-                nh = (uint64_t(e.w) << 32) | e.z;
-                esc = false;
-            } else if (pair) {
+            if (pair) {
                 PairLine L;
                 read_pair_line(ws.lines, slot_l, a2, b2, L);
                 nl = pair_line_bound(L, super_l, r_l);
@@ -691,7 +721,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 nh = pair_line_bound(L, far != 0u ? super_far : super_l, r_h);
                 consume_symbols<kWords>(w, 6);
                 rem -= 2u;
-            } else if (!kPair && kWords == 3 && runs) {
+            } else if (!kPair && !kPacked && kWords == 3 && runs) {
                 uint32_t need_l = 0, need_h = 0;
                 PlaneLine L;
                 nl = nh = 0;
@@ -742,11 +772,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     // Small host batches run as ONE wave and announce their completion in host-visible memory, so that the caller
     // can poll a word instead of paying for a stream synchronisation: every count of this wave is out (system
     // scope) before the word changes.
-    if (counters != nullptr) {
+    if (counting) {
         wave_lds_sync();
         if (lane < uint32_t(kSearchCounters) && lane != uint32_t(kCntFirstLines))
             atomicAdd(reinterpret_cast<unsigned long long *>(counters + lane), uint64_t(ws.cnt[lane]));
-        if (lane == uint32_t(kCntFirstLines)) atomicAdd(reinterpret_cast<unsigned long long *>(counters + lane), uint64_t(ws.cnt[kCntLaneSteps]));
+        if (lane == uint32_t(kCntFirstLines)) atomicAdd(reinterpret_cast<unsigned long long *>(counters + lane), uint64_t(ws.cnt[kCntLaneSteps]) + ws.cnt[kCntFirstLines]);
     }
     if (done != nullptr) {
         __threadfence_system();
@@ -759,13 +789,13 @@ constexpr uint64_t kMaxTiles = 1ull << 32;
 
 // The kernel is persistent: the grid is what the device keeps resident -- workgroups per CU
 // (occupancy API: LDS- and VGPR-bound, capped below) x CUs; tiles are dealt out by atomic tickets.
-template <bool kReads, bool kPair, int kWords, bool kStride96>
+template <bool kReads, bool kPair, int kWords, bool kStride96, bool kPacked>
 uint32_t resident_waves() {
     static const uint32_t cached = [] {
         int device = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&device) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_count_kmers_lanes<kReads, kPair, kWords, kStride96>, 64, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_count_kmers_lanes<kReads, kPair, kWords, kStride96, kPacked>, 64, 0) != hipSuccess ||
             cus <= 0 || per_cu <= 0)
             return 7u * 256u;
         // LDS decides (12.1 / 12.9 KiB -> 12 waves); whole multiples of the four SIMDs only: with
@@ -776,19 +806,19 @@ uint32_t resident_waves() {
             const int want = std::atoi(env);
             if (want > 0) per_cu = want;
         }
-        if (std::getenv("MSBWT_VERBOSE")) std::fprintf(stderr, "[msbwt] lanes kernel <%d,%d,%d,%d>: %d workgroups per CU x %d CUs\n", int(kReads), int(kPair), kWords, int(kStride96), per_cu, cus);
+        if (std::getenv("MSBWT_VERBOSE")) std::fprintf(stderr, "[msbwt] lanes kernel <%d,%d,%d,%d,%d>: %d workgroups per CU x %d CUs\n", int(kReads), int(kPair), kWords, int(kStride96), int(kPacked), per_cu, cus);
         return uint32_t(cus) * uint32_t(per_cu);
     }();
     return cached;
 }
 
-template <bool kReads, bool kPair, int kWords, bool kStride96>
+template <bool kReads, bool kPair, int kWords, bool kStride96, bool kPacked>
 hipError_t launch_variant(hipStream_t stream, const IndexView &ix, const QuerySource &src, uint32_t *flags) {
     const uint4 *table = static_cast<const uint4 *>(ix.table.entries);
     const uint32_t *filter = table ? ix.table.filter : nullptr;
     const uint32_t filter_mask = filter ? uint32_t((1ull << (2 * ix.table.filter_depth)) - 1ull) : 0u;
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
-    const uint64_t waves = std::min<uint64_t>(tiles, resident_waves<kReads, kPair, kWords, kStride96>());
+    const uint64_t waves = std::min<uint64_t>(tiles, resident_waves<kReads, kPair, kWords, kStride96, kPacked>());
     if (tiles > kMaxTiles) return hipErrorInvalidValue;
     // Ticket counters are only needed when there are more tiles than waves; without them (small batches, the
     // single-query path: no memset, no atomics) the kernel strides statically.
@@ -799,7 +829,7 @@ hipError_t launch_variant(hipStream_t stream, const IndexView &ix, const QuerySo
     }
     // tiles per ticket: about eight tickets per wave at least, sixteen tiles at most
     const uint32_t grain = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(16, tiles / (waves * 8))));
-    hipLaunchKernelGGL((k_count_kmers_lanes<kReads, kPair, kWords, kStride96>), dim3(uint32_t(waves)), dim3(64), 0, stream,
+    hipLaunchKernelGGL((k_count_kmers_lanes<kReads, kPair, kWords, kStride96, kPacked>), dim3(uint32_t(waves)), dim3(64), 0, stream,
                        static_cast<const uint4 *>(ix.blocks), ix.total, table, uint32_t(ix.table.depth), ix.table.packed ? 1u : 0u, filter, filter_mask,
                        table ? static_cast<const uint4 *>(ix.table.side) : nullptr, static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags, ix.debug,
                        tickets ? static_cast<unsigned long long *>(ix.tile_counter) : nullptr, grain, waves == 1 ? ix.done : nullptr, ix.done_seq, ix.counters,
@@ -807,11 +837,11 @@ hipError_t launch_variant(hipStream_t stream, const IndexView &ix, const QuerySo
     return hipGetLastError();
 }
 
-template <bool kReads>
+template <bool kReads, bool kPacked>
 hipError_t launch_shape(bool pair, bool longk, hipStream_t stream, const IndexView &ix, const QuerySource &src, uint32_t *flags) {
-    if (!pair) return longk ? launch_variant<kReads, false, 6, false>(stream, ix, src, flags) : launch_variant<kReads, false, 3, false>(stream, ix, src, flags);
-    if (ix.pair_stride96) return longk ? launch_variant<kReads, true, 6, true>(stream, ix, src, flags) : launch_variant<kReads, true, 3, true>(stream, ix, src, flags);
-    return longk ? launch_variant<kReads, true, 6, false>(stream, ix, src, flags) : launch_variant<kReads, true, 3, false>(stream, ix, src, flags);
+    if (!pair) return longk ? launch_variant<kReads, false, 6, false, kPacked>(stream, ix, src, flags) : launch_variant<kReads, false, 3, false, kPacked>(stream, ix, src, flags);
+    if (ix.pair_stride96) return longk ? launch_variant<kReads, true, 6, true, kPacked>(stream, ix, src, flags) : launch_variant<kReads, true, 3, true, kPacked>(stream, ix, src, flags);
+    return longk ? launch_variant<kReads, true, 6, false, kPacked>(stream, ix, src, flags) : launch_variant<kReads, true, 3, false, kPacked>(stream, ix, src, flags);
 }
 
 }  // namespace
@@ -824,7 +854,9 @@ hipError_t launch_lanes(const IndexView &ix, const QuerySource &src, bool reads,
     pair = pair && ix.pair_blocks != nullptr && ix.block_format == kBlocksPlanes;
     if (ix.block_format != kBlocksPlanes && src.packed) return hipErrorInvalidValue;  // (packed queries on run blocks are unpacked by the caller)
     const bool longk = src.k > uint32_t(kMaxShortK);
-    return reads ? launch_shape<true>(pair, longk, stream, ix, src, flags) : launch_shape<false>(pair, longk, stream, ix, src, flags);
+    if (reads) return src.packed ? hipErrorInvalidValue : launch_shape<true, false>(pair, longk, stream, ix, src, flags);
+    if ((src.out_index != nullptr || src.place_inline != 0u) && !src.packed) return hipErrorInvalidValue;  // (counts are placed for packed queries only)
+    return src.packed ? launch_shape<false, true>(pair, longk, stream, ix, src, flags) : launch_shape<false, false>(pair, longk, stream, ix, src, flags);
 }
 
 }  // namespace msbwt
