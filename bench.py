@@ -600,6 +600,8 @@ def main():
     def run_steps(batch, nsteps, narrow, a, b, per_rank, native=None, exchange=True):
         """nsteps passes over queries [a, b) of the batch; N > 1: + all_gather of `per_rank` counts per rank"""
         outs = [torch.zeros(per_rank, dtype=torch.int64, device=dev) for _ in range(2)]
+        if os.environ.get("MSBWT_VERBOSE"):  # (with the library's own load lines: where everything a step touches sits)
+            log("buffers: queries %#x counts %#x" % ((batch.reads if batch.reads is not None else batch.q).data_ptr(), outs[0].data_ptr()))
         if not multi:
             for _ in range(nsteps):
                 batch.count_into(outs[0], a, b)
