@@ -3,7 +3,7 @@
 build of the index, with every array at the same address.)  Builds several instances of the same index side by side, times the
 same batch on each of them in turn, several rounds; then the same without the packed table's side array -- the one thing the
 build does not lay out deterministically (escape lines take their side groups through an atomic cursor).
-   python tools/instance_probe.py [workload] [instances] [rounds]"""
+   python tools/instance_probe.py [workload] [instances] [rounds] [sides, e.g. 1 or 10]"""
 import os
 import sys
 
@@ -38,7 +38,8 @@ def main():
             times.append(ev0.elapsed_time(ev1))
         return times
 
-    for side in (1, 0):
+    sides = [int(c) for c in (sys.argv[4] if len(sys.argv) > 4 else "10")]
+    for side in sides:
         inst = []
         for _ in range(ninst):
             b = msbwt.RleBWT()
