@@ -1,6 +1,7 @@
 #!/bin/bash
 # same box: the round-3 tree (.r03_tree, commit f8ae2d7) against this one on the lines where set-up, not memory, decides:
 # C2 random 21-mers, C3 fused, the 1e9-random-31-mer line at human scale
+# (the old tree is a worktree made beforehand, here: git worktree add --detach .r03_tree f8ae2d7 -- git-ignored, but it travels to the GPU box)
 out=$PWD/gpurun_out/r4ab; mkdir -p $out
 python -c "import __graft_entry__ as g; g.build()" > $out/build.log 2>&1 || exit 1
 (cd .r03_tree && python -c "import __graft_entry__ as g; g.build()" > $out/build_r03.log 2>&1) || exit 1
