@@ -155,6 +155,90 @@ int hip_fail(msbwt_rle *h, hipError_t e, const char *what) {
         if (e_ != hipSuccess) return hip_fail(h, e_, #expr);  \
     } while (0)
 
+// EXPERIMENT, off unless MSBWT_BIG_ALLOC=chunks (round 4 found that the speed of a launch on a C4-sized index follows the PHYSICAL
+// memory its 2.6 GB of pair blocks were given): the pair blocks from whole 1 GiB physical chunks mapped into a
+// 1 GiB-aligned virtual range (hipMemCreate / hipMemMap -- the sequence tools/ubench_placement.hip runs) instead of hipMalloc.  Any
+// failure on the way falls back to hipMalloc; big_free takes either kind.
+struct ChunkedRange {
+    void *base = nullptr;
+    size_t size = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+};
+std::mutex g_ranges_mu;
+std::vector<ChunkedRange> g_ranges;
+
+void unmap_range(ChunkedRange *r, size_t mapped) {
+    if (r->base && mapped) (void)hipMemUnmap(r->base, mapped);
+    for (auto h : r->handles) (void)hipMemRelease(h);
+    if (r->base) (void)hipMemAddressFree(r->base, r->size);
+    (void)hipGetLastError();
+}
+
+hipError_t big_alloc(void **out, size_t bytes) {
+    const char *mode = std::getenv("MSBWT_BIG_ALLOC");
+    if (!mode || std::strcmp(mode, "chunks") != 0 || bytes < (size_t(64) << 20)) return hipMalloc(out, bytes);
+    int device = 0;
+    hipMemAllocationProp prop = {};
+    size_t gran = 0;
+    if (hipGetDevice(&device) != hipSuccess) return hipMalloc(out, bytes);
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0 || ((size_t(1) << 30) % gran) != 0) {
+        (void)hipGetLastError();
+        return hipMalloc(out, bytes);
+    }
+    const size_t chunk = size_t(1) << 30;
+    ChunkedRange r;
+    r.size = (bytes + gran - 1) / gran * gran;
+    size_t mapped = 0;
+    bool ok = hipMemAddressReserve(&r.base, r.size, chunk, nullptr, 0) == hipSuccess;
+    while (ok && mapped < r.size) {
+        const size_t piece = std::min(chunk, r.size - mapped);
+        hipMemGenericAllocationHandle_t h;
+        ok = hipMemCreate(&h, piece, &prop, 0) == hipSuccess;
+        if (!ok) break;
+        r.handles.push_back(h);
+        ok = hipMemMap(static_cast<char *>(r.base) + mapped, piece, 0, h, 0) == hipSuccess;
+        if (ok) mapped += piece;
+    }
+    if (ok) {
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        ok = hipMemSetAccess(r.base, r.size, &acc, 1) == hipSuccess;
+    }
+    if (!ok) {
+        unmap_range(&r, mapped);
+        return hipMalloc(out, bytes);
+    }
+    if (std::getenv("MSBWT_VERBOSE")) std::fprintf(stderr, "[msbwt] %zu bytes from %zu physical chunks at %p\n", bytes, r.handles.size(), r.base);
+    *out = r.base;
+    std::lock_guard<std::mutex> lock(g_ranges_mu);
+    g_ranges.push_back(std::move(r));
+    return hipSuccess;
+}
+
+void big_free(void *p) {
+    if (!p) return;
+    ChunkedRange r;
+    {
+        std::lock_guard<std::mutex> lock(g_ranges_mu);
+        for (size_t i = 0; i < g_ranges.size(); ++i)
+            if (g_ranges[i].base == p) {
+                r = std::move(g_ranges[i]);
+                g_ranges.erase(g_ranges.begin() + long(i));
+                break;
+            }
+    }
+    if (!r.base) {
+        (void)hipFree(p);
+        return;
+    }
+    (void)hipDeviceSynchronize();  // (hipFree waits for the device by itself; an unmap does not)
+    unmap_range(&r, r.size);
+}
+
 // Measurement aid (tools/placement_probe.py): MSBWT_PROBE_PADS="a,b,c,d" allocates -- and never frees -- a pad of that many KiB
 // right before the superblock table (a), the table's side array (b), a launch slot's ticket counters (c) and the status block
 // (d) are allocated, so that ONE small array at a time can be moved inside the runtime's 2 MiB fragments.
@@ -179,7 +263,7 @@ void release_index(msbwt_rle *h) {
     if (h->d_filter) (void)hipFree(h->d_filter);
     h->d_filter = nullptr;
     h->filter_depth = 0;
-    if (h->d_pair_blocks) (void)hipFree(h->d_pair_blocks);
+    if (h->d_pair_blocks) big_free(h->d_pair_blocks);
     if (h->d_pair_super) (void)hipFree(h->d_pair_super);
     h->d_blocks = h->d_table = h->d_pair_blocks = h->d_pair_super = nullptr;
     h->pair_bytes = 0;
@@ -482,7 +566,7 @@ double probe_typical_width(msbwt_rle *h) {
 // built on the device from them.  Default policy: build it when it fits in half of what is
 // still free in HBM after the blocks (it is a pure speed-for-memory trade).
 int rebuild_pair_index(msbwt_rle *h) {
-    if (h->d_pair_blocks) (void)hipFree(h->d_pair_blocks);
+    if (h->d_pair_blocks) big_free(h->d_pair_blocks);
     if (h->d_pair_super) (void)hipFree(h->d_pair_super);
     h->d_pair_blocks = h->d_pair_super = nullptr;
     h->pair_bytes = 0;
@@ -514,7 +598,7 @@ int rebuild_pair_index(msbwt_rle *h) {
         if (!know_free || sz.pair_block_bytes + sz.scratch_bytes > free_b / 2) return MSBWT_OK;
     }
     void *scratch = nullptr;
-    hipError_t e = hipMalloc(&h->d_pair_blocks, sz.pair_block_bytes);
+    hipError_t e = big_alloc(&h->d_pair_blocks, sz.pair_block_bytes);
     if (e == hipSuccess) probe_pad(0);
     if (e == hipSuccess) e = hipMalloc(&h->d_pair_super, sz.super_bytes);
     if (e == hipSuccess) e = hipMalloc(&scratch, sz.scratch_bytes);
@@ -522,7 +606,7 @@ int rebuild_pair_index(msbwt_rle *h) {
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (scratch) (void)hipFree(scratch);
     if (e != hipSuccess) {
-        if (h->d_pair_blocks) (void)hipFree(h->d_pair_blocks);
+        if (h->d_pair_blocks) big_free(h->d_pair_blocks);
         if (h->d_pair_super) (void)hipFree(h->d_pair_super);
         h->d_pair_blocks = h->d_pair_super = nullptr;
         h->pair_overlap_bytes = 0;
@@ -1671,7 +1755,7 @@ int msbwt_rle_set_memory_budget(msbwt_rle *h, uint64_t bytes) {
     if (h->d_table) (void)hipFree(h->d_table);
     if (h->d_table_side) (void)hipFree(h->d_table_side);
     if (h->d_filter) (void)hipFree(h->d_filter);
-    if (h->d_pair_blocks) (void)hipFree(h->d_pair_blocks);
+    if (h->d_pair_blocks) big_free(h->d_pair_blocks);
     if (h->d_pair_super) (void)hipFree(h->d_pair_super);
     h->d_table = h->d_table_side = h->d_pair_blocks = h->d_pair_super = nullptr;
     h->d_filter = nullptr;
