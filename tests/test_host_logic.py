@@ -406,3 +406,20 @@ def test_two_bit_packing_layout():
         q = np.array([[1, 2, bad, 3]], dtype=np.uint8)
         with pytest.raises(msbwt.MsbwtError):
             msbwt.rle_bwt.pack_2bit(q)
+
+
+def test_tools_and_run_scripts_are_well_formed():
+    """The measurement tools only ever run on the GPU box: a syntax error there costs a box.  Every tools/*.py compiles and
+    every tools/**/*.sh passes `bash -n`."""
+    import glob
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scripts = sorted(glob.glob(os.path.join(root, "tools", "*.py")))
+    assert scripts
+    for path in scripts:
+        with open(path) as f:
+            compile(f.read(), path, "exec")  # (syntax only: nothing is imported, nothing is written)
+    shells = sorted(glob.glob(os.path.join(root, "tools", "*.sh")) + glob.glob(os.path.join(root, "tools", "runs_r*", "*.sh")))
+    assert shells
+    for path in shells:
+        assert subprocess.run(["bash", "-n", path], capture_output=True).returncode == 0, path
