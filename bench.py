@@ -15,7 +15,9 @@ geometric select the independent-symbol stand-ins of rounds 1-2) -- and 3e8 PRES
                  symbols, suffix-sorted on the host in this run) of a genome WITH REPEATS (synth.REPEAT_FAMILIES): 1e8
                  read-derived 31-mers, with parity, roofline and the kernel's own counters (lines per query, second-line rate,
                  share of queries on escape lines of the packed table); `library_ordered` = the same with the library's own
-                 batch-ordering pass forced on;
+                 batch-ordering pass forced on; `pair_blocks_rebuilt` = the same batch timed again after the pair blocks (+ table)
+                 were freed and rebuilt: launches on a C4-sized index run in one of two modes 15 % apart, decided by the memory
+                 the pair blocks were given (DESIGN.md section 5) -- a ratio far from 1 says the line was measured in the other one;
   c4_real_reads  the same on the random genome of rounds 2-3.
 Other workloads: c2, c3 (--fused = configs[2]), c4, big.
 
@@ -1061,6 +1063,27 @@ def main():
                     args.steps = saved
                     del u4
                 bwt4.set_batch_order(-1)
+            # Which of this line's two modes the build is in (the time of a launch on a C4-sized index follows the physical
+            # memory its pair blocks were given, 15 % apart): the pair blocks (+ table) rebuilt once, the same batch timed again -- a slow
+            # line can then be told from a regression by its own record.
+            try:
+                saved = args.steps
+                args.steps = min(args.steps, 5)
+                try:
+                    t_rebuild = time.time()
+                    bwt4.set_pair_index(1 if bwt4.get_pair_index() else 0)
+                    t_rebuild = time.time() - t_rebuild
+                    p4, _, pel4, pkms4, _, _ = measure(Batch(bwt4, d_q4, 0, None, 31), 0, n4, n4)
+                    line["pair_blocks_rebuilt"] = {"ms_per_step": pel4 / args.steps * 1e3, "kernel_ms": pkms4, "rebuild_s": t_rebuild,
+                                                   "counts_equal_first_run": bool(torch.equal(p4, o4)),
+                                                   "ratio_to_the_line": (pel4 / args.steps) / (el4 / saved),
+                                                   "note": "msbwt_rle_set_pair_index on the loaded index frees and rebuilds the pair blocks and the table; the same "
+                                                           "batch timed again.  A ratio far from 1 means the two builds sit in different modes of this line"}
+                    del p4
+                finally:
+                    args.steps = saved
+            except Exception as e:  # (a diagnostic: never the reason a bench line is lost)
+                line["pair_blocks_rebuilt"] = {"error": repr(e)}
             if not args.no_oracle:
                 from oracle import oracle as orc
                 ref4 = orc.OracleRleBWT(8)

@@ -58,6 +58,10 @@ def test_bench_default_run_carries_the_real_msbwt_line():
     assert rep["parity"]["max_count_in_sample"] > 4 * rep["parity"]["mean_count_in_sample"]   # repeats: some k-mers occur far more often than the coverage
     assert not rep["batch_ordered_by_the_library"] and rep["library_ordered"]["counts_equal_unordered_run"] and rep["library_ordered"]["value"] > 0
     assert r["roofline"]["layout_algorithmic"]["lines_per_query"] > 1 and "telemetry" in r
+    # ... and which of the line's two modes the build is in: the pair blocks rebuilt, the same batch timed again
+    for key in ("c4_repeats", "c4_real_reads"):
+        again = r[key]["pair_blocks_rebuilt"]
+        assert "error" not in again and again["counts_equal_first_run"] and again["ms_per_step"] > 0 and again["ratio_to_the_line"] > 0
 
 
 def test_bench_default_is_the_metric_config():
