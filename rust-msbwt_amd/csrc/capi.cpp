@@ -155,10 +155,11 @@ int hip_fail(msbwt_rle *h, hipError_t e, const char *what) {
         if (e_ != hipSuccess) return hip_fail(h, e_, #expr);  \
     } while (0)
 
-// EXPERIMENT, off unless MSBWT_BIG_ALLOC=chunks (round 4 found that the speed of a launch on a C4-sized index follows the PHYSICAL
+// EXPERIMENT, off unless MSBWT_BIG_ALLOC=chunks | contiguous (round 4 found that the speed of a launch on a C4-sized index follows the PHYSICAL
 // memory its 2.6 GB of pair blocks were given): the pair blocks from whole 1 GiB physical chunks mapped into a
-// 1 GiB-aligned virtual range (hipMemCreate / hipMemMap -- the sequence tools/ubench_placement.hip runs) instead of hipMalloc.  Any
-// failure on the way falls back to hipMalloc; big_free takes either kind.
+// 1 GiB-aligned virtual range (hipMemCreate / hipMemMap -- the sequence tools/ubench_placement.hip runs) instead of hipMalloc, or
+// ("contiguous") from hipExtMallocWithFlags(hipDeviceMallocContiguous).  Any failure on the way falls back to hipMalloc; big_free
+// takes every kind.
 struct ChunkedRange {
     void *base = nullptr;
     size_t size = 0;
@@ -176,6 +177,14 @@ void unmap_range(ChunkedRange *r, size_t mapped) {
 
 hipError_t big_alloc(void **out, size_t bytes) {
     const char *mode = std::getenv("MSBWT_BIG_ALLOC");
+    if (mode && std::strcmp(mode, "contiguous") == 0 && bytes >= (size_t(64) << 20)) {  // physically contiguous, by the runtime's own flag
+        if (hipExtMallocWithFlags(out, bytes, hipDeviceMallocContiguous) == hipSuccess) {
+            if (std::getenv("MSBWT_VERBOSE")) std::fprintf(stderr, "[msbwt] %zu contiguous bytes at %p\n", bytes, *out);
+            return hipSuccess;
+        }
+        (void)hipGetLastError();
+        return hipMalloc(out, bytes);
+    }
     if (!mode || std::strcmp(mode, "chunks") != 0 || bytes < (size_t(64) << 20)) return hipMalloc(out, bytes);
     int device = 0;
     hipMemAllocationProp prop = {};
