@@ -698,7 +698,9 @@ def main():
         nqs = max(1, b - a)
         info = the_bwt.table_info()
         return {"queries": b - a, "raw": c,
-                "lines_per_query": (c["first_lines"] + c["second_lines"]) / nqs + (1.0 if the_bwt.get_table_depth() else 0.0),
+                # (sparse-table lookups are search steps of their own: their bucket lines are among first_lines already)
+                "lines_per_query": (c["first_lines"] + c["second_lines"]) / nqs + (0.0 if c.get("table_steps") else (1.0 if the_bwt.get_table_depth() else 0.0)),
+                "table_lines_per_query": c.get("table_steps", 0) / nqs, "sparse_table": the_bwt.sparse_table_info(),
                 "search_lines_per_query": (c["first_lines"] + c["second_lines"]) / nqs,
                 "steps_per_searched_query": c["lane_steps"] / max(1, c["searched"]),
                 "second_line_rate": c["second_lines"] / max(1, c["lane_steps"]),

@@ -239,6 +239,37 @@ int msbwt_rle_table_info(const msbwt_rle *bwt, uint64_t *lines, uint64_t *escape
  * of HBM free once plane and pair blocks are in place. */
 int msbwt_auto_table_depths(uint64_t total_symbols, uint64_t free_hbm_bytes, int pair_index, int *flat_depth, int *packed_depth);
 int msbwt_rle_get_table_packed(const msbwt_rle *bwt);
+/* Sparse suffix table (the reference's stubbed kmer_cache, src/msbwt_core.rs:133-146 / src/rle_bwt.rs:332-346, taken past what a
+ * direct-address table can hold): the ranges of the `depth`-symbol suffixes that OCCUR in the BWT, 16 <= depth <= 24, as a hashed
+ * table of 128-byte buckets of 14 entries (layout and hash: rust-msbwt_amd/csrc/sparse_table.hpp).  The direct table above has 4^depth
+ * entries whatever the data -- 73 GB at depth 17, of which a 30x human read set can fill 17 % and a chr20-sized one 0.4 % -- while a
+ * table of the present suffixes reaches depth 23 in about 14 bytes per distinct 23-mer: every present 31-mer is three pair steps
+ * (of seven) shorter.  One lookup = one random 128-byte line, fetched like any search step's; the table is complete, so a miss is
+ * count 0 (the early exit of src/msbwt_core.rs:151-153); entries 255 or more wide (suffixes of high-copy repeats) keep their range
+ * in a side array, one more line.  Built on the device by frontier expansion with the index's own rank code (each present d-mer ->
+ * its <= 16 present (d+2)-mers by one pair step), which also yields the DISTINCT counts per depth that size it.  Needs the pair
+ * index; the one-query-per-lane kernel uses it for every batch with k >= depth, shorter k-mers (and k-mers with '$' / 'N' among
+ * their last `depth` symbols) use the direct table, which then stays small (packed depth 15 at most when automatic).
+ * depth: -1 = automatic (default: the deepest depth <= 23 whose table fits HBM -- and a memory budget, if one is set -- with an
+ * eighth of the device left free; none if no depth fits, e.g. a read set whose error k-mers outnumber everything), 0 = off, 16..24 =
+ * exactly that depth (an error if it cannot be built).  MSBWT_SPARSE_TABLE=<depth>|auto|0 in the environment sets the initial mode.
+ * Takes effect immediately if an index is loaded.  Results never change.
+ * msbwt_rle_get_sparse_table: depth of the table in HBM, 0 = none.
+ * msbwt_rle_sparse_table_info: out[MSBWT_SPARSE_INFO_WORDS] = [0] depth, [1] entries, [2] buckets, [3] bytes of the bucket lines,
+ * [4] entries in the side array, [5] its bytes, [6] entries displaced to a later bucket, [7] depth of the direct table the build
+ * started from, [9] buckets a lookup may go beyond its own, [10 + d] DISTINCT d-symbol suffixes that occur (d = 0..24; 0 where the
+ * build did not pass: it advances two symbols at a time), [35 + d] of which 255 or more wide.  The counts are kept even when no
+ * table was built.
+ * msbwt_sparse_hash / msbwt_sparse_table_shape: the table's hash and sizing as pure functions (no device needed).
+ * msbwt_rle_download_sparse_table: copies the bucket lines (and the side array) to the host; returns the bytes of the lines,
+ * SIZE_MAX without a table or on error (tests check every entry against the oracle). */
+#define MSBWT_SPARSE_INFO_WORDS 64
+int msbwt_rle_set_sparse_table(msbwt_rle *bwt, int depth);
+int msbwt_rle_get_sparse_table(const msbwt_rle *bwt);
+int msbwt_rle_sparse_table_info(const msbwt_rle *bwt, uint64_t *out);
+int msbwt_sparse_hash(uint64_t key, int depth, uint64_t nbuckets, uint32_t *bucket, uint32_t *tag);
+int msbwt_sparse_table_shape(int depth, uint64_t entries, uint64_t *nbuckets, int *probe);
+size_t msbwt_rle_download_sparse_table(const msbwt_rle *bwt, void *out_lines, size_t cap_bytes, void *out_side, size_t cap_side_bytes);
 /* Presence filter: one bit per ACGT suffix of length min(12, table depth), set when some table
  * entry with that suffix is a non-empty range; at most 2 MiB, so it lives in L2 and decides
  * absent k-mers (random queries, small genomes) without fetching the table line.  Built on the
@@ -312,7 +343,8 @@ int msbwt_rle_search_kernel_for(const msbwt_rle *bwt, size_t k);
  * fetch each), [2] of which two-symbol steps, [3] steps that needed a second line (range over two blocks), [4] steps a query
  * waited because the second-line slots of its wave were taken, [5] queries whose packed-table line is an escape line,
  * [6] of which searched from scratch (no side array), [7] queries decided by the table / presence filter alone, [8] queries
- * that entered the search, [9] first lines fetched; the rest 0.  msbwt_rle_search_counters copies the block out and
+ * that entered the search, [9] first lines fetched, [10] sparse-table bucket lines fetched (included in [1]), [11] of which did not
+ * hold the key although the bucket had displaced entries (the lookup went on to the next bucket); the rest 0.  msbwt_rle_search_counters copies the block out and
  * zeroes it (synchronises `hip_stream`, on which the counted launches ran).  Results never change. */
 #define MSBWT_SEARCH_COUNTERS 16
 int msbwt_rle_set_search_counters(msbwt_rle *bwt, int enabled);

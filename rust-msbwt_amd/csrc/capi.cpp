@@ -26,6 +26,7 @@
 #include "rle_codec.hpp"
 #include "run_build.hpp"
 #include "run_index.hpp"
+#include "sparse_build.hpp"
 
 using namespace msbwt;
 
@@ -56,6 +57,14 @@ struct msbwt_rle {
     uint64_t table_side_bytes = 0;
     uint64_t table_lines = 0, table_escape_lines = 0;  // of the packed table in HBM
     int wanted_table_side = 1;       // 0 = no side array (queries of escape lines search from scratch, as until round 3)
+    // sparse suffix table (sparse_table.hpp): ranges of the suffixes that occur, deeper than the direct table reaches
+    void *d_sparse = nullptr;        // (nbuckets + probe) lines of 128 bytes
+    void *d_sparse_side = nullptr;   // 16-byte {l, h} entries of its ESCAPE entries
+    uint64_t sparse_bytes = 0, sparse_side_bytes = 0;
+    uint32_t sparse_nbuckets = 0, sparse_probe = 0;
+    int sparse_depth = 0;
+    int wanted_sparse = -1;          // -1 = automatic (beside a pair index, as deep as the data and HBM allow, at most 23), 0 = off, 16..24 = that depth
+    SparseBuildReport sparse_report{};
     bool counting = false;           // search counters wanted (msbwt_rle_set_search_counters)
     int wanted_table_packed = -1; // -1 = pack when the data warrants it and it fits, 0 = never, 1 = whenever a pair index exists
     uint32_t *d_filter = nullptr;   // presence bits over the low 2*filter_depth index bits of the table
@@ -260,6 +269,16 @@ void probe_pad(int which) {
     if (kib[which] > 0 && hipMalloc(&pad, size_t(kib[which]) * 1024) != hipSuccess) (void)hipGetLastError();
 }
 
+void release_sparse(msbwt_rle *h) {
+    if (h->d_sparse) (void)hipFree(h->d_sparse);
+    if (h->d_sparse_side) (void)hipFree(h->d_sparse_side);
+    h->d_sparse = h->d_sparse_side = nullptr;
+    h->sparse_bytes = h->sparse_side_bytes = 0;
+    h->sparse_nbuckets = h->sparse_probe = 0;
+    h->sparse_depth = 0;
+    h->sparse_report = SparseBuildReport{};
+}
+
 void release_index(msbwt_rle *h) {
     if (h->d_blocks) (void)hipFree(h->d_blocks);
     if (h->d_overflow) (void)hipFree(h->d_overflow);
@@ -272,6 +291,7 @@ void release_index(msbwt_rle *h) {
     if (h->d_filter) (void)hipFree(h->d_filter);
     h->d_filter = nullptr;
     h->filter_depth = 0;
+    release_sparse(h);
     if (h->d_pair_blocks) big_free(h->d_pair_blocks);
     if (h->d_pair_super) (void)hipFree(h->d_pair_super);
     h->d_blocks = h->d_table = h->d_pair_blocks = h->d_pair_super = nullptr;
@@ -303,6 +323,13 @@ IndexView view_of(msbwt_rle *h) {
     v.pair_super = static_cast<const uint64_t *>(h->d_pair_super);
     v.pair_stride96 = h->d_pair_blocks && h->pair_stride == 96;
     v.search_kernel = h->search_kernel;
+    if (h->d_sparse && h->d_pair_blocks) {
+        v.sparse.lines = h->d_sparse;
+        v.sparse.nbuckets = h->sparse_nbuckets;
+        v.sparse.depth = uint32_t(h->sparse_depth);
+        v.sparse.probe = h->sparse_probe;
+        v.sparse.side = h->d_sparse_side;
+    }
     v.debug = h->d_flags ? reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(h->d_flags) + 64) : nullptr;
     return v;  // tile_counter: with_tickets()
 }
@@ -428,7 +455,114 @@ int rebuild_filter(msbwt_rle *h) {
     return MSBWT_OK;
 }
 
-int rebuild_table(msbwt_rle *h) {
+// Sparse suffix table (sparse_table.hpp) from the flat direct table that is in HBM right now (its parent; none: from the root).
+// Optional structure: when nothing fits (or a step fails for want of memory) the handle simply has none -- unless a depth was
+// asked for explicitly, which is then an error.  keep_free: bytes that what is built afterwards (the packed direct table) still
+// needs; allowance: what a memory budget leaves for this table (kNoBudget: none in force).
+int build_sparse(msbwt_rle *h, uint64_t keep_free, uint64_t allowance) {
+    release_sparse(h);
+    const bool verbose = std::getenv("MSBWT_VERBOSE") != nullptr;
+    const bool explicit_depth = h->wanted_sparse > 0;
+    const void *flat = (h->d_table && !h->table_packed) ? h->d_table : nullptr;
+    const int flat_depth = flat ? h->table_depth : 0;
+    const int max_depth = explicit_depth ? h->wanted_sparse : kSparseAutoDepth;
+    if (max_depth <= flat_depth || max_depth < kSparseMinDepth) return explicit_depth ? fail(h, MSBWT_ERR_INVALID_ARG, "sparse table depth must exceed the direct table's") : MSBWT_OK;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return MSBWT_OK;
+    struct Temps {
+        void *work = nullptr, *counts = nullptr, *lines = nullptr, *side = nullptr;
+        ~Temps() {
+            for (void *p : {work, counts, lines, side})
+                if (p) (void)hipFree(p);
+        }
+    } tmp;
+    const size_t work_bytes = sparse_work_bytes(free_b);
+    auto optional = [&](hipError_t e, const char *what) -> int {  // an optional structure gives way; an explicit wish does not
+        (void)hipGetLastError();
+        if (explicit_depth) return hip_fail(h, e, what);
+        if (verbose) std::fprintf(stderr, "[msbwt] sparse table: %s: %s -- none built\n", what, hipGetErrorString(e));
+        return MSBWT_OK;
+    };
+    hipError_t e = hipMalloc(&tmp.work, work_bytes);
+    if (e != hipSuccess) return optional(e, "scratch");
+    SparseBuildReport rep;
+    e = sparse_count_levels(view_of(h), flat, flat_depth, max_depth, tmp.work, work_bytes, &rep, h->stream);
+    if (e != hipSuccess) return optional(e, "sizing pass");
+    if (verbose) {
+        std::fprintf(stderr, "[msbwt] sparse table: distinct suffixes by length:");
+        for (int d = flat_depth; d <= max_depth; ++d)
+            if (rep.distinct[d]) std::fprintf(stderr, " %d: %llu (%llu wide)", d, (unsigned long long)rep.distinct[d], (unsigned long long)rep.escapes[d]);
+        std::fprintf(stderr, "\n");
+    }
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return MSBWT_OK;
+    const uint64_t spare = keep_free + total_b / 8;  // an eighth of the HBM stays free for the caller's batches
+    const uint64_t avail = std::min<uint64_t>(allowance, uint64_t(free_b) > spare ? uint64_t(free_b) - spare : 0);
+    int chosen = 0;
+    uint64_t nbuckets = 0;
+    for (int d = max_depth; d >= kSparseMinDepth && d > flat_depth; --d) {
+        if (explicit_depth ? d != max_depth : rep.distinct[d] == 0) continue;  // not a level of this pass (the other parity), or nothing occurs
+        const uint64_t needed = uint64_t(double(rep.distinct[d]) / kSparseLoad) + 1, nb = sparse_buckets_for(d, rep.distinct[d]);
+        const uint64_t lines = nb + kSparseMaxProbe;
+        if (lines > 0xFFFFFFFFull) continue;
+        // a table that the tags force to be much larger than its entries need is not worth its depth (toy indexes stay small)
+        if (!explicit_depth && sparse_min_buckets(d) > std::max<uint64_t>(8 * needed, 65536)) continue;
+        if (lines * 128 + rep.escapes[d] * 16 + lines * sizeof(uint32_t) > avail) {
+            if (explicit_depth) return fail(h, MSBWT_ERR_HIP, "the sparse table of the requested depth does not fit in HBM");
+            continue;
+        }
+        chosen = d;
+        nbuckets = nb;
+        break;
+    }
+    if (!chosen) {
+        h->sparse_report = rep;  // (the distinct counts are worth keeping: msbwt_rle_sparse_table_info)
+        if (verbose) std::fprintf(stderr, "[msbwt] sparse table: no depth fits %.2f GB -- none built\n", double(avail) / 1e9);
+        return explicit_depth ? fail(h, MSBWT_ERR_HIP, "no sparse table could be built") : MSBWT_OK;
+    }
+    const uint64_t nside = rep.escapes[chosen];
+    if (nside) {
+        e = hipMalloc(&tmp.side, nside * 16);
+        if (e != hipSuccess) return optional(e, "side array");
+    }
+    for (int attempt = 0;; ++attempt) {
+        const int probe = sparse_probe_limit(chosen, nbuckets);
+        if (probe < 1) return optional(hipErrorInvalidValue, "bucket count");
+        const uint64_t lines = nbuckets + uint64_t(probe);
+        e = hipMalloc(&tmp.lines, lines * 128);
+        if (e == hipSuccess) e = hipMalloc(&tmp.counts, lines * sizeof(uint32_t));
+        if (e != hipSuccess) return optional(e, "bucket lines");
+        e = sparse_fill(view_of(h), flat, flat_depth, chosen, tmp.lines, nbuckets, uint32_t(probe), tmp.side, tmp.counts, tmp.work, work_bytes, &rep, h->stream);
+        if (e == hipSuccess) {
+            h->sparse_probe = uint32_t(probe);
+            h->sparse_bytes = lines * 128;
+            break;
+        }
+        if (e != hipErrorInvalidValue || attempt == 3) return optional(e, "fill pass");
+        (void)hipFree(tmp.lines);  // some entry found no slot within the probe limit: a quarter more buckets
+        (void)hipFree(tmp.counts);
+        tmp.lines = tmp.counts = nullptr;
+        nbuckets += nbuckets / 4;
+    }
+    h->d_sparse = tmp.lines;
+    h->d_sparse_side = tmp.side;
+    tmp.lines = tmp.side = nullptr;
+    h->sparse_side_bytes = nside * 16;
+    h->sparse_nbuckets = uint32_t(nbuckets);
+    h->sparse_depth = chosen;
+    h->sparse_report = rep;
+    if (verbose)
+        std::fprintf(stderr, "[msbwt] sparse table: depth %d, %llu entries in %u buckets (%.2f per bucket, %llu displaced, %llu in the side array), %.2f GB\n", chosen,
+                     (unsigned long long)rep.entries, h->sparse_nbuckets, double(rep.entries) / double(nbuckets), (unsigned long long)rep.displaced,
+                     (unsigned long long)rep.nescapes, double(h->sparse_bytes + h->sparse_side_bytes) / 1e9);
+    return MSBWT_OK;
+}
+
+// Direct table beside a sparse one: only queries shorter than the sparse table's entries (and those with '$' / 'N' among their last
+// symbols) still read it, so it stays small -- packed depth 15 (4.6 GB) at most.
+constexpr int kDirectDepthBesideSparse = 13;  // levels of the flat table (the packed one: + 2)
+
+int rebuild_table(msbwt_rle *h, bool allow_sparse = true) {
+    release_sparse(h);
     if (h->d_filter) (void)hipFree(h->d_filter);
     h->d_filter = nullptr;
     h->filter_depth = 0;
@@ -458,7 +592,16 @@ int rebuild_table(msbwt_rle *h) {
         depth = c.flat;
         pack = c.packed != 0 || (h->d_pair_blocks != nullptr && h->wanted_table_packed > 0);  // mode 1: whenever a pair index exists
     }
-    if (depth <= 0) return MSBWT_OK;
+    // The sparse table (sparse_table.hpp) is tried whenever a pair index exists; the automatic direct table then stays small.
+    // Should no sparse depth fit (a read set whose error k-mers outnumber the genome's many times over), the direct table is built
+    // again as if there were no such thing.
+    const bool try_sparse = allow_sparse && h->wanted_sparse != 0 && h->d_pair_blocks != nullptr && h->block_format == kBlocksPlanes && h->totals.total > 0;
+    bool capped = false;
+    if (try_sparse && automatic && depth > kDirectDepthBesideSparse) {
+        depth = kDirectDepthBesideSparse;
+        capped = true;
+    }
+    if (depth <= 0 && !try_sparse) return MSBWT_OK;
     if (depth + 2 > 18) pack = false;
     auto build_flat = [&](int d) -> int {
         const size_t bytes = (size_t(1) << (2 * d)) * 16;
@@ -476,8 +619,20 @@ int rebuild_table(msbwt_rle *h) {
         h->table_bytes = bytes;
         return rebuild_filter(h);  // from the flat table, before it may be packed away
     };
-    int rc = build_flat(depth);
-    if (rc || !h->d_table || !pack) return rc;
+    int rc = depth > 0 ? build_flat(depth) : MSBWT_OK;
+    if (rc) return rc;
+    if (try_sparse) {
+        uint64_t allowance = kNoBudget;
+        if (h->planned) {  // what the budget leaves once blocks, pair blocks and the direct table are paid for
+            const uint64_t direct = (pack && h->d_table) ? packed_table_bytes(depth + 2) : uint64_t(h->table_bytes);
+            const uint64_t held = h->nblocks * kBlockBytes + h->pair_bytes + direct;
+            allowance = h->memory_budget > held ? h->memory_budget - held : 0;
+        }
+        rc = build_sparse(h, (pack && h->d_table) ? packed_table_bytes(depth + 2) : 0, allowance);
+        if (rc) return rc;
+        if (!h->d_sparse && capped) return rebuild_table(h, false);
+    }
+    if (!h->d_table || !pack) return rc;
     // Packed form, two levels deeper (kernels.hpp, launch_pack_table): every level removes a line fetch
     // per query, and the first step after a shallow table is the expensive one (wide ranges straddle
     // blocks).  Needs the pair index.
@@ -779,6 +934,7 @@ int install(msbwt_rle *h, const uint8_t *rle, size_t n) {
     if (!rc) stage(h->pair_stride == 96 ? "pair blocks, stride 96" : "pair blocks, stride 128", h->pair_bytes);
     if (!rc) rc = rebuild_table(h);
     if (!rc) stage(h->table_packed ? "suffix table, packed" : "suffix table, flat", h->table_bytes);
+    if (!rc && h->d_sparse) stage("sparse suffix table", h->sparse_bytes + h->sparse_side_bytes);
     if (rc) {
         release_index(h);
         return rc;
@@ -786,7 +942,7 @@ int install(msbwt_rle *h, const uint8_t *rle, size_t n) {
     if (verbose)
         std::fprintf(stderr, "[msbwt] load: %llu symbols, table depth %d, a present %u-mer occurs %.0f times (median), %.2f GB of HBM in all\n",
                      (unsigned long long)t.total, h->table_depth, kProbeSteps, h->typical_width,
-                     double(h->nblocks * kBlockBytes + h->overflow_bytes + h->pair_bytes + h->table_bytes) / 1e9);
+                     double(h->nblocks * kBlockBytes + h->overflow_bytes + h->pair_bytes + h->table_bytes + h->sparse_bytes + h->sparse_side_bytes) / 1e9);
     if (verbose)  // where the arrays landed (run-to-run differences of up to 15 % on one box follow the process, not the clocks: profiles/r04_lab)
         std::fprintf(stderr, "[msbwt] load: blocks %p pair blocks %p pair super %p table %p side %p filter %p\n", h->d_blocks, h->d_pair_blocks,
                      static_cast<void *>(h->d_pair_super), h->d_table, h->d_table_side, static_cast<void *>(h->d_filter));
@@ -977,6 +1133,10 @@ msbwt_rle *msbwt_rle_new_on_device(uint8_t bin_power, int device) {
     if (const char *env = std::getenv("MSBWT_TABLE_DEPTH")) h->wanted_table_depth = std::max(-1, std::min(std::atoi(env), kMaxTableDepth));
     if (const char *env = std::getenv("MSBWT_TABLE_PACKED")) h->wanted_table_packed = std::atoi(env) ? 1 : 0;
     if (const char *env = std::getenv("MSBWT_TABLE_SIDE")) h->wanted_table_side = std::atoi(env) ? 1 : 0;
+    if (const char *env = std::getenv("MSBWT_SPARSE_TABLE")) {
+        const int d = std::strcmp(env, "auto") == 0 ? -1 : std::atoi(env);
+        h->wanted_sparse = (d == 0 || d == -1 || (d >= kSparseMinDepth && d <= kSparseMaxDepth)) ? d : -1;
+    }
     if (const char *env = std::getenv("MSBWT_PAIR_INDEX")) h->wanted_pair = std::atoi(env) ? 1 : 0;
     if (const char *env = std::getenv("MSBWT_PAIR_STRIDE")) h->wanted_pair_stride = std::atoi(env);
     if (const char *env = std::getenv("MSBWT_FILTER")) h->wanted_filter = std::atoi(env) ? -1 : 0;
@@ -1446,6 +1606,7 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
     h->wanted_table_depth = src->wanted_table_depth;
     h->wanted_table_packed = src->wanted_table_packed;
     h->wanted_table_side = src->wanted_table_side;
+    h->wanted_sparse = src->wanted_sparse;
     h->wanted_block_format = src->wanted_block_format;
     h->block_format = src->block_format;
     h->wanted_pair = src->wanted_pair;
@@ -1487,6 +1648,8 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
         {reinterpret_cast<void *const *>(&src->d_filter), reinterpret_cast<void **>(&h->d_filter), src->d_filter ? (size_t(1) << (2 * src->filter_depth)) / 8 : 0},
         {&src->d_pair_blocks, &h->d_pair_blocks, src->d_pair_blocks ? psz.pair_block_bytes : 0},
         {&src->d_pair_super, &h->d_pair_super, src->d_pair_super ? psz.super_bytes : 0},
+        {&src->d_sparse, &h->d_sparse, src->d_sparse ? size_t(src->sparse_bytes) : 0},
+        {&src->d_sparse_side, &h->d_sparse_side, src->d_sparse_side ? size_t(src->sparse_side_bytes) : 0},
     };
     for (const Piece &p : pieces) {
         if (!p.bytes || !*p.from) continue;
@@ -1505,6 +1668,12 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
     h->table_side_bytes = src->table_side_bytes;
     h->table_lines = src->table_lines;
     h->table_escape_lines = src->table_escape_lines;
+    h->sparse_bytes = src->sparse_bytes;
+    h->sparse_side_bytes = src->sparse_side_bytes;
+    h->sparse_nbuckets = src->sparse_nbuckets;
+    h->sparse_probe = src->sparse_probe;
+    h->sparse_depth = src->sparse_depth;
+    h->sparse_report = src->sparse_report;
     h->typical_width = src->typical_width;
     h->pair_overlap_bytes = src->pair_overlap_bytes;
     h->filter_depth = src->filter_depth;
@@ -1761,6 +1930,7 @@ int msbwt_rle_set_memory_budget(msbwt_rle *h, uint64_t bytes) {
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
     // the optional structures are rebuilt under the new budget (the plan counts the memory they hold now as free)
+    release_sparse(h);
     if (h->d_table) (void)hipFree(h->d_table);
     if (h->d_table_side) (void)hipFree(h->d_table_side);
     if (h->d_filter) (void)hipFree(h->d_filter);
@@ -1813,6 +1983,71 @@ int msbwt_rle_table_info(const msbwt_rle *h, uint64_t *lines, uint64_t *escape_l
     if (escape_lines) *escape_lines = packed ? h->table_escape_lines : 0;
     if (side_bytes) *side_bytes = packed ? h->table_side_bytes : 0;
     return MSBWT_OK;
+}
+
+// ---- sparse suffix table (sparse_table.hpp) ----------------------------------------------------------------------------------
+int msbwt_rle_set_sparse_table(msbwt_rle *h, int depth) {
+    if (!h || !(depth == -1 || depth == 0 || (depth >= kSparseMinDepth && depth <= kSparseMaxDepth))) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->wanted_sparse = depth;
+    if (!h->loaded) return MSBWT_OK;
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    return rebuild_table(h);
+}
+
+int msbwt_rle_get_sparse_table(const msbwt_rle *h) { return (h && h->d_sparse && h->d_pair_blocks) ? h->sparse_depth : 0; }
+
+int msbwt_rle_sparse_table_info(const msbwt_rle *ch, uint64_t *out) {
+    msbwt_rle *h = const_cast<msbwt_rle *>(ch);
+    if (!h || !out) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    std::memset(out, 0, MSBWT_SPARSE_INFO_WORDS * sizeof(uint64_t));
+    const SparseBuildReport &r = h->sparse_report;
+    if (h->d_sparse) {
+        out[0] = uint64_t(h->sparse_depth);
+        out[1] = r.entries;
+        out[2] = h->sparse_nbuckets;
+        out[3] = h->sparse_bytes;
+        out[4] = r.nescapes;
+        out[5] = h->sparse_side_bytes;
+        out[6] = r.displaced;
+        out[9] = h->sparse_probe;
+    }
+    out[7] = uint64_t(r.parent_depth);
+    for (int d = 0; d <= kSparseMaxDepth; ++d) {
+        out[10 + d] = r.distinct[d];
+        out[10 + kSparseMaxDepth + 1 + d] = r.escapes[d];
+    }
+    return MSBWT_OK;
+}
+
+int msbwt_sparse_hash(uint64_t key, int depth, uint64_t nbuckets, uint32_t *bucket, uint32_t *tag) {
+    if (depth < kSparseMinDepth || depth > kSparseMaxDepth || nbuckets == 0 || nbuckets > 0xFFFFFFFFull || !bucket || !tag) return MSBWT_ERR_INVALID_ARG;
+    const uint64_t x = sparse_mix(key, uint32_t(2 * depth));
+    *bucket = sparse_bucket(x, uint32_t(2 * depth), uint32_t(nbuckets));
+    *tag = sparse_tag(x);
+    return MSBWT_OK;
+}
+
+int msbwt_sparse_table_shape(int depth, uint64_t entries, uint64_t *nbuckets, int *probe) {
+    if (depth < kSparseMinDepth || depth > kSparseMaxDepth || !nbuckets || !probe) return MSBWT_ERR_INVALID_ARG;
+    *nbuckets = sparse_buckets_for(depth, entries);
+    *probe = sparse_probe_limit(depth, *nbuckets);
+    return MSBWT_OK;
+}
+
+size_t msbwt_rle_download_sparse_table(const msbwt_rle *ch, void *out_lines, size_t cap_bytes, void *out_side, size_t cap_side_bytes) {
+    msbwt_rle *h = const_cast<msbwt_rle *>(ch);
+    if (!h || !h->loaded || !h->d_sparse) return SIZE_MAX;
+    std::lock_guard<std::mutex> lock(h->mu);
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return SIZE_MAX;
+    if (out_lines && cap_bytes >= h->sparse_bytes && hipMemcpy(out_lines, h->d_sparse, h->sparse_bytes, hipMemcpyDeviceToHost) != hipSuccess) return SIZE_MAX;
+    if (out_side && h->d_sparse_side && cap_side_bytes >= h->sparse_side_bytes &&
+        hipMemcpy(out_side, h->d_sparse_side, h->sparse_side_bytes, hipMemcpyDeviceToHost) != hipSuccess)
+        return SIZE_MAX;
+    return size_t(h->sparse_bytes);
 }
 
 int msbwt_rle_set_search_counters(msbwt_rle *h, int enabled) {
@@ -1890,7 +2125,7 @@ int msbwt_rle_search_kernel_for(const msbwt_rle *h, size_t k) {
 uint64_t msbwt_rle_device_bytes(const msbwt_rle *h) {
     if (!h || !h->loaded) return 0;
     return h->nblocks * kBlockBytes + h->overflow_bytes + (h->d_table ? uint64_t(h->table_bytes) + h->table_side_bytes : 0) + h->pair_bytes +
-           (h->d_filter ? (uint64_t(1) << (2 * h->filter_depth)) / 8 : 0);
+           (h->d_filter ? (uint64_t(1) << (2 * h->filter_depth)) / 8 : 0) + h->sparse_bytes + h->sparse_side_bytes;
 }
 
 int msbwt_rle_set_kernel_timing(msbwt_rle *h, int enabled) {

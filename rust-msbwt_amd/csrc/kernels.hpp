@@ -4,6 +4,8 @@
 
 #include <cstdint>
 
+#include "sparse_table.hpp"
+
 namespace msbwt {
 
 // bits of the device status word
@@ -60,7 +62,14 @@ struct IndexView {
     // optional search counters of the lanes kernel (kSearchCounters u64, added to by every wave): what a batch did to
     // the index -- steps, second lines, escape lines ... (msbwt_rle_search_counters); nullptr = not wanted
     uint64_t *counters = nullptr;
+    // optional sparse suffix table (sparse_table.hpp): the ranges of the suffixes that occur, deeper than the direct table
+    // reaches; the lanes kernel looks up queries of at least its depth there (beside a pair index), shorter ones in `table`
+    SparseView sparse;
 };
+
+inline bool sparse_serves(const IndexView &ix, uint32_t k) {
+    return ix.sparse.lines != nullptr && ix.pair_blocks != nullptr && ix.block_format == kBlocksPlanes && k >= ix.sparse.depth;
+}
 
 // indices into IndexView::counters
 enum SearchCounter {
@@ -74,6 +83,8 @@ enum SearchCounter {
     kCntTableDecided,      // queries decided by the table or the presence filter alone
     kCntSearched,          // queries that entered the search
     kCntFirstLines,        // first-bound lines fetched (one per lane-step) + side-array entries fetched for escape-line queries
+    kCntTableSteps,        // sparse table: bucket lines fetched (lane-steps that were lookups; included in kCntLaneSteps)
+    kCntTableDisplaced,    // ... of which did not find the key in a bucket that had displaced entries (the lookup went on)
     kSearchCounters = 16
 };
 

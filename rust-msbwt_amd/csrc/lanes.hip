@@ -38,6 +38,7 @@
 #include "kernels.hpp"
 #include "rank_ops.hpp"
 #include "search_common.hpp"
+#include "sparse_table.hpp"
 
 namespace msbwt {
 namespace {
@@ -267,7 +268,11 @@ __device__ __forceinline__ uint64_t pair_line_bound(const PairLine &L, uint64_t 
 // A compile-time switch, not a launch-uniform branch: with both ways of fetching a tile in one kernel the compiler merged
 // their results through register copies, i.e. WAITED for the tile's bytes right after asking for them -- setup no longer
 // ran ahead of memory (same box, C2 random 21-mers: 0.253 ms per 10^7 against 0.225 ms before packed queries existed).
-template <bool kReads, bool kPair, int kWords, bool kStride96, bool kPacked>
+// kSparse (kPair only): the launch looks its queries up in the SPARSE suffix table (sparse_table.hpp) instead of the direct one --
+// `table` = its bucket lines, `depth` = its depth, `table_side` = its side array.  A lookup is a search step of its own kind: the
+// lane's line is its key's bucket, fetched with the other lanes' lines, and the lane finds its entry among the line's 14 tags.
+// A compile-time switch for the same reason as kPacked -- and so that the direct-table kernels carry none of it.
+template <bool kReads, bool kPair, int kWords, bool kStride96, bool kPacked, bool kSparse>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_count_kmers_lanes(const uint4 *__restrict__ blocks, uint64_t total,
                                                           const uint4 *__restrict__ table, uint32_t depth, uint32_t table_packed,
                                                           const uint32_t *__restrict__ filter, uint32_t filter_mask,
@@ -276,8 +281,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                                                           uint32_t *__restrict__ flags, uint64_t *__restrict__ debug,
                                                           unsigned long long *__restrict__ tile_counter, uint32_t grain,
                                                           uint64_t *__restrict__ done, uint64_t done_seq, uint64_t *__restrict__ counters,
-                                                          uint32_t format, const uint4 *__restrict__ run_overflow) {
+                                                          uint32_t format, const uint4 *__restrict__ run_overflow, uint32_t sparse_nbuckets,
+                                                          uint32_t sparse_probe) {
     static_assert(!(kReads && kPacked), "packed queries are a matrix-mode input");
+    static_assert(!kSparse || kPair, "the sparse table continues with pair steps");
     using Scratch = LaneScratchT<kWords, kPacked>;
     // run blocks (run_index.hpp; launch-uniform): `blocks` are 128-byte lines of 512 positions with 96 one-byte runs, decoded
     // by the lane that owns the query; single-symbol steps only (the kPair instantiations never see them)
@@ -346,6 +353,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
 
     // the lane's running query
     bool have = false;
+    bool tmode = false;   // kSparse: the query is still to be looked up -- l = its bucket, h = its tag, the next step fetches the bucket line
+    uint32_t tdist = 0;   // ... and how many buckets beyond its own the lookup has gone
     uint32_t ovf_l = 0, ovf_h = 0;  // run blocks: 1 + the overflow plane block this bound is to be ranked from (0: its run block)
     uint64_t l = 0, h = 0;
     uint32_t w[kWords], rem = 0;
@@ -451,11 +460,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             // lanes' lines -- nothing waits, but the flag's bookkeeping in every step cost C3 fused, an index without a single
             // escape line, 2.3 % (18.55 against 18.12 ms, same box); the wait costs only the tiles that meet one.
             bool escaped = false, restart = false;
-            if (prep_kind == 1u) {
+            bool lookup = false;  // kSparse: enters the ring as a table lookup
+            if (kSparse && prep_kind == 3u) {
+                pl = prep_entry.x;  // bucket
+                ph = prep_entry.y;  // tag
+                skip = depth;
+                lookup = true;
+            }
+            if (!kSparse && prep_kind == 1u) {
                 if (table_decode(env, prep_entry, pl, ph)) skip = depth;
                 else escaped = true;
             }
-            if (__ballot(escaped) != 0ull) {  // wave-uniform, rare
+            if (!kSparse && __ballot(escaped) != 0ull) {  // wave-uniform, rare
                 if (kSideFetch && table_side != nullptr) {
                     if (escaped) {
                         const uint4 e = table_side[pl];
@@ -473,7 +489,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             uint32_t prep_w[kWords];
             unpack_words<kWords>(prep_q, skip, prep_w);
             bool pending = prep_kind != 0u;
-            if (pending && (prep_rem == 0u || pl == ph)) {  // decided by the table (or an empty index)
+            if (pending && !lookup && (prep_rem == 0u || pl == ph)) {  // decided by the table (or an empty index)
                 store_count<kReads>(src, place_of(prep_tile * kTile + lane, prep_out), ph - pl);
                 pending = false;
             }
@@ -491,6 +507,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 it.l_lo = uint32_t(pl);
                 it.h_lo = uint32_t(ph);
                 it.meta = uint32_t(pl >> 32) | (uint32_t(ph >> 32) << 8) | (prep_rem << 16) | (lane << 24);  // l, h < 2^40; rem <= 64
+                if (kSparse && lookup) it.meta |= 1u << 23;
 #pragma unroll
                 for (int i = 0; i < kWords; ++i) it.w[i] = prep_w[i];
                 if constexpr (kPacked) it.out = prep_out;
@@ -512,7 +529,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 h = (uint64_t((it.meta >> 8) & 0xFFu) << 32) | it.h_lo;
 #pragma unroll
                 for (int i = 0; i < kWords; ++i) w[i] = it.w[i];
-                rem = (it.meta >> 16) & 0xFFu;
+                rem = (it.meta >> 16) & (kSparse ? 0x7Fu : 0xFFu);
+                tmode = kSparse && ((it.meta >> 23) & 1u) != 0u;
+                tdist = 0u;
                 qid = ring_tile * kTile + (it.meta >> 24);
                 if constexpr (kPacked) qid = place_of(qid, it.out);
                 ovf_l = ovf_h = 0u;
@@ -524,7 +543,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
         }
         // a range outside the index would turn into a wild line address: end such a query with
         // u64::MAX and a status flag instead (never seen on a well-formed index; cheap insurance)
-        const bool broken = have && (h > total || l > h);
+        const bool broken = have && !(kSparse && tmode) && (h > total || l > h);
         if (broken) {
             atomicOr(flags, kFlagInternal);
             if (debug != nullptr && atomicCAS(reinterpret_cast<unsigned long long *>(debug), 0ull, 1ull) == 0ull) {
@@ -604,8 +623,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                         passed = maybe;
                     }
                     if (maybe) {
-                        prep_entry = table_fetch(env, pq.tidx);  // stays in flight: consumed in step A of a later iteration
-                        prep_kind = 1;
+                        if constexpr (kSparse) {  // nothing to fetch here: the bucket line is the query's first search step
+                            const uint64_t x = sparse_mix(pq.tidx, 2u * depth);
+                            prep_entry.x = sparse_bucket(x, 2u * depth, sparse_nbuckets);
+                            prep_entry.y = sparse_tag(x);
+                            prep_kind = 3;
+                        } else {
+                            prep_entry = table_fetch(env, pq.tidx);  // stays in flight: consumed in step A of a later iteration
+                            prep_kind = 1;
+                        }
                         prep_q = pq;
                     } else {
                         store_count<kReads>(src, place_of(q0 + lane, prep_out), 0ull);
@@ -640,7 +666,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
 
         // ---- D: one search step of every busy lane ----
         const uint32_t s1 = w[0] & 7u, s2 = (w[0] >> 3) & 7u;
-        const bool pair = kPair && have && rem >= 2u && (acgt_bit(s1) & acgt_bit(s2)) != 0u;
+        const bool looking = kSparse && have && tmode;  // this step fetches the query's bucket of the sparse table
+        const bool pair = kPair && have && !looking && rem >= 2u && (acgt_bit(s1) & acgt_bit(s2)) != 0u;
         const uint32_t a2 = acgt_code(s1) & 3u, b2 = acgt_code(s2) & 3u;
         constexpr bool s96 = kStride96;  // compile-time: the stride-128 kernel carries no division
         const uint64_t base = pair ? reinterpret_cast<uint64_t>(pair_blocks) : reinterpret_cast<uint64_t>(blocks);
@@ -661,6 +688,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             line_l = ovf_l != 0u ? reinterpret_cast<uint64_t>(run_overflow) + uint64_t(ovf_l - 1u) * 128u : reinterpret_cast<uint64_t>(blocks) + (l >> 9) * 128u;
             line_h = ovf_h != 0u ? reinterpret_cast<uint64_t>(run_overflow) + uint64_t(ovf_h - 1u) * 128u : reinterpret_cast<uint64_t>(blocks) + (h >> 9) * 128u;
             one_line = line_l == line_h;
+        }
+        if (kSparse && looking) {
+            line_l = reinterpret_cast<uint64_t>(table) + l * 128u;
+            one_line = true;
         }
         const bool second = have && !one_line;
         const uint64_t second_mask = __ballot(second);
@@ -708,11 +739,58 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             count(kCntPairSteps, __ballot(act && pair));
             count(kCntSecondLines, __ballot(act && second));
             count(kCntSatOut, __ballot(have && !act));
+            if (kSparse) count(kCntTableSteps, __ballot(act && looking));
         }
         if (act) {
             uint64_t nl, nh;
             bool step_done = true;
-            if (pair) {
+            if (kSparse && looking) {
+                // the bucket line: 14 tags in words 0..13 (chunks 0-3), l in words 14..27 and bytes 112..125, the bucket's header in
+                // bytes 126..127 (sparse_table.hpp).  A key sits in at most one slot of at most one bucket: a tag match is the entry.
+                const uint32_t base_t = line_base(slot_l), g = slot_l & 7u;
+                const uint4 c0 = ws.lines[base_t + (0u ^ g)], c1 = ws.lines[base_t + (1u ^ g)], c2 = ws.lines[base_t + (2u ^ g)], c3 = ws.lines[base_t + (3u ^ g)];
+                const uint32_t tags[kSparseSlots] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y};
+                const uint32_t want = uint32_t(h);
+                uint32_t hit = kSparseSlots, width = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < kSparseSlots; ++i) {
+                    const uint32_t t = tags[i];
+                    const bool match = ((t ^ want) << (32u - kSparseTagBits)) == 0u && (t >> kSparseTagBits) != 0u;
+                    hit = match ? i : hit;
+                    width = match ? t >> kSparseTagBits : width;
+                }
+                const uint32_t header = ws.lines[base_t + (7u ^ g)].w >> 16;
+                nl = nh = 0;
+                step_done = false;
+                if (hit < kSparseSlots) {
+                    const uint32_t word = kSparseL0Word + hit;
+                    const uint32_t lo = reinterpret_cast<const uint32_t *>(ws.lines)[(base_t + ((word >> 2) ^ g)) * 4u + (word & 3u)];
+                    const uint32_t hi = reinterpret_cast<const uint8_t *>(ws.lines)[(base_t + (7u ^ g)) * 16u + hit];
+                    l = (uint64_t(hi) << 32) | lo;
+                    h = l + width;
+                    if (width == kSparseEscapeWidth) {  // a high-copy suffix: its range is a flat entry of the side array, one more line
+                        const uint4 e = table_side[l];
+                        l = (uint64_t(e.y) << 32) | e.x;
+                        h = (uint64_t(e.w) << 32) | e.z;
+                    }
+                    tmode = false;
+                    if (rem == 0u) {  // k == depth: the table's range is the answer
+                        store_count<kReads>(src, qid, h - l);
+                        have = false;
+                    }
+                } else if (header > kSparseSlots && tdist < sparse_probe) {  // entries of this bucket were displaced: the next one
+                    ++l;
+                    ++tdist;
+                } else {  // a miss in a complete table: the suffix does not occur (msbwt_core.rs:151-153)
+                    store_count<kReads>(src, qid, 0ull);
+                    have = false;
+                }
+                if (counting) {
+                    count(kCntEscapeQueries, __ballot(hit < kSparseSlots && width == kSparseEscapeWidth));
+                    count(kCntTableDisplaced, __ballot(hit >= kSparseSlots && have));
+                    count(kCntTableDecided, __ballot(hit >= kSparseSlots && !have));
+                }
+            } else if (pair) {
                 PairLine L;
                 read_pair_line(ws.lines, slot_l, a2, b2, L);
                 nl = pair_line_bound(L, super_l, r_l);
@@ -789,13 +867,13 @@ constexpr uint64_t kMaxTiles = 1ull << 32;
 
 // The kernel is persistent: the grid is what the device keeps resident -- workgroups per CU
 // (occupancy API: LDS- and VGPR-bound, capped below) x CUs; tiles are dealt out by atomic tickets.
-template <bool kReads, bool kPair, int kWords, bool kStride96, bool kPacked>
+template <bool kReads, bool kPair, int kWords, bool kStride96, bool kPacked, bool kSparse>
 uint32_t resident_waves() {
     static const uint32_t cached = [] {
         int device = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&device) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_count_kmers_lanes<kReads, kPair, kWords, kStride96, kPacked>, 64, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_count_kmers_lanes<kReads, kPair, kWords, kStride96, kPacked, kSparse>, 64, 0) != hipSuccess ||
             cus <= 0 || per_cu <= 0)
             return 7u * 256u;
         // LDS decides (12.1 / 12.9 KiB -> 12 waves); whole multiples of the four SIMDs only: with
@@ -806,19 +884,20 @@ uint32_t resident_waves() {
             const int want = std::atoi(env);
             if (want > 0) per_cu = want;
         }
-        if (std::getenv("MSBWT_VERBOSE")) std::fprintf(stderr, "[msbwt] lanes kernel <%d,%d,%d,%d,%d>: %d workgroups per CU x %d CUs\n", int(kReads), int(kPair), kWords, int(kStride96), int(kPacked), per_cu, cus);
+        if (std::getenv("MSBWT_VERBOSE")) std::fprintf(stderr, "[msbwt] lanes kernel <%d,%d,%d,%d,%d,%d>: %d workgroups per CU x %d CUs\n", int(kReads), int(kPair), kWords, int(kStride96), int(kPacked), int(kSparse), per_cu, cus);
         return uint32_t(cus) * uint32_t(per_cu);
     }();
     return cached;
 }
 
-template <bool kReads, bool kPair, int kWords, bool kStride96, bool kPacked>
+template <bool kReads, bool kPair, int kWords, bool kStride96, bool kPacked, bool kSparse>
 hipError_t launch_variant(hipStream_t stream, const IndexView &ix, const QuerySource &src, uint32_t *flags) {
-    const uint4 *table = static_cast<const uint4 *>(ix.table.entries);
-    const uint32_t *filter = table ? ix.table.filter : nullptr;
+    // (kSparse: the sparse table's lines, depth and side array travel in the direct table's arguments)
+    const uint4 *table = static_cast<const uint4 *>(kSparse ? ix.sparse.lines : ix.table.entries);
+    const uint32_t *filter = ix.table.entries ? ix.table.filter : nullptr;
     const uint32_t filter_mask = filter ? uint32_t((1ull << (2 * ix.table.filter_depth)) - 1ull) : 0u;
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
-    const uint64_t waves = std::min<uint64_t>(tiles, resident_waves<kReads, kPair, kWords, kStride96, kPacked>());
+    const uint64_t waves = std::min<uint64_t>(tiles, resident_waves<kReads, kPair, kWords, kStride96, kPacked, kSparse>());
     if (tiles > kMaxTiles) return hipErrorInvalidValue;
     // Ticket counters are only needed when there are more tiles than waves; without them (small batches, the
     // single-query path: no memset, no atomics) the kernel strides statically.
@@ -829,19 +908,25 @@ hipError_t launch_variant(hipStream_t stream, const IndexView &ix, const QuerySo
     }
     // tiles per ticket: about eight tickets per wave at least, sixteen tiles at most
     const uint32_t grain = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(16, tiles / (waves * 8))));
-    hipLaunchKernelGGL((k_count_kmers_lanes<kReads, kPair, kWords, kStride96, kPacked>), dim3(uint32_t(waves)), dim3(64), 0, stream,
-                       static_cast<const uint4 *>(ix.blocks), ix.total, table, uint32_t(ix.table.depth), ix.table.packed ? 1u : 0u, filter, filter_mask,
-                       table ? static_cast<const uint4 *>(ix.table.side) : nullptr, static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags, ix.debug,
+    const uint4 *side = static_cast<const uint4 *>(kSparse ? ix.sparse.side : (table ? ix.table.side : nullptr));
+    hipLaunchKernelGGL((k_count_kmers_lanes<kReads, kPair, kWords, kStride96, kPacked, kSparse>), dim3(uint32_t(waves)), dim3(64), 0, stream,
+                       static_cast<const uint4 *>(ix.blocks), ix.total, table, kSparse ? ix.sparse.depth : uint32_t(ix.table.depth), (!kSparse && ix.table.packed) ? 1u : 0u,
+                       filter, filter_mask, side, static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags, ix.debug,
                        tickets ? static_cast<unsigned long long *>(ix.tile_counter) : nullptr, grain, waves == 1 ? ix.done : nullptr, ix.done_seq, ix.counters,
-                       uint32_t(ix.block_format), static_cast<const uint4 *>(ix.overflow));
+                       uint32_t(ix.block_format), static_cast<const uint4 *>(ix.overflow), ix.sparse.nbuckets, ix.sparse.probe);
     return hipGetLastError();
 }
 
 template <bool kReads, bool kPacked>
 hipError_t launch_shape(bool pair, bool longk, hipStream_t stream, const IndexView &ix, const QuerySource &src, uint32_t *flags) {
-    if (!pair) return longk ? launch_variant<kReads, false, 6, false, kPacked>(stream, ix, src, flags) : launch_variant<kReads, false, 3, false, kPacked>(stream, ix, src, flags);
-    if (ix.pair_stride96) return longk ? launch_variant<kReads, true, 6, true, kPacked>(stream, ix, src, flags) : launch_variant<kReads, true, 3, true, kPacked>(stream, ix, src, flags);
-    return longk ? launch_variant<kReads, true, 6, false, kPacked>(stream, ix, src, flags) : launch_variant<kReads, true, 3, false, kPacked>(stream, ix, src, flags);
+    if (!pair) return longk ? launch_variant<kReads, false, 6, false, kPacked, false>(stream, ix, src, flags) : launch_variant<kReads, false, 3, false, kPacked, false>(stream, ix, src, flags);
+    // the sparse table serves every query that is at least as long as its entries (shorter ones: the direct table)
+    if (sparse_serves(ix, src.k)) {
+        if (ix.pair_stride96) return longk ? launch_variant<kReads, true, 6, true, kPacked, true>(stream, ix, src, flags) : launch_variant<kReads, true, 3, true, kPacked, true>(stream, ix, src, flags);
+        return longk ? launch_variant<kReads, true, 6, false, kPacked, true>(stream, ix, src, flags) : launch_variant<kReads, true, 3, false, kPacked, true>(stream, ix, src, flags);
+    }
+    if (ix.pair_stride96) return longk ? launch_variant<kReads, true, 6, true, kPacked, false>(stream, ix, src, flags) : launch_variant<kReads, true, 3, true, kPacked, false>(stream, ix, src, flags);
+    return longk ? launch_variant<kReads, true, 6, false, kPacked, false>(stream, ix, src, flags) : launch_variant<kReads, true, 3, false, kPacked, false>(stream, ix, src, flags);
 }
 
 }  // namespace

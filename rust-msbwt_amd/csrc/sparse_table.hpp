@@ -1,0 +1,99 @@
+// Sparse suffix table: the ranges of the d-symbol suffixes that OCCUR, d up to 24 -- the reference's stubbed kmer_cache
+// (src/msbwt_core.rs:133-146, src/rle_bwt.rs:332-346) taken past what a direct-address table can hold.
+//
+// The direct table (kernels.hpp, TableView) has 4^d entries whatever the data: at d = 17 that is 73 GB of which at most
+// 17 % (a 30x human read set), 0.4 % (chr20-sized) or 0.02 % (C2) can be non-empty.  The same bytes spent on the suffixes
+// that are PRESENT reach d = 23: three pair steps of seven fewer for every present 31-mer, and lines per query are the only
+// lever the search has left in the HBM regime.  One lookup = ONE random 128-byte line, like the direct
+// table's; a miss in this table -- it is complete: every d-mer that occurs has an entry -- is count 0, exactly the early
+// exit of src/msbwt_core.rs:151-153.
+//
+// Layout: `nbuckets` lines of 128 bytes, 14 entries each, structure-of-arrays inside the line so that the lane that owns
+// the query finds its entry with dword compares:
+//     words  0..13   tag[i]  = low 24 bits of the mixed key | width << 24   (width 1..254; 255 = ESCAPE; 0 = empty slot)
+//     words 14..27   l_lo[i] = low 32 bits of the range's l (ESCAPE: of the entry's index in the side array)
+//     bytes 112..125 l_hi[i] = bits 32..39 of l
+//     bytes 126..127 header  = how many entries wanted this bucket (saturating): > 14 = some were displaced to the next
+//                              bucket(s), so a lookup that does not find its key here goes on (linear probing over buckets)
+// Key = the table index of the direct table (A C G T -> 0..3, step t at bits [2t, 2t+2), step 0 = the k-mer's LAST symbol),
+// n = 2 d bits.  It is mixed by a bijection of n-bit words (two odd multiplications and xor-shifts): bucket = the top 32
+// bits of the mixed key scaled to [0, nbuckets) -- contiguous windows of the mixed key per bucket, at most
+// W = 2^(n-32) * ceil(2^32 / nbuckets) wide -- and the low 24 bits are kept as the tag: within (probe + 1) * W <= 2^24
+// consecutive values no two share their low 24 bits, so a tag match IS a key match (no false positives, nothing to verify).
+// An entry whose range is 255 or more wide (a suffix of a high-copy repeat) names a flat {l, h} entry of 16 bytes in a side
+// array: one more line for that query, like the escape lines of the packed direct table.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#include <hip/hip_runtime.h>
+#define MSBWT_HD __host__ __device__ __forceinline__
+#else
+#define MSBWT_HD inline
+#endif
+
+namespace msbwt {
+
+constexpr uint32_t kSparseSlots = 14;        // entries per 128-byte bucket
+constexpr uint32_t kSparseTagBits = 24;
+constexpr uint32_t kSparseEscapeWidth = 255;  // width field of an entry whose range lives in the side array
+constexpr uint32_t kSparseMaxProbe = 15;      // a key lives at most this many buckets behind its own
+constexpr int kSparseMinDepth = 16, kSparseMaxDepth = 24;
+constexpr int kSparseAutoDepth = 23;          // the automatic choice never goes deeper (msbwt_rle_set_sparse_table takes 16..24)
+constexpr double kSparseLoad = 9.0;           // entries per bucket the builder aims for (64 % of the slots: 0.9 % of the entries displaced)
+constexpr uint32_t kSparseL0Word = 14, kSparseHiByte = 112, kSparseHeaderByte = 126;
+
+struct SparseView {
+    const void *lines = nullptr;   // nbuckets x 128 bytes, or nullptr: no sparse table
+    uint32_t nbuckets = 0;
+    uint32_t depth = 0;            // symbols an entry stands for
+    uint32_t probe = 0;            // buckets a lookup may go beyond its own
+    const void *side = nullptr;    // 16-byte {l, h} entries of the ESCAPE entries
+};
+
+// the bijection of n-bit words (n = 2 depth, 32 <= n <= 48)
+MSBWT_HD uint64_t sparse_mix(uint64_t key, uint32_t n) {
+    const uint64_t mask = (uint64_t(1) << n) - 1u;
+    uint64_t x = key & mask;
+    x = (x * 0x9E3779B97F4A7C15ull) & mask;
+    x ^= x >> (n >> 1);
+    x = (x * 0xD6E8FEB86659FD93ull) & mask;
+    x ^= x >> (n >> 1);
+    return x;
+}
+
+// bucket of a mixed key: its top 32 bits scaled to [0, nbuckets)
+MSBWT_HD uint32_t sparse_bucket(uint64_t mixed, uint32_t n, uint32_t nbuckets) {
+    const uint32_t top = uint32_t(mixed >> (n - 32u));
+    return uint32_t((uint64_t(top) * nbuckets) >> 32);
+}
+
+MSBWT_HD uint32_t sparse_tag(uint64_t mixed) { return uint32_t(mixed) & ((1u << kSparseTagBits) - 1u); }
+
+// How far a lookup may probe with `nbuckets` buckets at depth d so that tags stay unambiguous: (probe + 1) * W <= 2^24,
+// W = 2^(n-32) * ceil(2^32 / nbuckets).  Negative: this many buckets are too few for the depth.
+inline int sparse_probe_limit(int depth, uint64_t nbuckets) {
+    if (depth < kSparseMinDepth || depth > kSparseMaxDepth || nbuckets == 0 || nbuckets > 0xFFFFFFFFull) return -1;
+    const uint64_t per_top = ((uint64_t(1) << 32) + nbuckets - 1) / nbuckets;
+    const uint64_t window = per_top << (2 * depth - 32);
+    const uint64_t fit = (uint64_t(1) << kSparseTagBits) / window;  // windows that fit the tag space
+    if (fit < 2) return -1;
+    return int(fit - 1 < kSparseMaxProbe ? fit - 1 : kSparseMaxProbe);
+}
+
+// fewest buckets a table of this depth may have (probe limit >= 3)
+inline uint64_t sparse_min_buckets(int depth) {
+    const int shift = 2 * depth - 32 + 2;  // W <= 2^22  <=>  ceil(2^32 / nb) <= 2^(22 - (n - 32))
+    if (shift >= int(kSparseTagBits)) return ~uint64_t(0);
+    const uint64_t per_top = uint64_t(1) << (kSparseTagBits - shift);  // allowed ceil(2^32 / nb)
+    return ((uint64_t(1) << 32) + per_top - 1) / per_top;
+}
+
+// buckets for `entries` entries at depth d (the load the builder aims for, within what the tags allow)
+inline uint64_t sparse_buckets_for(int depth, uint64_t entries, double load = kSparseLoad) {
+    const uint64_t want = uint64_t(double(entries) / load) + 1;
+    const uint64_t least = sparse_min_buckets(depth);
+    return want > least ? want : least;
+}
+
+}  // namespace msbwt

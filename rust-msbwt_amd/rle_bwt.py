@@ -214,7 +214,7 @@ class RleBWT(BWT):
             _raise(rc, self._h)
 
     def set_batch_order(self, mode):
-        """-1 = the library orders dense batches itself (default), 0 = never, 1 = whenever the pass applies."""
+        """-1 = automatic (default; today that means never, include/msbwt_hip.h), 0 = never, 1 = whenever the pass applies."""
         rc = _lib.lib().msbwt_rle_set_batch_order(self._h, int(mode))
         if rc:
             _raise(rc, self._h)
@@ -294,7 +294,43 @@ class RleBWT(BWT):
         return {"lines": a.value, "escape_lines": b.value, "side_bytes": c.value}
 
     COUNTER_NAMES = ("wave_steps", "lane_steps", "pair_steps", "second_lines", "sat_out", "escape_queries", "escape_restarts",
-                     "table_decided", "searched", "first_lines")
+                     "table_decided", "searched", "first_lines", "table_steps", "table_displaced")
+
+    # ---- sparse suffix table (include/msbwt_hip.h, msbwt_rle_set_sparse_table) ----
+    def set_sparse_table(self, depth):
+        """-1 = automatic (default), 0 = off, 16..24 = exactly that depth."""
+        rc = _lib.lib().msbwt_rle_set_sparse_table(self._h, int(depth))
+        if rc:
+            _raise(rc, self._h)
+
+    def get_sparse_table(self):
+        """Depth of the sparse suffix table in HBM, 0 = none."""
+        return int(_lib.lib().msbwt_rle_get_sparse_table(self._h))
+
+    def sparse_table_info(self):
+        """What msbwt_rle_sparse_table_info reports, by name; "distinct" / "wide": {depth: count} for the depths the build passed."""
+        out = (C.c_uint64 * 64)()
+        rc = _lib.lib().msbwt_rle_sparse_table_info(self._h, out)
+        if rc:
+            _raise(rc, self._h)
+        info = {"depth": int(out[0]), "entries": int(out[1]), "buckets": int(out[2]), "bytes": int(out[3]), "side_entries": int(out[4]),
+                "side_bytes": int(out[5]), "displaced": int(out[6]), "parent_depth": int(out[7]), "probe": int(out[9])}
+        info["distinct"] = {d: int(out[10 + d]) for d in range(25) if out[10 + d]}
+        info["wide"] = {d: int(out[35 + d]) for d in range(25) if out[10 + d]}
+        return info
+
+    def download_sparse_table(self):
+        """(lines, side): the bucket lines as a (nlines, 32) uint32 array and the side array as (n, 2) uint64 -- for tests."""
+        info = self.sparse_table_info()
+        if not info["depth"]:
+            return None, None
+        lines = np.empty((info["bytes"] // 128, 32), dtype=np.uint32)
+        side = np.empty((info["side_bytes"] // 16, 2), dtype=np.uint64)
+        got = _lib.lib().msbwt_rle_download_sparse_table(self._h, lines.ctypes.data_as(C.c_void_p), lines.nbytes,
+                                                         side.ctypes.data_as(C.c_void_p) if side.size else None, side.nbytes)
+        if got == _lib.SIZE_MAX:
+            _raise(_lib.ERR_HIP, self._h)
+        return lines, side
 
     def set_search_counters(self, enabled):
         rc = _lib.lib().msbwt_rle_set_search_counters(self._h, 1 if enabled else 0)

@@ -14,18 +14,21 @@ from rle_random import random_kmers, random_stream, raw_byte_stream, runs_to_byt
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["auto", "groups", "lanes", "runs"])
+@pytest.fixture(autouse=True, params=["auto", "groups", "lanes", "runs", "sparse"])
 def search_kernel(request, monkeypatch):
-    """Every test of this file runs four times: with the automatic choice of count_kmers kernel,
-    with the 8-lanes-per-query kernel forced, with the one-query-per-lane (LDS-staged) kernel
-    forced, and on the run-block index format (MSBWT_BLOCKS=runs: no plane blocks, no pair index)
-    -- a handle reads MSBWT_SEARCH / MSBWT_BLOCKS when it is created."""
-    monkeypatch.setenv("MSBWT_SEARCH", "auto" if request.param == "runs" else request.param)
-    monkeypatch.setenv("MSBWT_BLOCKS", "runs" if request.param == "runs" else "planes")
+    """Every test of this file runs five times: with the automatic choices (kernel, sparse suffix table when the data warrant
+    one), with the 8-lanes-per-query kernel forced, with the one-query-per-lane (LDS-staged) kernel forced on the DIRECT suffix
+    table only, on the run-block index format (MSBWT_BLOCKS=runs: no plane blocks, no pair index), and with the lane-per-query
+    kernel on a SPARSE suffix table of the smallest depth (16: every query of 16 symbols or more is looked up there) -- a handle
+    reads MSBWT_SEARCH / MSBWT_BLOCKS / MSBWT_SPARSE_TABLE when it is created."""
+    mode = request.param
+    monkeypatch.setenv("MSBWT_SEARCH", "lanes" if mode in ("lanes", "sparse") else ("auto" if mode == "runs" else mode))
+    monkeypatch.setenv("MSBWT_BLOCKS", "runs" if mode == "runs" else "planes")
+    monkeypatch.setenv("MSBWT_SPARSE_TABLE", {"lanes": "0", "sparse": "16"}.get(mode, "auto"))
     # pair blocks: the forced-lanes mode keeps the disjoint 128-position blocks, the others take the
     # automatic choice (overlapping stride-96 blocks on indexes this small)
-    monkeypatch.setenv("MSBWT_PAIR_STRIDE", "128" if request.param == "lanes" else "0")
-    return request.param
+    monkeypatch.setenv("MSBWT_PAIR_STRIDE", "128" if mode == "lanes" else "0")
+    return mode
 
 
 def needs_plane_blocks(mode):
@@ -578,6 +581,7 @@ def test_escape_lines_of_a_real_bwt_with_repeats_cost_one_line(search_kernel):
     o = orc.OracleRleBWT()
     o.load_vector(rle)
     b = gpu_bwt(rle)
+    b.set_sparse_table(0)  # (this test is about the DIRECT table's escape lines: 31-mers must not be served by the sparse one)
     b.set_pair_index(1)
     b.set_table_depth(3)
     b.set_table_packed(1)

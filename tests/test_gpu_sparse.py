@@ -1,0 +1,223 @@
+"""The sparse suffix table (include/msbwt_hip.h, msbwt_rle_set_sparse_table; csrc/sparse_table.hpp) against the CPU oracle:
+every entry the device builder wrote, the distinct counts it reports, and the counts of the kernels that look queries up in
+it.  Needs an MI355X: run with `pytest -m gpu`."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import rust_msbwt_amd as msbwt
+from rust_msbwt_amd import RleBWT, _lib
+from oracle import oracle as orc
+from rle_random import random_kmers, random_stream
+
+pytestmark = pytest.mark.gpu
+
+ACGT = np.array([1, 2, 3, 5], dtype=np.uint8)
+
+
+def read_set(seed, genome_len, n_reads, read_len, repeats=0, err=0.0):
+    """Reads of a random genome (optionally with a few exact repeats pasted in, so that some suffixes occur often)."""
+    rng = np.random.default_rng(seed)
+    g = ACGT[rng.integers(0, 4, size=genome_len)]
+    for _ in range(repeats):
+        src, dst = rng.integers(0, genome_len - 400, size=2)
+        g[dst:dst + 300] = g[src:src + 300]
+    starts = rng.integers(0, genome_len - read_len, size=n_reads)
+    reads = np.stack([g[s:s + read_len] for s in starts])
+    if err:
+        flip = rng.random(reads.shape) < err
+        reads = np.where(flip, ACGT[rng.integers(0, 4, size=reads.shape)], reads)
+    return reads
+
+
+def bwt_of(reads):
+    text = ["".join("$ACGNT"[c] for c in r) for r in reads]
+    return orc.convert_to_vec(orc.naive_bwt(text))
+
+
+def load_pair(rle, monkeypatch, depth, **env):
+    monkeypatch.setenv("MSBWT_SEARCH", "lanes")
+    monkeypatch.setenv("MSBWT_SPARSE_TABLE", str(depth))
+    for k, v in env.items():
+        monkeypatch.setenv(k, str(v))
+    ref = orc.OracleRleBWT()
+    ref.load_vector(rle)
+    b = RleBWT()
+    b.load_vector(rle)
+    return b, ref
+
+
+def oracle_ranges(ref, kmers):
+    """[l, h) of every row of `kmers` by the oracle's own constrain_range, last symbol first (msbwt_core.rs:150-156)."""
+    n, k = kmers.shape
+    l = np.zeros(n, dtype=np.uint64)
+    h = np.full(n, ref.get_total_size(), dtype=np.uint64)
+    for t in range(k):
+        l, h = ref.constrain_ranges(kmers[:, k - 1 - t], l, h)
+    return l, h
+
+
+def table_key(kmers):
+    """The table index of the rows' symbols: A C G T -> 0..3, step t (the t-th symbol from the END) at bits [2t, 2t+2)."""
+    codes = (kmers.astype(np.uint64) - 1 - (kmers.astype(np.uint64) >> 2))
+    k = kmers.shape[1]
+    key = np.zeros(len(kmers), dtype=np.uint64)
+    for t in range(k):
+        key |= codes[:, k - 1 - t] << np.uint64(2 * t)
+    return key
+
+
+def host_lookup(lines, side, info, key):
+    """What the kernel does with one key, on the downloaded table: -> (l, h) or None."""
+    b, tag = C.c_uint32(), C.c_uint32()
+    assert _lib.lib().msbwt_sparse_hash(int(key), info["depth"], info["buckets"], C.byref(b), C.byref(tag)) == 0
+    bucket = b.value
+    for dist in range(info["probe"] + 1):
+        line = lines[bucket + dist]
+        raw = line.view(np.uint8)
+        for slot in range(14):
+            t = int(line[slot])
+            if (t >> 24) != 0 and (t & 0xFFFFFF) == tag.value:
+                lo = int(line[14 + slot]) | (int(raw[112 + slot]) << 32)
+                width = t >> 24
+                if width == 255:
+                    return int(side[lo][0]), int(side[lo][1])
+                return lo, lo + width
+        header = int(raw[126]) | (int(raw[127]) << 8)
+        if header <= 14:
+            return None
+    return None
+
+
+@pytest.mark.parametrize("depth", [16, 17, 20])
+def test_every_entry_of_the_table_is_the_oracles_range(depth, monkeypatch):
+    reads = read_set(11, 3000, 700, 60, repeats=4, err=0.01)
+    b, ref = load_pair(bwt_of(reads), monkeypatch, depth)
+    assert b.get_sparse_table() == depth and b.get_pair_index()
+    info = b.sparse_table_info()
+    lines, side = b.download_sparse_table()
+    # the suffixes that occur = the distinct ACGT substrings of the reads
+    present = np.unique(np.concatenate([np.lib.stride_tricks.sliding_window_view(reads, depth, axis=1).reshape(-1, depth)]), axis=0)
+    assert info["entries"] == len(present) == info["distinct"][depth]
+    l, h = oracle_ranges(ref, present)
+    assert (h > l).all()
+    for key, el, eh in zip(table_key(present), l, h):
+        assert host_lookup(lines, side, info, key) == (int(el), int(eh))
+    # the table is complete and holds nothing else: absent suffixes miss, and the slots in use are exactly the entries
+    absent = random_kmers(5, 3000, depth)
+    al, ah = oracle_ranges(ref, absent)
+    for key, el, eh in zip(table_key(absent), al, ah):
+        got = host_lookup(lines, side, info, key)
+        assert got == ((int(el), int(eh)) if eh > el else None)
+    assert int(((lines[:, :14] >> 24) != 0).sum()) == info["entries"]
+    # distinct counts of the shallower levels the build passed through
+    for d, n in info["distinct"].items():
+        if 4 <= d <= depth:
+            assert n == len(np.unique(np.lib.stride_tricks.sliding_window_view(reads, d, axis=1).reshape(-1, d), axis=0)), d
+
+
+@pytest.mark.parametrize("stride", [96, 128])
+@pytest.mark.parametrize("depth", [16, 19, 23, 24])
+def test_counts_with_the_sparse_table_equal_the_oracle(depth, stride, monkeypatch):
+    reads = read_set(21 + depth, 5000, 900, 80, repeats=6, err=0.005)
+    b, ref = load_pair(bwt_of(reads), monkeypatch, depth, MSBWT_PAIR_STRIDE=stride)
+    assert b.get_sparse_table() == depth and b.get_pair_stride() == stride
+    rng = np.random.default_rng(depth)
+    for k in [depth, depth + 1, depth + 2, 31, 32, 33, 47, 64]:
+        if k < depth or k > 80:
+            continue
+        windows = np.lib.stride_tricks.sliding_window_view(reads, k, axis=1).reshape(-1, k)
+        q = np.concatenate([windows[rng.integers(0, len(windows), size=3000)], random_kmers(k, 1500, k)])
+        # some queries differ from a present one in a single symbol, early or late
+        mut = windows[rng.integers(0, len(windows), size=1500)].copy()
+        pos = rng.integers(0, k, size=len(mut))
+        mut[np.arange(len(mut)), pos] = ACGT[rng.integers(0, 4, size=len(mut))]
+        # and some hold '$' / 'N' inside or outside the table's reach
+        odd = windows[rng.integers(0, len(windows), size=600)].copy()
+        odd[np.arange(len(odd)), rng.integers(0, k, size=len(odd))] = rng.choice([0, 4], size=len(odd))
+        q = np.ascontiguousarray(np.concatenate([q, mut, odd]))
+        rng.shuffle(q)
+        exp = ref.count_kmers(q)
+        assert b.search_kernel_for(k) == "lanes"
+        assert np.array_equal(b.count_kmers(q), exp), k
+        if k <= 64:
+            plain = q[np.isin(q, ACGT).all(axis=1)]
+            assert np.array_equal(b.count_kmers_packed(msbwt.rle_bwt.pack_2bit(plain), k), ref.count_kmers(plain)), k
+    # the fused read windows, both strands
+    k = max(depth, 25)
+    fwd, rc = b.count_read_kmers(reads[:200], k, ascii=False, forward=True, revcomp=True)
+    windows = np.lib.stride_tricks.sliding_window_view(reads[:200], k, axis=1)
+    assert np.array_equal(fwd, ref.count_kmers(windows.reshape(-1, k)).reshape(fwd.shape))
+    rcq = np.array([orc.reverse_complement_i(w) for w in windows.reshape(-1, k)], dtype=np.uint8)
+    assert np.array_equal(rc, ref.count_kmers(rcq).reshape(rc.shape))
+    # switching the table off (and on again) changes nothing but the table
+    b.set_sparse_table(0)
+    assert b.get_sparse_table() == 0
+    q = np.ascontiguousarray(windows.reshape(-1, k)[:4000])
+    assert np.array_equal(b.count_kmers(q), ref.count_kmers(q))
+    b.set_sparse_table(depth)
+    assert b.get_sparse_table() == depth
+    assert np.array_equal(b.count_kmers(q), ref.count_kmers(q))
+
+
+def test_wide_entries_go_through_the_side_array_and_full_buckets_displace(monkeypatch):
+    """Suffixes of a high-copy repeat (range 255 or more wide) keep their range in the side array; with enough entries some
+    buckets overflow and their keys are found a bucket later -- both by the kernel's own counters."""
+    rng = np.random.default_rng(3)
+    genome = ACGT[rng.integers(0, 4, size=40000)]
+    unit = ACGT[rng.integers(0, 4, size=40)]
+    reads = [genome[s:s + 50] for s in rng.integers(0, len(genome) - 50, size=2500)]
+    reads += [np.concatenate([unit, unit])[o:o + 50] for o in rng.integers(0, 30, size=600)]  # 600 copies of one 40-mer's rotations
+    reads = np.stack(reads)
+    b, ref = load_pair(bwt_of(reads), monkeypatch, 16)
+    info = b.sparse_table_info()
+    assert info["side_entries"] > 0 and info["side_entries"] == info["wide"][16]
+    assert info["displaced"] > 0, info
+    k = 31
+    windows = np.lib.stride_tricks.sliding_window_view(reads, k, axis=1).reshape(-1, k)
+    q = np.ascontiguousarray(np.concatenate([windows, random_kmers(9, 20000, k)]))
+    b.set_search_counters(True)
+    got = b.count_kmers(q)
+    cnt = b.search_counters(0)
+    assert np.array_equal(got, ref.count_kmers(q))
+    assert got.max() >= 255
+    assert cnt["escape_queries"] > 0 and cnt["table_displaced"] > 0 and cnt["table_steps"] >= len(windows)  # (random k-mers mostly end in the presence filter)
+    # every query that entered the search took exactly one lookup plus ceil((k - 16) / 2) pair steps at most
+    assert cnt["lane_steps"] <= cnt["table_steps"] + cnt["searched"] * 8
+
+
+def test_arbitrary_symbol_streams_and_replicas(monkeypatch):
+    """Not a BWT at all: a random run stream over all six symbols -- the table is whatever backward search says, like the oracle."""
+    rle = random_stream(77, 30000, "short")
+    b, ref = load_pair(rle, monkeypatch, 16)
+    assert b.get_sparse_table() == 16
+    for k in (16, 21, 31, 40):
+        q = np.ascontiguousarray(np.concatenate([random_kmers(k, 20000, k), random_kmers(k + 1, 3000, k, alphabet=(0, 1, 2, 3, 4, 5))]))
+        assert np.array_equal(b.count_kmers(q), ref.count_kmers(q)), k
+    twin = b.replicate(b.device_ordinal())
+    assert twin.get_sparse_table() == 16 and twin.sparse_table_info()["entries"] == b.sparse_table_info()["entries"]
+    q = np.ascontiguousarray(random_kmers(5, 30000, 24))
+    assert np.array_equal(twin.count_kmers(q), ref.count_kmers(q))
+    assert twin.device_bytes() == b.device_bytes()
+
+
+def test_automatic_depth_follows_the_data_and_short_queries_use_the_direct_table(monkeypatch):
+    reads = read_set(5, 20000, 6000, 100, err=0.005)
+    monkeypatch.setenv("MSBWT_SEARCH", "auto")
+    monkeypatch.delenv("MSBWT_SPARSE_TABLE", raising=False)
+    rle = bwt_of(reads)
+    ref = orc.OracleRleBWT()
+    ref.load_vector(rle)
+    b = RleBWT()
+    b.load_vector(rle)
+    depth = b.get_sparse_table()
+    info = b.sparse_table_info()
+    assert 16 <= depth <= 23 and info["bytes"] <= 64 << 20, info  # a toy index gets a toy table
+    assert b.get_table_depth() <= 15  # the direct table beside it stays small
+    for k in (8, depth - 1, depth, 31):
+        windows = np.lib.stride_tricks.sliding_window_view(reads, k, axis=1).reshape(-1, k)
+        q = np.ascontiguousarray(np.concatenate([windows[::7], random_kmers(k, 5000, k)]))
+        assert np.array_equal(b.count_kmers(q), ref.count_kmers(q)), k
+    with pytest.raises(msbwt.MsbwtError):
+        b.set_sparse_table(12)
