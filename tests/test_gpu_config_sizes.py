@@ -152,8 +152,8 @@ def test_stream_beyond_2_pow_33_symbols_hbm_regime():
 
 def test_human_scale_9e10_symbols_against_the_oracle():
     """The size and the index the metric is quoted on: the exact MSBWT of 5.96e8 error-free reads, 9e10 symbols (positions
-    beyond 2^36, 40-bit header counts with high bytes up to 20, the full 238 GB index: depth-17 packed table, overlapping
-    pair blocks addressed at human scale): 2e6 present (LF-walk) +
+    beyond 2^36, 40-bit header counts with high bytes up to 20, the full index: sparse suffix table of depth 23 -- and, with it switched off, the 238 GB index of
+    rounds 2-4 with its depth-17 packed table --, overlapping pair blocks addressed at human scale): 2e6 present (LF-walk) +
     2e6 random 31-mers under both search kernels, and 1e6 batched constrain_range calls with l, h > 2^36, all
     against the oracle on the same stream.  Needs ~250 GB of HBM and ~20 GB of host memory; about two minutes."""
     import synth
@@ -173,7 +173,10 @@ def test_human_scale_9e10_symbols_against_the_oracle():
     assert total == n_reads * 151 and abs(total - bench.HUMAN_SYMBOLS) < 1e-3 * bench.HUMAN_SYMBOLS and total > 2**36
     bwt = RleBWT(device=0)
     bwt.load_vector(rle)
-    assert bwt.get_total_size() == total and bwt.get_table_depth() == 17 and bwt.get_pair_index()
+    # the default index since round 5: sparse suffix table of depth 23 (3e9 distinct 23-mers, ~42 GB), a small direct table beside it
+    assert bwt.get_total_size() == total and bwt.get_pair_index() and bwt.get_sparse_table() == 23 and bwt.get_table_depth() == 15
+    info = bwt.sparse_table_info()
+    assert 2.9e9 < info["entries"] < 3.1e9 and info["entries"] == info["distinct"][23] and info["bytes"] < 50e9, info
     # a real 30x BWT: present k-mers keep ranges ~ coverage wide, and the loader answers with overlapping pair blocks
     assert bwt.get_typical_range_width() >= 20 and bwt.get_pair_stride() == 96
     ref = orc.OracleRleBWT()
@@ -191,6 +194,14 @@ def test_human_scale_9e10_symbols_against_the_oracle():
         bwt.set_search_kernel(mode)
         got = _count_matrix(torch, dev, bwt, d_q).cpu().numpy().astype(np.uint64)
         assert np.array_equal(got, exp), mode
+    # without the sparse table the loader builds what rounds 2-4 measured: the depth-17 packed direct table (73 GB, 238 GB in all)
+    bwt.set_sparse_table(0)
+    assert bwt.get_sparse_table() == 0 and bwt.get_table_depth() == 17 and bwt.device_bytes() > 230e9
+    bwt.set_search_kernel("lanes")
+    got = _count_matrix(torch, dev, bwt, d_q).cpu().numpy().astype(np.uint64)
+    assert np.array_equal(got, exp)
+    bwt.set_sparse_table(-1)
+    assert bwt.get_sparse_table() == 23 and bwt.get_table_depth() == 15
     # k > 32 takes the other instantiation of the lanes kernel (6 words of symbols): 59-mers, fmlrc's long k
     bwt.set_search_kernel("auto")
     long_q = bench.walk_kmers(torch, np, bwt, dev, total, 500_000, 59, 7)
