@@ -344,7 +344,8 @@ int msbwt_rle_search_kernel_for(const msbwt_rle *bwt, size_t k);
  * waited because the second-line slots of its wave were taken, [5] queries whose packed-table line is an escape line,
  * [6] of which searched from scratch (no side array), [7] queries decided by the table / presence filter alone, [8] queries
  * that entered the search, [9] first lines fetched, [10] sparse-table bucket lines fetched (included in [1]), [11] of which did not
- * hold the key although the bucket had displaced entries (the lookup went on to the next bucket); the rest 0.  msbwt_rle_search_counters copies the block out and
+ * hold the key although the bucket had displaced entries (the lookup went on to the next bucket), [12] of [10], lookups that rode
+ * along with the search of the tile before theirs (in second-line slots that step left free) instead of taking a step of their own; the rest 0.  msbwt_rle_search_counters copies the block out and
  * zeroes it (synchronises `hip_stream`, on which the counted launches ran).  Results never change. */
 #define MSBWT_SEARCH_COUNTERS 16
 int msbwt_rle_set_search_counters(msbwt_rle *bwt, int enabled);

@@ -85,6 +85,7 @@ enum SearchCounter {
     kCntFirstLines,        // first-bound lines fetched (one per lane-step) + side-array entries fetched for escape-line queries
     kCntTableSteps,        // sparse table: bucket lines fetched (lane-steps that were lookups; included in kCntLaneSteps)
     kCntTableDisplaced,    // ... of which did not find the key in a bucket that had displaced entries (the lookup went on)
+    kCntTableRides,        // ... of which rode along with the search of the tile before (no search step of their own)
     kSearchCounters = 16
 };
 

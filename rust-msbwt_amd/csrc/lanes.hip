@@ -264,6 +264,32 @@ __device__ __forceinline__ uint64_t pair_line_bound(const PairLine &L, uint64_t 
     return super_base + L.field + pair_line_count(L, r);
 }
 
+// ---- sparse suffix table (sparse_table.hpp): this lane's key among the 14 entries of a staged bucket line -------------------------
+// The line: 14 tags in words 0..13 (chunks 0-3), l in words 14..27 and bytes 112..125, the bucket's header in bytes 126..127.  A
+// key sits in at most one slot of at most one bucket, so a tag match IS the entry.  -> true: l and width (255 = the range lives
+// in the side array, l = its index there); false: not in this bucket -- header > 14 says that entries of it were displaced.
+__device__ __forceinline__ bool sparse_scan(const uint4 *lines, uint32_t slot, uint32_t want, uint64_t &l, uint32_t &width, uint32_t &header) {
+    const uint32_t base = line_base(slot), g = slot & 7u;
+    const uint4 c0 = lines[base + (0u ^ g)], c1 = lines[base + (1u ^ g)], c2 = lines[base + (2u ^ g)], c3 = lines[base + (3u ^ g)];
+    const uint32_t tags[kSparseSlots] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y};
+    uint32_t hit = kSparseSlots;
+    width = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < kSparseSlots; ++i) {
+        const uint32_t t = tags[i];
+        const bool match = ((t ^ want) << (32u - kSparseTagBits)) == 0u && (t >> kSparseTagBits) != 0u;
+        hit = match ? i : hit;
+        width = match ? t >> kSparseTagBits : width;
+    }
+    header = lines[base + (7u ^ g)].w >> 16;
+    if (hit >= kSparseSlots) return false;
+    const uint32_t word = kSparseL0Word + hit;
+    const uint32_t lo = reinterpret_cast<const uint32_t *>(lines)[(base + ((word >> 2) ^ g)) * 4u + (word & 3u)];
+    const uint32_t hi = reinterpret_cast<const uint8_t *>(lines)[(base + (7u ^ g)) * 16u + hit];
+    l = (uint64_t(hi) << 32) | lo;
+    return true;
+}
+
 // kPacked (matrix mode only): the queries come as 2-bit words (QuerySource::packed), possibly with a place for each count.
 // A compile-time switch, not a launch-uniform branch: with both ways of fetching a tile in one kernel the compiler merged
 // their results through register copies, i.e. WAITED for the tile's bytes right after asking for them -- setup no longer
@@ -461,17 +487,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             // escape line, 2.3 % (18.55 against 18.12 ms, same box); the wait costs only the tiles that meet one.
             bool escaped = false, restart = false;
             bool lookup = false;  // kSparse: enters the ring as a table lookup
-            if (kSparse && prep_kind == 3u) {
+            if (kSparse && prep_kind == 3u) {  // not looked up on the way (no free slot, a short search before it): its bucket is its first step
                 pl = prep_entry.x;  // bucket
                 ph = prep_entry.y;  // tag
                 skip = depth;
                 lookup = true;
             }
+            if (kSparse && prep_kind == 4u) {  // looked up while the tile before it was searched (step D): l, width
+                pl = (uint64_t(prep_entry.y & 0xFFu) << 32) | prep_entry.x;
+                ph = pl + (prep_entry.y >> 8);
+                skip = depth;
+                escaped = (prep_entry.y >> 8) == kSparseEscapeWidth;  // (pl = the entry's index in the side array)
+            }
             if (!kSparse && prep_kind == 1u) {
                 if (table_decode(env, prep_entry, pl, ph)) skip = depth;
                 else escaped = true;
             }
-            if (!kSparse && __ballot(escaped) != 0ull) {  // wave-uniform, rare
+            if (__ballot(escaped) != 0ull) {  // wave-uniform, rare
                 if (kSideFetch && table_side != nullptr) {
                     if (escaped) {
                         const uint4 e = table_side[pl];
@@ -483,6 +515,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                     restart = true;
                     pl = 0;
                     ph = total;
+                    skip = 0;
                 }
             }
             const uint32_t prep_rem = k - skip;
@@ -507,7 +540,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 it.l_lo = uint32_t(pl);
                 it.h_lo = uint32_t(ph);
                 it.meta = uint32_t(pl >> 32) | (uint32_t(ph >> 32) << 8) | (prep_rem << 16) | (lane << 24);  // l, h < 2^40; rem <= 64
-                if (kSparse && lookup) it.meta |= 1u << 23;
+                if (kSparse && lookup) it.meta = prep_entry.z | (prep_rem << 16) | (lane << 24) | (1u << 23);  // (buckets gone beyond its own so far)
 #pragma unroll
                 for (int i = 0; i < kWords; ++i) it.w[i] = prep_w[i];
                 if constexpr (kPacked) it.out = prep_out;
@@ -532,6 +565,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 rem = (it.meta >> 16) & (kSparse ? 0x7Fu : 0xFFu);
                 tmode = kSparse && ((it.meta >> 23) & 1u) != 0u;
                 tdist = 0u;
+                if (kSparse && tmode) {
+                    tdist = it.meta & 0xFFu;
+                    l = it.l_lo;
+                    h = it.h_lo;
+                }
                 qid = ring_tile * kTile + (it.meta >> 24);
                 if constexpr (kPacked) qid = place_of(qid, it.out);
                 ovf_l = ovf_h = 0u;
@@ -627,6 +665,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                             const uint64_t x = sparse_mix(pq.tidx, 2u * depth);
                             prep_entry.x = sparse_bucket(x, 2u * depth, sparse_nbuckets);
                             prep_entry.y = sparse_tag(x);
+                            prep_entry.z = 0u;  // buckets gone beyond its own
                             prep_kind = 3;
                         } else {
                             prep_entry = table_fetch(env, pq.tidx);  // stays in flight: consumed in step A of a later iteration
@@ -703,7 +742,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
         const uint32_t slot_l = lane, slot_h = second ? 64u + second_rank : lane;
         list[lane] = act ? line_l : dummy;
         if (second && act) list[slot_h] = line_h;
-        if (lane < 8u && 64u + nsecond + lane < uint32_t(kLineSlots)) list[64u + nsecond + lane] = dummy;  // the ragged end of the last second-bound region
+        // kSparse: the second-line slots this step leaves free carry lookups of the PREPARED tile -- its queries' bucket lines ride
+        // along with the search of the tile before it (16 a step: the four pair steps of a 31-mer behind a depth-23 table bring in
+        // a whole tile), so that a tile whose turn comes mostly knows its ranges and a lookup costs no search step of its own.
+        bool riding = false;
+        uint32_t slot_ride = 0, nextra = nsecond;
+        if (kSparse) {
+            const bool wants = prepared && prep_kind == 3u;
+            const uint64_t wants_mask = __ballot(wants);
+            if (wants_mask != 0ull) {  // wave-uniform
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(wants_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(wants_mask), 0u));
+                const uint32_t room = kMaxSecond - nsecond;
+                riding = wants && rank < room;
+                slot_ride = 64u + nsecond + rank;
+                if (riding) list[slot_ride] = reinterpret_cast<uint64_t>(table) + uint64_t(prep_entry.x) * 128u;
+                nextra += min(uint32_t(__popcll(wants_mask)), room);
+            }
+        }
+        if (lane < 8u && 64u + nextra + lane < uint32_t(kLineSlots)) list[64u + nextra + lane] = dummy;  // the ragged end of the last second-bound region
         // pair steps: K[a][b] + occ2 at the superblock start (L2-resident table).  One 8-byte load per lane
         // is a separate L2 request each (64 per wave): the second bound's base is fetched only in the rare
         // case that it lies in another superblock -- into a register of its own, so that nothing here waits
@@ -727,7 +783,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             wave_lds_sync();
 #pragma unroll
             for (int i = 0; i < kRegions; ++i) {
-                const bool wanted = i < 8 ? ((busy >> (8 * i)) & 0xFFull) != 0ull : nsecond > uint32_t(8 * (i - 8));  // wave-uniform
+                const bool wanted = i < 8 ? ((busy >> (8 * i)) & 0xFFull) != 0ull : nextra > uint32_t(8 * (i - 8));  // wave-uniform
                 if (wanted) __builtin_amdgcn_global_load_lds((global_void *)addr[i], (lds_void *)&ws.lines[region_base(i)], 16, 0, 0);
             }
         }
@@ -739,37 +795,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             count(kCntPairSteps, __ballot(act && pair));
             count(kCntSecondLines, __ballot(act && second));
             count(kCntSatOut, __ballot(have && !act));
-            if (kSparse) count(kCntTableSteps, __ballot(act && looking));
+            if (kSparse) {
+                count(kCntTableSteps, __ballot(act && looking) );
+                count(kCntTableSteps, __ballot(riding));
+                count(kCntFirstLines, __ballot(riding));
+                count(kCntTableRides, __ballot(riding));
+            }
+        }
+        if (kSparse && __ballot(riding) != 0ull) {  // the prepared tile's lookups that rode along
+            if (riding) {
+                uint64_t tl = 0;
+                uint32_t tw = 0, header = 0;
+                if (sparse_scan(ws.lines, slot_ride, prep_entry.y, tl, tw, header)) {
+                    prep_entry.x = uint32_t(tl);
+                    prep_entry.y = uint32_t(tl >> 32) | (tw << 8);
+                    prep_kind = 4;
+                } else if (header > kSparseSlots && prep_entry.z < sparse_probe) {  // entries of this bucket were displaced: the next one, next time
+                    ++prep_entry.x;
+                    ++prep_entry.z;
+                } else {  // a miss in a complete table: the suffix does not occur (msbwt_core.rs:151-153)
+                    store_count<kReads>(src, place_of(prep_tile * kTile + lane, prep_out), 0ull);
+                    prep_kind = 0;
+                }
+            }
+            if (counting) {
+                count(kCntTableDisplaced, __ballot(riding && prep_kind == 3u));
+                count(kCntTableDecided, __ballot(riding && prep_kind == 0u));
+            }
         }
         if (act) {
             uint64_t nl, nh;
             bool step_done = true;
-            if (kSparse && looking) {
-                // the bucket line: 14 tags in words 0..13 (chunks 0-3), l in words 14..27 and bytes 112..125, the bucket's header in
-                // bytes 126..127 (sparse_table.hpp).  A key sits in at most one slot of at most one bucket: a tag match is the entry.
-                const uint32_t base_t = line_base(slot_l), g = slot_l & 7u;
-                const uint4 c0 = ws.lines[base_t + (0u ^ g)], c1 = ws.lines[base_t + (1u ^ g)], c2 = ws.lines[base_t + (2u ^ g)], c3 = ws.lines[base_t + (3u ^ g)];
-                const uint32_t tags[kSparseSlots] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y};
-                const uint32_t want = uint32_t(h);
-                uint32_t hit = kSparseSlots, width = 0;
-#pragma unroll
-                for (uint32_t i = 0; i < kSparseSlots; ++i) {
-                    const uint32_t t = tags[i];
-                    const bool match = ((t ^ want) << (32u - kSparseTagBits)) == 0u && (t >> kSparseTagBits) != 0u;
-                    hit = match ? i : hit;
-                    width = match ? t >> kSparseTagBits : width;
-                }
-                const uint32_t header = ws.lines[base_t + (7u ^ g)].w >> 16;
+            if (kSparse && looking) {  // this step fetched the query's own bucket
+                uint64_t tl = 0;
+                uint32_t width = 0, header = 0;
+                const bool hit = sparse_scan(ws.lines, slot_l, uint32_t(h), tl, width, header);
                 nl = nh = 0;
                 step_done = false;
-                if (hit < kSparseSlots) {
-                    const uint32_t word = kSparseL0Word + hit;
-                    const uint32_t lo = reinterpret_cast<const uint32_t *>(ws.lines)[(base_t + ((word >> 2) ^ g)) * 4u + (word & 3u)];
-                    const uint32_t hi = reinterpret_cast<const uint8_t *>(ws.lines)[(base_t + (7u ^ g)) * 16u + hit];
-                    l = (uint64_t(hi) << 32) | lo;
-                    h = l + width;
+                if (hit) {
+                    l = tl;
+                    h = tl + width;
                     if (width == kSparseEscapeWidth) {  // a high-copy suffix: its range is a flat entry of the side array, one more line
-                        const uint4 e = table_side[l];
+                        const uint4 e = table_side[tl];
                         l = (uint64_t(e.y) << 32) | e.x;
                         h = (uint64_t(e.w) << 32) | e.z;
                     }
@@ -786,9 +853,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                     have = false;
                 }
                 if (counting) {
-                    count(kCntEscapeQueries, __ballot(hit < kSparseSlots && width == kSparseEscapeWidth));
-                    count(kCntTableDisplaced, __ballot(hit >= kSparseSlots && have));
-                    count(kCntTableDecided, __ballot(hit >= kSparseSlots && !have));
+                    count(kCntEscapeQueries, __ballot(hit && width == kSparseEscapeWidth));
+                    count(kCntFirstLines, __ballot(hit && width == kSparseEscapeWidth));
+                    count(kCntTableDisplaced, __ballot(!hit && have));
+                    count(kCntTableDecided, __ballot(!hit && !have));
                 }
             } else if (pair) {
                 PairLine L;

@@ -294,7 +294,7 @@ class RleBWT(BWT):
         return {"lines": a.value, "escape_lines": b.value, "side_bytes": c.value}
 
     COUNTER_NAMES = ("wave_steps", "lane_steps", "pair_steps", "second_lines", "sat_out", "escape_queries", "escape_restarts",
-                     "table_decided", "searched", "first_lines", "table_steps", "table_displaced")
+                     "table_decided", "searched", "first_lines", "table_steps", "table_displaced", "table_rides")
 
     # ---- sparse suffix table (include/msbwt_hip.h, msbwt_rle_set_sparse_table) ----
     def set_sparse_table(self, depth):

@@ -176,13 +176,15 @@ def test_wide_entries_go_through_the_side_array_and_full_buckets_displace(monkey
     assert info["displaced"] > 0, info
     k = 31
     windows = np.lib.stride_tricks.sliding_window_view(reads, k, axis=1).reshape(-1, k)
-    q = np.ascontiguousarray(np.concatenate([windows, random_kmers(9, 20000, k)]))
+    # (many more tiles than resident waves -- 3072 -- so that most tiles are prepared while another one is searched)
+    q = np.ascontiguousarray(np.concatenate([windows] * 12 + [random_kmers(9, 20000, k)]))
     b.set_search_counters(True)
     got = b.count_kmers(q)
     cnt = b.search_counters(0)
     assert np.array_equal(got, ref.count_kmers(q))
     assert got.max() >= 255
-    assert cnt["escape_queries"] > 0 and cnt["table_displaced"] > 0 and cnt["table_steps"] >= len(windows)  # (random k-mers mostly end in the presence filter)
+    assert cnt["table_rides"] > 0.25 * 12 * len(windows)  # most lookups ride along with the search of the tile before theirs
+    assert cnt["escape_queries"] > 0 and cnt["table_displaced"] > 0 and cnt["table_steps"] >= 12 * len(windows)  # (random k-mers mostly end in the presence filter)
     # every query that entered the search took exactly one lookup plus ceil((k - 16) / 2) pair steps at most
     assert cnt["lane_steps"] <= cnt["table_steps"] + cnt["searched"] * 8
 
