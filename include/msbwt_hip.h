@@ -345,11 +345,17 @@ int msbwt_rle_search_kernel_for(const msbwt_rle *bwt, size_t k);
  * [6] of which searched from scratch (no side array), [7] queries decided by the table / presence filter alone, [8] queries
  * that entered the search, [9] first lines fetched, [10] sparse-table bucket lines fetched (included in [1]), [11] of which did not
  * hold the key although the bucket had displaced entries (the lookup went on to the next bucket), [12] of [10], lookups that rode
- * along with the search of the tile before theirs (in second-line slots that step left free) instead of taking a step of their own; the rest 0.  msbwt_rle_search_counters copies the block out and
+ * along with the search of the tile before theirs (in second-line slots that step left free) instead of taking a step of their own, [13] waves of the
+ * persistent kernel that were dealt at least one tile; the rest 0.  msbwt_rle_search_counters copies the block out and
  * zeroes it (synchronises `hip_stream`, on which the counted launches ran).  Results never change. */
 #define MSBWT_SEARCH_COUNTERS 16
 int msbwt_rle_set_search_counters(msbwt_rle *bwt, int enabled);
 int msbwt_rle_search_counters(const msbwt_rle *bwt, uint64_t *out, void *hip_stream);
+/* Placement diagnostic: random 128-byte lines per second the memory system serves right now from one of the index's arrays
+ * (which: 0 = plane / run blocks, 1 = pair blocks, 2 = the sparse table's bucket lines, 3 = the direct suffix table; 0.0 when the
+ * index has no such array) -- about a millisecond of gathering, nothing is written.  (Round 5 used it on the "two modes" of C4-sized
+ * indexes -- the same launch 12 or 14 ms per instance of the index: a plain gather does not see them, profiles/r05_lab/two_modes.log.) */
+int msbwt_rle_probe_line_rate(const msbwt_rle *bwt, int which, double *lines_per_second);
 /* Bytes of HBM held by the index (blocks + table + filter + pair index). */
 uint64_t msbwt_rle_device_bytes(const msbwt_rle *bwt);
 /* Average duration in ms of the count kernel launches since the last reset, measured with

@@ -116,6 +116,7 @@ struct msbwt_rle {
 namespace {
 
 constexpr int kMaxTableDepth = 16;  // 4^16 x 16 B = 64 GiB
+
 constexpr size_t kStatusBytes = 1024;  // flag words, debug record (bytes 64..128), search counters (bytes 128..256)
 constexpr size_t kCountersOffset = 128;
 static_assert(MSBWT_SEARCH_COUNTERS == kSearchCounters, "the header's counter block is the kernels'");
@@ -164,109 +165,26 @@ int hip_fail(msbwt_rle *h, hipError_t e, const char *what) {
         if (e_ != hipSuccess) return hip_fail(h, e_, #expr);  \
     } while (0)
 
-// EXPERIMENT, off unless MSBWT_BIG_ALLOC=chunks | contiguous (round 4 found that the speed of a launch on a C4-sized index follows the PHYSICAL
-// memory its 2.6 GB of pair blocks were given): the pair blocks from whole 1 GiB physical chunks mapped into a
-// 1 GiB-aligned virtual range (hipMemCreate / hipMemMap -- the sequence tools/ubench_placement.hip runs) instead of hipMalloc, or
-// ("contiguous") from hipExtMallocWithFlags(hipDeviceMallocContiguous).  Any failure on the way falls back to hipMalloc; big_free
-// takes every kind.
-struct ChunkedRange {
-    void *base = nullptr;
-    size_t size = 0;
-    std::vector<hipMemGenericAllocationHandle_t> handles;
-};
-std::mutex g_ranges_mu;
-std::vector<ChunkedRange> g_ranges;
-
-void unmap_range(ChunkedRange *r, size_t mapped) {
-    if (r->base && mapped) (void)hipMemUnmap(r->base, mapped);
-    for (auto h : r->handles) (void)hipMemRelease(h);
-    if (r->base) (void)hipMemAddressFree(r->base, r->size);
-    (void)hipGetLastError();
-}
-
-hipError_t big_alloc(void **out, size_t bytes) {
-    const char *mode = std::getenv("MSBWT_BIG_ALLOC");
-    if (mode && std::strcmp(mode, "contiguous") == 0 && bytes >= (size_t(64) << 20)) {  // physically contiguous, by the runtime's own flag
-        if (hipExtMallocWithFlags(out, bytes, hipDeviceMallocContiguous) == hipSuccess) {
-            if (std::getenv("MSBWT_VERBOSE")) std::fprintf(stderr, "[msbwt] %zu contiguous bytes at %p\n", bytes, *out);
-            return hipSuccess;
-        }
+// random 128-byte lines per second the memory system serves from this allocation right now (0: could not be measured)
+double line_rate_of(const void *p, size_t bytes, hipStream_t stream) {
+    hipEvent_t a = nullptr, b = nullptr;
+    uint64_t lines = 0;
+    float ms = 0.f;
+    hipError_t e = hipEventCreate(&a);
+    if (e == hipSuccess) e = hipEventCreate(&b);
+    if (e == hipSuccess) e = launch_probe_lines(p, bytes, 4, nullptr, nullptr, stream);  // warm-up: page tables, clocks
+    if (e == hipSuccess) e = hipEventRecord(a, stream);
+    if (e == hipSuccess) e = launch_probe_lines(p, bytes, 48, &lines, nullptr, stream);  // 2.5 x 10^7 lines: about 0.6 ms
+    if (e == hipSuccess) e = hipEventRecord(b, stream);
+    if (e == hipSuccess) e = hipEventSynchronize(b);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    if (e != hipSuccess || ms <= 0.f) {
         (void)hipGetLastError();
-        return hipMalloc(out, bytes);
+        return 0.0;
     }
-    if (!mode || std::strcmp(mode, "chunks") != 0 || bytes < (size_t(64) << 20)) return hipMalloc(out, bytes);
-    int device = 0;
-    hipMemAllocationProp prop = {};
-    size_t gran = 0;
-    if (hipGetDevice(&device) != hipSuccess) return hipMalloc(out, bytes);
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = device;
-    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0 || ((size_t(1) << 30) % gran) != 0) {
-        (void)hipGetLastError();
-        return hipMalloc(out, bytes);
-    }
-    const size_t chunk = size_t(1) << 30;
-    ChunkedRange r;
-    r.size = (bytes + gran - 1) / gran * gran;
-    size_t mapped = 0;
-    bool ok = hipMemAddressReserve(&r.base, r.size, chunk, nullptr, 0) == hipSuccess;
-    while (ok && mapped < r.size) {
-        const size_t piece = std::min(chunk, r.size - mapped);
-        hipMemGenericAllocationHandle_t h;
-        ok = hipMemCreate(&h, piece, &prop, 0) == hipSuccess;
-        if (!ok) break;
-        r.handles.push_back(h);
-        ok = hipMemMap(static_cast<char *>(r.base) + mapped, piece, 0, h, 0) == hipSuccess;
-        if (ok) mapped += piece;
-    }
-    if (ok) {
-        hipMemAccessDesc acc = {};
-        acc.location = prop.location;
-        acc.flags = hipMemAccessFlagsProtReadWrite;
-        ok = hipMemSetAccess(r.base, r.size, &acc, 1) == hipSuccess;
-    }
-    if (!ok) {
-        unmap_range(&r, mapped);
-        return hipMalloc(out, bytes);
-    }
-    if (std::getenv("MSBWT_VERBOSE")) std::fprintf(stderr, "[msbwt] %zu bytes from %zu physical chunks at %p\n", bytes, r.handles.size(), r.base);
-    *out = r.base;
-    std::lock_guard<std::mutex> lock(g_ranges_mu);
-    g_ranges.push_back(std::move(r));
-    return hipSuccess;
-}
-
-void big_free(void *p) {
-    if (!p) return;
-    ChunkedRange r;
-    {
-        std::lock_guard<std::mutex> lock(g_ranges_mu);
-        for (size_t i = 0; i < g_ranges.size(); ++i)
-            if (g_ranges[i].base == p) {
-                r = std::move(g_ranges[i]);
-                g_ranges.erase(g_ranges.begin() + long(i));
-                break;
-            }
-    }
-    if (!r.base) {
-        (void)hipFree(p);
-        return;
-    }
-    (void)hipDeviceSynchronize();  // (hipFree waits for the device by itself; an unmap does not)
-    unmap_range(&r, r.size);
-}
-
-// Measurement aid (tools/placement_probe.py): MSBWT_PROBE_PADS="a,b,c,d" allocates -- and never frees -- a pad of that many KiB
-// right before the superblock table (a), the table's side array (b), a launch slot's ticket counters (c) and the status block
-// (d) are allocated, so that ONE small array at a time can be moved inside the runtime's 2 MiB fragments.
-void probe_pad(int which) {
-    const char *env = std::getenv("MSBWT_PROBE_PADS");
-    if (!env) return;
-    long kib[4] = {0, 0, 0, 0};
-    std::sscanf(env, "%ld,%ld,%ld,%ld", &kib[0], &kib[1], &kib[2], &kib[3]);
-    void *pad = nullptr;
-    if (kib[which] > 0 && hipMalloc(&pad, size_t(kib[which]) * 1024) != hipSuccess) (void)hipGetLastError();
+    return double(lines) / (double(ms) * 1e-3);
 }
 
 void release_sparse(msbwt_rle *h) {
@@ -292,7 +210,7 @@ void release_index(msbwt_rle *h) {
     h->d_filter = nullptr;
     h->filter_depth = 0;
     release_sparse(h);
-    if (h->d_pair_blocks) big_free(h->d_pair_blocks);
+    if (h->d_pair_blocks) (void)hipFree(h->d_pair_blocks);
     if (h->d_pair_super) (void)hipFree(h->d_pair_super);
     h->d_blocks = h->d_table = h->d_pair_blocks = h->d_pair_super = nullptr;
     h->pair_bytes = 0;
@@ -352,7 +270,6 @@ hipError_t with_slot(msbwt_rle *h, hipStream_t stream, Launch &&launch) {
     (void)hipGetLastError();  // hipErrorNotReady from a busy slot is not an error
     if (!slot) {
         msbwt_rle::TicketSlot fresh;
-        probe_pad(2);
         hipError_t e = hipMalloc(&fresh.counters, kTicketBytes);
         if (std::getenv("MSBWT_VERBOSE")) std::fprintf(stderr, "[msbwt] launch slot: ticket counters %p\n", fresh.counters);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&fresh.done, hipEventDisableTiming);
@@ -381,7 +298,6 @@ hipError_t with_tickets(msbwt_rle *h, hipStream_t stream, Launch &&launch) {
 int ensure_runtime(msbwt_rle *h) {
     if (!h->stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     if (!h->d_flags) {
-        probe_pad(3);
         HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_flags), kStatusBytes));
         if (std::getenv("MSBWT_VERBOSE")) std::fprintf(stderr, "[msbwt] status block %p\n", static_cast<void *>(h->d_flags));
         HIP_TRY(h, hipMemset(h->d_flags, 0, kStatusBytes));
@@ -505,7 +421,7 @@ int build_sparse(msbwt_rle *h, uint64_t keep_free, uint64_t allowance) {
         const uint64_t lines = nb + kSparseMaxProbe;
         if (lines > 0xFFFFFFFFull) continue;
         // a table that the tags force to be much larger than its entries need is not worth its depth (toy indexes stay small)
-        if (!explicit_depth && sparse_min_buckets(d) > std::max<uint64_t>(8 * needed, 65536)) continue;
+        if (!explicit_depth && sparse_min_buckets(d) > std::max<uint64_t>(16 * needed, 65536)) continue;
         if (lines * 128 + rep.escapes[d] * 16 + lines * sizeof(uint32_t) > avail) {
             if (explicit_depth) return fail(h, MSBWT_ERR_HIP, "the sparse table of the requested depth does not fit in HBM");
             continue;
@@ -650,7 +566,6 @@ int rebuild_table(msbwt_rle *h, bool allow_sparse = true) {
     // MSBWT_TABLE_SIDE=0) their queries search from scratch.
     void *side = nullptr;
     if (e == hipSuccess && escapes > 0 && h->wanted_table_side != 0) {
-        probe_pad(1);
         if (hipMalloc(&side, size_t(escapes) * 512) != hipSuccess) {
             (void)hipGetLastError();
             side = nullptr;
@@ -730,7 +645,7 @@ double probe_typical_width(msbwt_rle *h) {
 // built on the device from them.  Default policy: build it when it fits in half of what is
 // still free in HBM after the blocks (it is a pure speed-for-memory trade).
 int rebuild_pair_index(msbwt_rle *h) {
-    if (h->d_pair_blocks) big_free(h->d_pair_blocks);
+    if (h->d_pair_blocks) (void)hipFree(h->d_pair_blocks);
     if (h->d_pair_super) (void)hipFree(h->d_pair_super);
     h->d_pair_blocks = h->d_pair_super = nullptr;
     h->pair_bytes = 0;
@@ -762,15 +677,14 @@ int rebuild_pair_index(msbwt_rle *h) {
         if (!know_free || sz.pair_block_bytes + sz.scratch_bytes > free_b / 2) return MSBWT_OK;
     }
     void *scratch = nullptr;
-    hipError_t e = big_alloc(&h->d_pair_blocks, sz.pair_block_bytes);
-    if (e == hipSuccess) probe_pad(0);
+    hipError_t e = hipMalloc(&h->d_pair_blocks, sz.pair_block_bytes);
     if (e == hipSuccess) e = hipMalloc(&h->d_pair_super, sz.super_bytes);
     if (e == hipSuccess) e = hipMalloc(&scratch, sz.scratch_bytes);
     if (e == hipSuccess) e = build_pair_index(h->d_blocks, h->nblocks, h->totals.start_index, h->d_pair_blocks, h->d_pair_super, scratch, h->stream, stride);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (scratch) (void)hipFree(scratch);
     if (e != hipSuccess) {
-        if (h->d_pair_blocks) big_free(h->d_pair_blocks);
+        if (h->d_pair_blocks) (void)hipFree(h->d_pair_blocks);
         if (h->d_pair_super) (void)hipFree(h->d_pair_super);
         h->d_pair_blocks = h->d_pair_super = nullptr;
         h->pair_overlap_bytes = 0;
@@ -1934,7 +1848,7 @@ int msbwt_rle_set_memory_budget(msbwt_rle *h, uint64_t bytes) {
     if (h->d_table) (void)hipFree(h->d_table);
     if (h->d_table_side) (void)hipFree(h->d_table_side);
     if (h->d_filter) (void)hipFree(h->d_filter);
-    if (h->d_pair_blocks) big_free(h->d_pair_blocks);
+    if (h->d_pair_blocks) (void)hipFree(h->d_pair_blocks);
     if (h->d_pair_super) (void)hipFree(h->d_pair_super);
     h->d_table = h->d_table_side = h->d_pair_blocks = h->d_pair_super = nullptr;
     h->d_filter = nullptr;
@@ -2048,6 +1962,22 @@ size_t msbwt_rle_download_sparse_table(const msbwt_rle *ch, void *out_lines, siz
         hipMemcpy(out_side, h->d_sparse_side, h->sparse_side_bytes, hipMemcpyDeviceToHost) != hipSuccess)
         return SIZE_MAX;
     return size_t(h->sparse_bytes);
+}
+
+int msbwt_rle_probe_line_rate(const msbwt_rle *ch, int which, double *lines_per_second) {
+    msbwt_rle *h = const_cast<msbwt_rle *>(ch);
+    if (!h || !lines_per_second || which < 0 || which > 3) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!h->loaded) return fail(h, MSBWT_ERR_NOT_LOADED, "no BWT loaded");
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    const void *p = which == 0 ? h->d_blocks : which == 1 ? h->d_pair_blocks : which == 2 ? h->d_sparse : h->d_table;
+    const uint64_t bytes = which == 0 ? h->nblocks * kBlockBytes : which == 1 ? pair_index_sizes(h->nblocks, h->pair_stride).pair_block_bytes
+                           : which == 2 ? h->sparse_bytes : uint64_t(h->table_bytes);
+    *lines_per_second = 0.0;
+    if (!p || bytes < 128) return MSBWT_OK;
+    *lines_per_second = line_rate_of(p, bytes, h->stream);
+    return MSBWT_OK;
 }
 
 int msbwt_rle_set_search_counters(msbwt_rle *h, int enabled) {

@@ -389,6 +389,30 @@ __global__ __launch_bounds__(256) void k_probe_widths(const uint4 *__restrict__ 
     if (sub == 0u) out[g] = ok ? h - l : 0ull;
 }
 
+// ---- how fast does the memory system serve random 128-byte lines of THIS allocation? ---------------------------------------------
+// (msbwt_rle_probe_line_rate: a diagnostic.  Round 5 asked it whether the "two modes" of the C4-sized lines are visible to a plain
+// gather over the arrays involved -- they are not, profiles/r05_lab/two_modes.log.)  8 lanes read one line, 8 independent lines in flight per lane, `iters`
+// rounds; the lines follow a counter-based hash, the contents do not matter (nothing is written but a sink word that never is).
+__global__ __launch_bounds__(256) void k_probe_lines(const uint4 *__restrict__ base, uint64_t nlines, uint32_t iters, uint32_t *__restrict__ sink) {
+    const uint64_t tid = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, group = tid >> 3;
+    const uint32_t piece = uint32_t(tid) & 7u;
+    uint32_t acc = 0;
+    for (uint32_t it = 0; it < iters; ++it) {
+        uint4 v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            uint64_t z = (group * 0x9E3779B97F4A7C15ull) + uint64_t(it) * 8u + u;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z ^= z >> 31;
+            v[u] = base[__umul64hi(z, nlines) * 8u + piece];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    if (acc == 0x9E3779B9u && sink != nullptr) sink[0] = acc;  // (keeps the loads alive)
+}
+
 __global__ void k_table_root(uint4 *table, uint64_t total) {
     if (threadIdx.x == 0 && blockIdx.x == 0) table[0] = make_uint4(0u, 0u, uint32_t(total), uint32_t(total >> 32));
 }
@@ -595,6 +619,15 @@ hipError_t launch_probe_widths(const IndexView &ix, uint32_t nsamples, uint32_t 
     if (ix.block_format != kBlocksPlanes || nsamples == 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_probe_widths, dim3((nsamples * kGroup + 255) / 256), dim3(256), 0, stream, static_cast<const uint4 *>(ix.blocks), ix.total,
                        nsamples, steps, seed, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_probe_lines(const void *base, uint64_t bytes, uint32_t iters, uint64_t *lines_touched, uint32_t *sink, hipStream_t stream) {
+    const uint64_t nlines = bytes / 128;
+    if (!base || nlines == 0) return hipErrorInvalidValue;
+    const uint32_t blocks = 256u * 8u;  // 8 resident blocks of 256 threads per CU
+    hipLaunchKernelGGL(k_probe_lines, dim3(blocks), dim3(256), 0, stream, static_cast<const uint4 *>(base), nlines, iters, sink);
+    if (lines_touched) *lines_touched = uint64_t(blocks) * 256u / 8u * iters * 8u;
     return hipGetLastError();
 }
 

@@ -86,6 +86,7 @@ enum SearchCounter {
     kCntTableSteps,        // sparse table: bucket lines fetched (lane-steps that were lookups; included in kCntLaneSteps)
     kCntTableDisplaced,    // ... of which did not find the key in a bucket that had displaced entries (the lookup went on)
     kCntTableRides,        // ... of which rode along with the search of the tile before (no search step of their own)
+    kCntWavesWorked,       // waves of the persistent kernel that were dealt at least one tile (a workgroup that became resident late finds none)
     kSearchCounters = 16
 };
 
@@ -141,6 +142,9 @@ hipError_t launch_pack_table(const IndexView &ix, int flat_depth, const void *fl
 // pseudo-random row, searched as it is read off; 0 = the walk met '$' / 'N').  What the pair-stride policy reads
 // (table_policy.hpp).  Plane blocks only.
 hipError_t launch_probe_widths(const IndexView &ix, uint32_t nsamples, uint32_t steps, uint64_t seed, uint64_t *d_out, hipStream_t stream);
+// Random 128-byte lines of [base, base + bytes) gathered for `iters` rounds (2^19 lines per round, nothing written): timed by the
+// caller with events, lines per second say how well THIS allocation is served (msbwt_rle_probe_line_rate).  sink: 4 device bytes or nullptr.
+hipError_t launch_probe_lines(const void *base, uint64_t bytes, uint32_t iters, uint64_t *lines_touched, uint32_t *sink, hipStream_t stream);
 inline uint64_t packed_table_bytes(int depth) { return ((uint64_t(1) << (2 * depth)) + 29) / 30 * 128; }
 // filter (zero-filled, 4^filter_depth bits) from a finished table of `depth` levels
 hipError_t launch_build_filter(const void *entries, int depth, int filter_depth, uint32_t *filter, hipStream_t stream);

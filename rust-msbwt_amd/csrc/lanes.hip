@@ -598,6 +598,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
 
         // ---- C: nothing prepared: pack the next tile and ask the table for its ranges ----
         if (!prepared && next_tile < ntiles) {
+            if (counting && lane == 0u) ws.cnt[kCntWavesWorked] = 1u;
             const uint64_t tile = next_tile;
             advance_tile();
             const uint64_t q0 = tile * kTile;

@@ -81,9 +81,11 @@ inline int sparse_probe_limit(int depth, uint64_t nbuckets) {
     return int(fit - 1 < kSparseMaxProbe ? fit - 1 : kSparseMaxProbe);
 }
 
-// fewest buckets a table of this depth may have (probe limit >= 3)
+// fewest buckets a table of this depth may have: a probe limit of at least 7, so that at the builder's load practically no
+// entry is displaced beyond it (with 4 -- what 9 entries per bucket leave a chr20-sized index at depth 23 -- about one entry in
+// 10^5 found no slot and the whole table was filled a second time with more buckets: round 5's first C4 builds)
 inline uint64_t sparse_min_buckets(int depth) {
-    const int shift = 2 * depth - 32 + 2;  // W <= 2^22  <=>  ceil(2^32 / nb) <= 2^(22 - (n - 32))
+    const int shift = 2 * depth - 32 + 3;  // W <= 2^21  <=>  ceil(2^32 / nb) <= 2^(21 - (n - 32))
     if (shift >= int(kSparseTagBits)) return ~uint64_t(0);
     const uint64_t per_top = uint64_t(1) << (kSparseTagBits - shift);  // allowed ceil(2^32 / nb)
     return ((uint64_t(1) << 32) + per_top - 1) / per_top;

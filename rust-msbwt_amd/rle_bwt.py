@@ -294,7 +294,7 @@ class RleBWT(BWT):
         return {"lines": a.value, "escape_lines": b.value, "side_bytes": c.value}
 
     COUNTER_NAMES = ("wave_steps", "lane_steps", "pair_steps", "second_lines", "sat_out", "escape_queries", "escape_restarts",
-                     "table_decided", "searched", "first_lines", "table_steps", "table_displaced", "table_rides")
+                     "table_decided", "searched", "first_lines", "table_steps", "table_displaced", "table_rides", "waves_worked")
 
     # ---- sparse suffix table (include/msbwt_hip.h, msbwt_rle_set_sparse_table) ----
     def set_sparse_table(self, depth):
@@ -405,6 +405,17 @@ class RleBWT(BWT):
         if rc < 0:
             _raise(rc, self._h)
         return {0: "generic", 1: "groups", 2: "lanes"}[rc]
+
+    PROBE_ARRAYS = {"blocks": 0, "pair_blocks": 1, "sparse_table": 2, "table": 3}
+
+    def probe_line_rate(self, which):
+        """Random 128-byte lines per second served right now from one of the index's arrays ("blocks", "pair_blocks",
+        "sparse_table", "table"); 0.0 if there is no such array.  A placement diagnostic (msbwt_rle_probe_line_rate)."""
+        out = C.c_double()
+        rc = _lib.lib().msbwt_rle_probe_line_rate(self._h, self.PROBE_ARRAYS.get(which, which), C.byref(out))
+        if rc:
+            _raise(rc, self._h)
+        return float(out.value)
 
     def device_bytes(self):
         return int(_lib.lib().msbwt_rle_device_bytes(self._h))
