@@ -85,13 +85,25 @@ def cpu_model():
     return "unknown"
 
 
+def lookup_depth(bwt, k):
+    """Symbols the suffix-table lookup of a k-symbol query stands for on this index: the sparse table's depth when it serves the
+    query (k >= its depth, lanes kernel), else the direct table's (0 = none applies)."""
+    sparse = bwt.get_sparse_table()
+    if sparse and k >= sparse and bwt.search_kernel_for(k) == "lanes":
+        return sparse
+    direct = bwt.get_table_depth()
+    return direct if k >= direct else 0
+
+
 def kernel_label(bwt, k, fused):
-    """Name (as in the rocprofv3 kernel trace) of the kernel the library runs for this index and k."""
+    """Name (as in the rocprofv3 kernel trace) of the kernel the library runs for this index and k:
+    k_count_kmers_lanes<kReads, kPair, kWords, kStride96, kPacked, kSparse> (csrc/lanes.hip)."""
     which = bwt.search_kernel_for(k)
     reads, words = ("true" if fused else "false"), (3 if k <= 32 else 6)
     if which == "lanes":
         pair, s96 = bwt.get_pair_index(), bwt.get_pair_index() and bwt.get_pair_stride() == 96
-        return "k_count_kmers_lanes<%s,%s,%d,%s>" % (reads, "true" if pair else "false", words, "true" if s96 else "false")
+        sparse = bool(bwt.get_sparse_table()) and k >= bwt.get_sparse_table()
+        return "k_count_kmers_lanes<%s,%s,%d,%s,false,%s>" % (reads, "true" if pair else "false", words, "true" if s96 else "false", "true" if sparse else "false")
     return "k_count_kmers_tiled<%s,%d>" % (reads, words) if which == "groups" else "k_count_kmers_generic"
 
 
@@ -257,7 +269,7 @@ def lookup_traffic(workload, k, bwt, kind, total, fused, full_size):
     stamp = kernel_stamp()
     try:
         for ent in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["entries"]:
-            same = (ent["workload"] == workload and ent["k"] == k and ent["table_depth"] == bwt.get_table_depth()
+            same = (ent["workload"] == workload and ent["k"] == k and ent["table_depth"] == lookup_depth(bwt, k)
                     and ent.get("pair_index", False) == bwt.get_pair_index() and ent.get("pair_stride", bwt.get_pair_stride()) == bwt.get_pair_stride()
                     and ent.get("query_kind") == kind and ent.get("bwt_symbols", total) == total and full_size
                     and bool(ent.get("fused", False)) == bool(fused))
@@ -270,7 +282,7 @@ def lookup_traffic(workload, k, bwt, kind, total, fused, full_size):
     return per_query, src, note, stamp
 
 
-def live_pmc_traffic(extra_args, queries, kernel_substr="k_count_kmers"):
+def live_pmc_traffic(extra_args, queries, kernel_substr="k_count_kmers", counters=("FETCH_SIZE", "WRITE_SIZE")):
     """HBM-side bytes per query of the count kernel, measured NOW: two rocprofv3 --pmc child passes (FETCH_SIZE and
     WRITE_SIZE separately, as MI355X_MICROARCH.md prescribes; the program goes directly after `--`) over a shortened copy
     of this run -- same index (same seeds), `queries` present k-mers, one warm-up and two timed launches.  The caller
@@ -283,7 +295,7 @@ def live_pmc_traffic(extra_args, queries, kernel_substr="k_count_kmers"):
     if not os.path.exists(prof):
         return None, "rocprofv3 not found"
     means = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for counter in counters:
         out_dir = tempfile.mkdtemp(prefix="msbwt_pmc_", dir="/tmp")
         cmd = [prof, "--pmc", counter, "--kernel-include-regex", kernel_substr, "--kernel-trace", "--output-format", "csv", "-d", out_dir, "-o", "run",
                "--", sys.executable, os.path.abspath(__file__), "--no-oracle", "--no-c5", "--no-c4", "--no-live-pmc", "--no-sorted", "--queries", str(queries),
@@ -298,19 +310,22 @@ def live_pmc_traffic(extra_args, queries, kernel_substr="k_count_kmers"):
             for row in csv.DictReader(open(f)):
                 if kernel_substr in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
                     rows.append((int(row.get("Dispatch_Id", 0)), float(row["Counter_Value"])))
-        vals = [v for _, v in sorted(rows)][:3]   # the child's own measurement: one warm-up + two launches, nothing that may follow
+        vals = [v for _, v in sorted(rows)][1:3]   # the child's own two timed launches: not its warm-up dispatch, nothing that may follow
         shutil.rmtree(out_dir, ignore_errors=True)
         if done.returncode != 0 or not vals:
             return None, "%s pass: rc %d, %d counter rows; %s" % (counter, done.returncode, len(vals), done.stderr[-300:].replace("\n", " | "))
         means[counter] = (sum(vals) / len(vals), len(vals))
     # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 tallies 128-byte read requests at 64 bytes (MI355X_MICROARCH.md, HBM section)
-    fetch_b, write_b = means["FETCH_SIZE"][0] * 1024 * 2, means["WRITE_SIZE"][0] * 1024
+    fetch_b = means["FETCH_SIZE"][0] * 1024 * 2
+    # (lines measured with the read pass alone: the writes of a count launch are its counts, 8 bytes per query, and little else -- 8.3 measured)
+    write_b = means["WRITE_SIZE"][0] * 1024 if "WRITE_SIZE" in means else 8.0 * queries
     return (fetch_b + write_b) / queries, {"queries_per_launch": queries, "launches": means["FETCH_SIZE"][1],
-                                           "fetch_bytes_per_query_x2_gfx950": fetch_b / queries, "write_bytes_per_query": write_b / queries}
+                                           "fetch_bytes_per_query_x2_gfx950": fetch_b / queries, "write_bytes_per_query": write_b / queries,
+                                           "write_bytes": "measured (WRITE_SIZE pass)" if "WRITE_SIZE" in means else "taken as 8 bytes per query (the counts): no WRITE_SIZE pass for this line"}
 
 
 def roofline_block(orc, ref, queries, k, ncpu, per_launch_q, kern_s, kernel_ms, launches, traffic_per_query, traffic_src, traffic_note,
-                   stamp, label, stats_sample, table_depth=0, pair_index=True, ordered=False):
+                   stamp, label, stats_sample, table_depth=0, pair_index=True, ordered=False, sparse=False):
     """roofline object of one measured line ("Bytes"): counter traffic / kernel time / 8 TB/s, next to
     (a) layout_algorithmic -- the bytes the RUNNING layout must move for this query set: one 128-byte table line (k >= table
         depth), then one 128-byte line per search step -- a pair step for every two remaining symbols, a plane step for an odd
@@ -341,6 +356,9 @@ def roofline_block(orc, ref, queries, k, ncpu, per_launch_q, kern_s, kernel_ms, 
                 "%.2f of %d reference steps per query) + k + 8; frac_algorithmic = that / kernel time / 8 TB/s; traffic_over_algorithmic = "
                 "counter bytes / it (> 1: ranges straddling two lines, superblock words; < 1: lines served by L2 / Infinity Cache)"
                 % (table_depth, mean_steps, k)}
+    if sparse:
+        layout["note"] += ("; the table line is a bucket of the SPARSE suffix table (depth %d: the ranges of the suffixes that occur, hashed; "
+                           "about 1 %% of the lookups go on to a second bucket)" % table_depth)
     if ordered:
         layout["note"] += "; this launch includes the library's batch-ordering pass, whose streaming traffic is not part of the minimum"
     return {
@@ -375,6 +393,8 @@ def main():
 
     def emit(obj):
         os.write(result_fd, (json.dumps(obj) + "\n").encode())
+
+    import gc
 
     import numpy as np
     import torch
@@ -836,7 +856,9 @@ def main():
     kind_text = {"walk": "present (LF-walk)", "random": "random", "reads": "read-derived"}[kind]
     if exact_bwt:
         wl = ("%s: EXACT multi-string BWT of %d error-free synthetic %d-bp reads (%.0fx of a random %d-bp genome; built on the GPU from the genome's "
-              "suffix order, synth/bwt_reads.py), %d symbols; %d %s %d-mers per step"
+              "suffix order, synth/bwt_reads.py), %d symbols; %d %s %d-mers per step.  The genome is REPEAT-FREE and the reads carry no errors: what "
+              "repeat families and read errors do to this path at the largest exact size that can be built here is in `c4_repeats` (cost by copy "
+              "number: its `copy_number_bins`)"
               % (args.workload, n_reads_total, read_len, coverage, genome_len, total, nq, kind_text, k))
     elif big:
         wl = ("%s: structure-equivalent synthetic RLE stream (NOT a real BWT; 30x-human-scale stand-in), %d symbols, run lengths %s; "
@@ -863,7 +885,9 @@ def main():
         "config": {
             "workload": wl, "k": k, "queries_per_step": job_queries, "queries_per_gpu": mine_n if strong else nq,
             "bwt_symbols": total, "index_bytes": bwt.device_bytes(),
-            "table_depth": bwt.get_table_depth(), "pair_index": bwt.get_pair_index(), "pair_stride": bwt.get_pair_stride(),
+            "table_depth": lookup_depth(bwt, k), "direct_table_depth": bwt.get_table_depth(), "sparse_table_depth": bwt.get_sparse_table(),
+            "sparse_table": {kk: vv for kk, vv in bwt.sparse_table_info().items() if kk != "wide"},
+            "pair_index": bwt.get_pair_index(), "pair_stride": bwt.get_pair_stride(),
             "typical_range_width": bwt.get_typical_range_width(), "block_format": bwt.get_block_format(),
             "parallelism": ("index replicated x%d; %s; per step one %s all_gather of all counts (%s payload, widened to u64 on "
                             "arrival), overlapped with the next step's kernel"
@@ -974,8 +998,8 @@ def main():
         kern_s = kernel_ms / 1e3 if launches else elapsed / args.steps
         tq, tsrc, tnote, stamp = lookup_traffic(args.workload, k, bwt, kind, total, fused, args.scale == 1.0)
         result["roofline"] = roofline_block(orc, ref, queries, k, ncpu, per_launch_q, kern_s, kernel_ms, launches, tq, tsrc, tnote, stamp,
-                                            kernel_label(bwt, k, fused), args.stats_sample, bwt.get_table_depth(), bwt.get_pair_index(),
-                                            (not fused) and bwt.batch_order_for(k, per_launch_q))
+                                            kernel_label(bwt, k, fused), args.stats_sample, lookup_depth(bwt, k), bwt.get_pair_index(),
+                                            (not fused) and bwt.batch_order_for(k, per_launch_q), sparse=lookup_depth(bwt, k) == bwt.get_sparse_table() != 0)
         if world == 1 and not args.no_cpu_baseline:
             ncs = min(len(queries), args.cpu_sample)
             t0 = time.time()
@@ -1043,7 +1067,8 @@ def main():
                                               int(cfg4["genome"] * c4_scale),
                                               "repeat-bearing (synth.REPEAT_FAMILIES: SINE-, LINE-, LTR-, DNA-element-like families, segmental duplications, "
                                               "satellite arrays, microsatellites)" if cfg4.get("repeats") else "random", cfg4["err"] * 100, total4, n4),
-                               "k": 31, "queries_per_step": n4, "bwt_symbols": total4, "index_bytes": bwt4.device_bytes(), "table_depth": bwt4.get_table_depth(),
+                               "k": 31, "queries_per_step": n4, "bwt_symbols": total4, "index_bytes": bwt4.device_bytes(), "table_depth": lookup_depth(bwt4, 31),
+                               "direct_table_depth": bwt4.get_table_depth(), "sparse_table_depth": bwt4.get_sparse_table(), "sparse_table": bwt4.sparse_table_info(),
                                "pair_stride": bwt4.get_pair_stride(), "typical_range_width": bwt4.get_typical_range_width(), "table": bwt4.table_info()}}
             line["search_counters"] = counted_pass(bwt4, b4, 0, n4, n4)
             # the same launch with the library's own batch-ordering pass forced on (msbwt_rle_set_batch_order(1); automatic = off, on
@@ -1065,6 +1090,39 @@ def main():
                     args.steps = saved
                     del u4
                 bwt4.set_batch_order(-1)
+            # What a k-mer costs by COPY NUMBER (the repeat-bearing line only): the batch's own counts pick sub-batches of read-derived 31-mers
+            # that occur 1-99, 100-999, 1 000-9 999 and >= 10 000 times in the read set (a young-SINE or satellite 31-mer occurs tens of
+            # thousands of times here; at human scale copy numbers are another ~50 x higher), each timed and counted on its own.
+            if cfg4.get("repeats"):
+                bins = []
+                for lo_c, hi_c in ((1, 100), (100, 1000), (1000, 10_000), (10_000, 1 << 62)):
+                    ids = torch.nonzero((o4 >= lo_c) & (o4 < hi_c)).flatten()
+                    have_b = int(ids.numel())
+                    if have_b < 1000:
+                        bins.append({"count_from": lo_c, "count_below": None if hi_c > 10**9 else hi_c, "queries_in_batch": have_b})
+                        continue
+                    want_b = 10_000_000
+                    pick = ids[torch.randint(0, have_b, (want_b,), device=dev, generator=torch.Generator(device=dev).manual_seed(lo_c))] if have_b < want_b else ids[:want_b]
+                    d_qb = d_q4[pick].contiguous()
+                    bb = Batch(bwt4, d_qb, 0, None, 31)
+                    saved = args.steps
+                    args.steps = min(args.steps, 5)
+                    ob, _, elb, kmsb, _, _ = measure(bb, 0, want_b, want_b)
+                    cb = counted_pass(bwt4, bb, 0, want_b, want_b)
+                    entry = {"count_from": lo_c, "count_below": None if hi_c > 10**9 else hi_c, "queries_in_batch": have_b, "queries_timed": want_b,
+                             "value": want_b * args.steps / elb, "ms_per_step": elb / args.steps * 1e3, "kernel_ms": kmsb,
+                             "lines_per_query": cb["lines_per_query"], "second_line_rate": cb["second_line_rate"], "escape_query_fraction": cb["escape_query_fraction"],
+                             "mean_count": float(ob.float().mean().item()), "counts_equal_main_run": bool(torch.equal(ob, o4[pick]))}
+                    args.steps = saved
+                    if not entry["counts_equal_main_run"]:
+                        log("PARITY FAILURE on %s: a copy-number sub-batch counts differently from the main run" % key)
+                        result["value"] = None
+                        rc = 1
+                    bins.append(entry)
+                    del d_qb, ob, pick, ids
+                line["copy_number_bins"] = {"bins": bins, "note": "sub-batches of the line's own read-derived 31-mers by their count in the read set (10^7 queries each, "
+                                                                  "sampled with repetition where the batch holds fewer), each timed over 5 steps and counted by the kernel's own "
+                                                                  "counters; their counts are those of the main run, whose parity sample the oracle checks"}
             # Which of this line's two modes the build is in (the time of a launch on a C4-sized index follows the physical
             # memory its pair blocks were given, 15 % apart): the pair blocks (+ table) rebuilt once, the same batch timed again -- a slow
             # line can then be told from a regression by its own record.
@@ -1103,8 +1161,29 @@ def main():
                     result["value"] = None
                     rc = 1
                 tq, tsrc, tnote, stamp = lookup_traffic(name, 31, bwt4, "reads", total4, False, c4_scale == 1.0)
+                live4 = None
+                if c4_scale == 1.0 and not args.no_live_pmc:
+                    # this line's HBM-side read traffic measured NOW, like the headline's: one rocprofv3 --pmc FETCH_SIZE child pass over the same
+                    # index (its .npy is cached) and 5 x 10^7 of the same kind of queries; the GPU is handed over for it
+                    keep = (o4, d_q4)
+                    del bwt4
+                    gc.collect()
+                    torch.cuda.empty_cache()
+                    t_live = time.time()
+                    per_q4, detail4 = live_pmc_traffic(["--workload", name, "--query-kind", "reads"], 50_000_000, counters=("FETCH_SIZE",))
+                    if per_q4 is None:
+                        live4 = {"error": detail4}
+                    else:
+                        live4 = dict(detail4, bytes_per_query=per_q4, committed_bytes_per_query=tq, seconds=time.time() - t_live)
+                        tq, tsrc, tnote = per_q4, "live: rocprofv3 --pmc FETCH_SIZE, one child pass of this run (same index, %d read-derived 31-mers per launch)" % detail4["queries_per_launch"], None
+                    log("%s: live PMC traffic: %s" % (key, live4))
+                    bwt4 = msbwt.RleBWT(device=local_rank)   # (only asked for its shape below)
+                    bwt4.load_numpy_file(npy4)
                 line["roofline"] = roofline_block(orc, ref4, qs4, 31, ncpu, n4, kms4 / 1e3 if launches4 else el4 / args.steps, kms4, launches4, tq, tsrc,
-                                                  tnote, stamp, kernel_label(bwt4, 31, False), args.stats_sample, bwt4.get_table_depth(), bwt4.get_pair_index(), ordered)
+                                                  tnote, stamp, kernel_label(bwt4, 31, False), args.stats_sample, lookup_depth(bwt4, 31), bwt4.get_pair_index(), ordered,
+                                                  sparse=lookup_depth(bwt4, 31) == bwt4.get_sparse_table() != 0)
+                if live4 is not None:
+                    line["roofline"]["traffic_live"] = live4
                 if not args.no_cpu_baseline:
                     ncs4 = min(len(qs4), args.cpu_sample // 4)
                     t0 = time.time()

@@ -89,7 +89,10 @@ int msbwt_rle_constrain_ranges(const msbwt_rle *bwt, const uint8_t *syms, const 
  * msbwt_rle_device_status(), which synchronises the stream (the device entry points keep their
  * own status word: a host-pointer call on another thread never sees or clears it).
  * Alignment: d_kmers should be 16-byte aligned -- then 1 <= k <= 64 runs the fast kernels; an
- * unaligned batch is still counted correctly, by the slower generic kernel. */
+ * unaligned batch is still counted correctly, by the slower generic kernel.
+ * Streams: launches queued on ONE stream share a block of tile-ticket counters (the stream orders them); launches on different
+ * streams -- and on hipStreamPerThread, whose one handle value stands for a different queue in every host thread -- get blocks of
+ * their own, handed back when the launch that used them has completed. */
 int msbwt_rle_count_kmers_device(const msbwt_rle *bwt, const void *d_kmers, size_t k, size_t n,
                                  void *d_out_counts, void *hip_stream);
 int msbwt_rle_constrain_ranges_device(const msbwt_rle *bwt, const void *d_syms, const void *d_l,
@@ -326,6 +329,11 @@ int msbwt_auto_index_plan(uint64_t total_symbols, uint64_t free_hbm_bytes, uint6
  * 6 <= k <= 32 the lane-per-query kernel serves it too (each lane decodes its own block's runs from LDS):
  * a 30x human-scale BWT in 44 GB at 1.8 x 10^9 present 31-mers/s (bit planes + pair blocks + table:
  * 238 GB, 5.4 x 10^9).  For replicas that must leave HBM to others.  Results never change. */
+/* msbwt_run_build_fits_device (pure, no device needed): 1 when the DEVICE builder of the run-block format fits `free_hbm_bytes` of free
+ * HBM for an index of that many symbols -- it holds the plane blocks (0.5 byte per symbol) beside the run blocks (~0.3) for a moment;
+ * when it does not (or an allocation fails on the way) the load builds the run blocks on the host and uploads them, as MSBWT_BUILD=host
+ * always does: an index that fits only BECAUSE the format is lean still loads. */
+int msbwt_run_build_fits_device(uint64_t total_symbols, uint64_t free_hbm_bytes);
 int msbwt_rle_set_block_format(msbwt_rle *bwt, int format);
 int msbwt_rle_get_block_format(const msbwt_rle *bwt);
 /* Search kernel for 1 <= k <= 64: 0 = automatic (default: 2 whenever a pair index exists and k >= 6, and on run

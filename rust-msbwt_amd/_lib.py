@@ -70,6 +70,7 @@ SIGNATURES = {
     "msbwt_rle_search_counters": (_int, [_vp, _vp, _vp]),
     "msbwt_rle_set_presence_filter": (_int, [_vp, _int]),
     "msbwt_rle_get_presence_filter": (_int, [_vp]),
+    "msbwt_run_build_fits_device": (_int, [_u64, _u64]),
     "msbwt_rle_set_block_format": (_int, [_vp, _int]),
     "msbwt_rle_get_block_format": (_int, [_vp]),
     "msbwt_rle_set_search_kernel": (_int, [_vp, _int]),

@@ -259,9 +259,11 @@ hipError_t with_slot(msbwt_rle *h, hipStream_t stream, Launch &&launch) {
     // Launches queued back to back on ONE stream are ordered by the stream itself (the memset of the counters waits for the
     // previous kernel), so they share a block without asking its event: a caller that enqueues N asynchronous launches
     // gets one block, not N allocations inside its launch path.
+    // (NOT for hipStreamPerThread: that one handle value stands for a different queue in every host thread, so two threads' launches
+    // "on the same stream" may run side by side -- they go by the completion event like launches on different streams)
     msbwt_rle::TicketSlot *slot = nullptr;
     for (auto &s : h->tickets)
-        if (s.used && s.last_stream == stream) {
+        if (stream != hipStreamPerThread && s.used && s.last_stream == stream) {
             slot = &s;
             break;
         }
@@ -578,7 +580,7 @@ int rebuild_table(msbwt_rle *h, bool allow_sparse = true) {
         if (side) (void)hipFree(side);
         if (packed) (void)hipFree(packed);
         (void)hipGetLastError();
-        if (!automatic || h->planned || h->wanted_table_packed > 0) return hip_fail(h, e, "pack suffix table");
+        if (!automatic || h->wanted_table_packed > 0) return hip_fail(h, e, "pack suffix table");
         // optional structure: the handle keeps a flat table -- within the flat table's OWN budget, not the
         // deeper parent that was only meant to be packed away
         const int own = auto_flat_table_depth(h->totals.total, h->nblocks * kBlockBytes);
@@ -723,7 +725,9 @@ int build_on_host(msbwt_rle *h, const uint8_t *rle, size_t n, Totals *t_out) {
 
 // Index build on the device (default): upload the RLE bytes, expand them in HBM
 // (device_build.hip).  The expanded index (0.5 B/symbol) never exists on the host.
-int build_on_device(msbwt_rle *h, const uint8_t *rle, size_t n, Totals *t_out) {
+constexpr int kBuildOnHostInstead = 1000;  // (internal) the run-block path's planes do not fit beside its runs: nothing is left allocated
+
+int build_on_device(msbwt_rle *h, const uint8_t *rle, size_t n, Totals *t_out, bool for_run_blocks = false) {
     struct Temps {
         void *rle = nullptr, *scratch = nullptr, *longs = nullptr;
         ~Temps() {
@@ -756,7 +760,21 @@ int build_on_device(msbwt_rle *h, const uint8_t *rle, size_t n, Totals *t_out) {
         return fail(h, MSBWT_ERR_TOO_LARGE, "BWT has 2^40 symbols or more");
     const uint64_t nblocks = plane_block_count(t.total);
     const size_t bytes = size_t(nblocks) * kBlockBytes;
-    HIP_TRY(h, hipMalloc(&h->d_blocks, bytes));
+    if (for_run_blocks) {  // planes AND runs must fit (table_policy.hpp); MSBWT_RUN_BUILD_FREE=<bytes>: tests pretend that much is free
+        size_t free_b = 0, total_b = 0;
+        uint64_t free_now = (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ? uint64_t(free_b) : ~uint64_t(0);
+        if (const char *env = std::getenv("MSBWT_RUN_BUILD_FREE")) free_now = std::strtoull(env, nullptr, 10);
+        if (!run_build_fits_device(t.total, free_now)) return kBuildOnHostInstead;
+    }
+    {
+        const hipError_t e = hipMalloc(&h->d_blocks, bytes);
+        if (e == hipErrorOutOfMemory && for_run_blocks) {
+            (void)hipGetLastError();
+            h->d_blocks = nullptr;
+            return kBuildOnHostInstead;
+        }
+        if (e != hipSuccess) return hip_fail(h, e, "hipMalloc(plane blocks)");
+    }
     HIP_TRY(h, hipMemsetAsync(h->d_blocks, 0, bytes, h->stream));
     HIP_TRY(h, hipMemcpyAsync(st.d_start_index, t.start_index, sizeof t.start_index, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMalloc(&tmp.longs, device_build_long_run_bytes(nlong)));
@@ -772,9 +790,21 @@ int build_on_device(msbwt_rle *h, const uint8_t *rle, size_t n, Totals *t_out) {
 // built on the host and uploaded.
 int build_run_index(msbwt_rle *h, const uint8_t *rle, size_t n, Totals *t_out) {
     const char *mode = std::getenv("MSBWT_BUILD");
-    if (!(mode && std::strcmp(mode, "host") == 0)) {
-        int rc = build_on_device(h, rle, n, t_out);  // h->d_blocks = plane blocks
-        if (rc) return rc;
+    // The device path holds the plane blocks (0.5 byte per symbol), the RLE bytes and its scratch for a moment, and then the run
+    // blocks beside the planes: about 0.8 byte per symbol at its peak against 0.3 for the finished index.  An index whose planes do
+    // not fit beside its runs is built on the host instead (as until round 3) -- decided beforehand from the free HBM where the totals
+    // can be told (run_build_fits_device), and again on the way should an allocation fail after all.
+    bool on_device = !(mode && std::strcmp(mode, "host") == 0);
+    if (on_device) {
+        int rc = build_on_device(h, rle, n, t_out, true);  // h->d_blocks = plane blocks
+        if (rc == kBuildOnHostInstead) {
+            if (std::getenv("MSBWT_VERBOSE")) std::fprintf(stderr, "[msbwt] run blocks: the device builder's peak does not fit the free HBM -- built on the host\n");
+            on_device = false;
+        } else if (rc) {
+            return rc;
+        }
+    }
+    if (on_device) {
         void *planes = h->d_blocks;
         h->d_blocks = nullptr;
         const uint64_t nplanes = plane_block_count(t_out->total), nruns = run_block_count(t_out->total);
@@ -791,8 +821,14 @@ int build_run_index(msbwt_rle *h, const uint8_t *rle, size_t n, Totals *t_out) {
         if (e == hipSuccess) e = launch_run_block_write(planes, nplanes, t_out->total, d_cnt, h->d_blocks, h->d_overflow, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         (void)hipFree(planes);
-        if (e != hipSuccess) return hip_fail(h, e, "build run blocks on the device");
-        return MSBWT_OK;
+        if (e == hipSuccess) return MSBWT_OK;
+        if (h->d_blocks) (void)hipFree(h->d_blocks);
+        if (h->d_overflow) (void)hipFree(h->d_overflow);
+        h->d_blocks = h->d_overflow = nullptr;
+        h->overflow_bytes = 0;
+        if (e != hipErrorOutOfMemory) return hip_fail(h, e, "build run blocks on the device");
+        (void)hipGetLastError();  // no room for the run blocks beside the planes: the planes are gone now, the host builder takes over
+        if (std::getenv("MSBWT_VERBOSE")) std::fprintf(stderr, "[msbwt] run blocks: out of memory on the device path -- built on the host\n");
     }
     Totals t;
     if (!compute_totals(rle, n, &t)) return fail(h, MSBWT_ERR_INVALID_SYMBOL, "RLE stream holds a symbol code >= 6");
@@ -2021,6 +2057,8 @@ int msbwt_auto_table_depths(uint64_t total_symbols, uint64_t free_hbm_bytes, int
     *packed_depth = c.packed;
     return MSBWT_OK;
 }
+
+int msbwt_run_build_fits_device(uint64_t total_symbols, uint64_t free_hbm_bytes) { return run_build_fits_device(total_symbols, free_hbm_bytes) ? 1 : 0; }
 
 int msbwt_auto_pair_stride(uint64_t total_symbols, uint64_t free_hbm_bytes, uint64_t hbm_total_bytes, double typical_width, int *stride) {
     if (!stride) return MSBWT_ERR_INVALID_ARG;

@@ -95,6 +95,17 @@ inline uint64_t expected_table_bytes(uint64_t total, uint64_t block_bytes, uint6
     return c.packed ? flat_b + packed_table_bytes(c.packed) : flat_b;
 }
 
+// ---- run blocks: does the DEVICE builder fit?  (capi.cpp, build_run_index; pinned by a CPU test through msbwt_run_build_fits_device) ----
+// Asked once the RLE bytes are in HBM and the totals are known: the plane blocks (128 bytes per 256 symbols) and the run blocks (128
+// bytes per 512 symbols, + up to an eighth in overflow blocks) must fit the free HBM side by side, with a 32nd of it as slack.  About
+// 0.8 byte per symbol at its peak against 0.3 for the finished index -- an index that loaded in this format only BECAUSE it is lean is
+// built on the host, as until round 3.
+inline bool run_build_fits_device(uint64_t total_symbols, uint64_t free_bytes) {
+    const uint64_t planes = (total_symbols / 256 + 1) * 128, runs = (total_symbols / 512 + 1) * 128;
+    const uint64_t peak = planes + runs + runs / 8;
+    return peak <= free_bytes - free_bytes / 32;
+}
+
 // ---- a memory budget for the whole index (msbwt_rle_set_memory_budget): the analogue of the reference's only space / time
 // knob, `bin_power` (rle_bwt.rs:309-322) -------------------------------------------------------------------------------------
 // The plane blocks (0.5 byte per symbol) are always built.  What the budget leaves goes, in this order, to the pair blocks

@@ -1014,3 +1014,108 @@ def test_run_block_format_is_selectable_and_lean():
         assert b.get_pair_index() == (fmt == "planes")
         assert np.array_equal(b.count_kmers(q1), exp[0])
     assert 0.25 * total < sizes["runs"] < 0.36 * total and 0.49 * total < sizes["planes"] < 0.51 * total
+
+
+def test_run_blocks_fall_back_to_the_host_builder_when_the_device_peak_does_not_fit(monkeypatch):
+    """The device builder of the lean format holds the plane blocks beside the run blocks for a moment (0.8 byte per symbol);
+    when that does not fit the free HBM -- here: MSBWT_RUN_BUILD_FREE pretends it does not -- the load builds the run blocks on
+    the host instead of failing, and the index is the same one."""
+    import synth
+    rle, total = synth.rle_stream(20_000_000, 6.0, 9)
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    q = random_kmers(8, 30000, 21)
+    exp = o.count_kmers(q)
+    monkeypatch.setenv("MSBWT_BLOCKS", "runs")
+    sizes = []
+    for free in (None, str(int(0.6 * total))):   # all of the HBM; enough for the finished index (0.3 byte per symbol), not for its builder
+        if free is None:
+            monkeypatch.delenv("MSBWT_RUN_BUILD_FREE", raising=False)
+        else:
+            monkeypatch.setenv("MSBWT_RUN_BUILD_FREE", free)
+        b = RleBWT()
+        b.load_vector(rle)
+        assert b.get_block_format() == "runs" and b.get_total_size() == total
+        assert np.array_equal(b.count_kmers(q), exp)
+        sizes.append(b.device_bytes())
+    assert sizes[0] == sizes[1]
+    assert msbwt._lib.lib().msbwt_run_build_fits_device(total, int(0.6 * total)) == 0
+
+
+def test_two_host_threads_on_their_per_thread_streams(search_kernel):
+    """hipStreamPerThread is ONE handle value that stands for a different queue in every host thread: launches two threads make
+    'on the same stream' may run side by side, so they must not share a block of tile-ticket counters.  Two threads,
+    many launches each with more tiles than resident waves, every count against the oracle."""
+    import threading
+    import torch
+    needs_plane_blocks(search_kernel)
+    rng = np.random.default_rng(12)
+    genome = np.array([1, 2, 3, 5], dtype=np.uint8)[rng.integers(0, 4, size=30000)]
+    reads = ["".join("$ACGNT"[c] for c in genome[s:s + 60]) for s in rng.integers(0, len(genome) - 60, size=3000)]
+    rle = orc.convert_to_vec(orc.naive_bwt(reads))
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    per_thread = 2   # hipStreamPerThread
+    dev = torch.device("cuda:0")
+    failures = []
+
+    def worker(seed):
+        r = np.random.default_rng(seed)
+        win = np.array([[("$ACGNT".index(ch)) for ch in reads[i][p:p + 31]] for i, p in zip(r.integers(0, len(reads), size=4000), r.integers(0, 30, size=4000))], dtype=np.uint8)
+        q = np.ascontiguousarray(np.concatenate([win] * 60 + [random_kmers(seed, 20000, 31)]))   # 260 000 queries: 4 063 tiles > 3 072 resident waves
+        exp = o.count_kmers(q)
+        d_q = torch.from_numpy(q).to(dev)
+        for _ in range(15):
+            d_out = torch.full((len(q),), -1, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            b.count_kmers_device(d_q.data_ptr(), 31, len(q), d_out.data_ptr(), per_thread)
+            b.device_status(per_thread)
+            if not np.array_equal(d_out.cpu().numpy().astype(np.uint64), exp):
+                failures.append(seed)
+                return
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in (1, 2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not failures
+
+
+@pytest.mark.parametrize("fraction", [0.9, 0.5, 0.2])
+def test_memory_budget_on_a_loaded_index(fraction, search_kernel):
+    """msbwt_rle_set_memory_budget on a LOADED index: the optional structures are rebuilt under the budget (pair blocks, direct and
+    sparse suffix tables), the index holds no more than the budget says (as long as that is at least the plane blocks), counts
+    stay the oracle's, and budget 0 restores the default index."""
+    import synth
+    needs_plane_blocks(search_kernel)
+    genome = synth.genome(300_000, 3)
+    reads = synth.reads(genome, 60_000, 100, 4, 0.005)
+    rle = synth.rle_encode(synth.build_msbwt_symbols(reads))
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    full = b.device_bytes()
+    planes = (b.get_total_size() // 256 + 1) * 128
+    shape = (b.get_pair_index(), b.get_pair_stride(), b.get_table_depth(), b.get_sparse_table())
+    qs = [np.ascontiguousarray(np.concatenate([synth.read_kmers(reads, k, limit=20_000, seed=k), random_kmers(k, 5_000, k)])) for k in (12, 21, 31)]
+    exp = [o.count_kmers(q) for q in qs]
+    budget = max(int(full * fraction), planes + (1 << 20))
+    b.set_memory_budget(budget)
+    assert b.get_memory_budget() == budget
+    held = b.device_bytes()
+    assert held <= budget + (4 << 20), (held, budget)   # (+ the presence filter, 2 MiB at most, and the side arrays)
+    assert held < full or fraction >= 0.9
+    for q, e in zip(qs, exp):
+        assert np.array_equal(b.count_kmers(q), e)
+    twin = b.replicate(b.device_ordinal())   # a replica carries the plan
+    assert twin.device_bytes() == held
+    assert np.array_equal(twin.count_kmers_packed(msbwt.rle_bwt.pack_2bit(qs[2][np.isin(qs[2], [1, 2, 3, 5]).all(axis=1)]), 31),
+                          o.count_kmers(qs[2][np.isin(qs[2], [1, 2, 3, 5]).all(axis=1)]))
+    twin.set_batch_order(1)
+    assert np.array_equal(twin.count_kmers(qs[2]), exp[2])
+    b.set_memory_budget(0)
+    assert b.device_bytes() == full and (b.get_pair_index(), b.get_pair_stride(), b.get_table_depth(), b.get_sparse_table()) == shape
+    for q, e in zip(qs, exp):
+        assert np.array_equal(b.count_kmers(q), e)

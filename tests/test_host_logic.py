@@ -423,3 +423,51 @@ def test_tools_and_run_scripts_are_well_formed():
     assert shells
     for path in shells:
         assert subprocess.run(["bash", "-n", path], capture_output=True).returncode == 0, path
+
+
+def test_sparse_table_hash_and_shape_are_pure_functions():
+    """csrc/sparse_table.hpp through msbwt_sparse_hash / msbwt_sparse_table_shape (no device): the mix is a bijection of 2 d-bit words --
+    so bucket + tag identify a key among the keys one lookup can meet --, the buckets are contiguous windows of the mixed key, and the
+    shape the builder picks leaves every lookup a probe limit of 7 buckets or more with tags unambiguous."""
+    L = _lib.lib()
+    rng = np.random.default_rng(1)
+    for depth in (16, 19, 23, 24):
+        n = 2 * depth
+        for entries in (0, 1000, 3 * 10 ** 7, 3 * 10 ** 9):
+            nb, probe = C.c_uint64(), C.c_int()
+            assert L.msbwt_sparse_table_shape(depth, entries, C.byref(nb), C.byref(probe)) == 0
+            assert nb.value >= entries / 9.0 and 7 <= probe.value <= 15 and nb.value + probe.value < 2 ** 32
+            window = (-(-2 ** 32 // nb.value)) << (n - 32)        # widest range of mixed keys one bucket takes
+            assert (probe.value + 1) * window <= 2 ** 24            # ... so that the 24-bit tags of one probe sequence never collide
+        # the mix loses nothing: with (nearly) 2^32 buckets the bucket is the mixed key's top 32 bits and the tag its low 24 -- together
+        # every bit of a key of at most 48 bits -- so distinct keys must give distinct pairs
+        keys = np.unique(rng.integers(0, 2 ** n, size=5000, dtype=np.uint64))
+        b, t = C.c_uint32(), C.c_uint32()
+        mixes = set()
+        for key in keys.tolist():
+            assert L.msbwt_sparse_hash(key, depth, 2 ** 32 - 1, C.byref(b), C.byref(t)) == 0
+            assert t.value < 2 ** 24
+            mixes.add((b.value, t.value))
+        assert len(mixes) >= len(keys) - 1   # (the scaling by 2^32 - 1 folds the two lowest top values together)
+        # and it spreads structured keys: consecutive keys (one symbol apart in the first position searched) over 1000 buckets
+        hits = np.zeros(1000, dtype=np.int64)
+        for key in range(20000):
+            L.msbwt_sparse_hash(key, depth, 1000, C.byref(b), C.byref(t))
+            hits[b.value] += 1
+        assert hits.max() <= 60 and hits.min() >= 2, (hits.min(), hits.max())
+    assert L.msbwt_sparse_hash(0, 15, 10, C.byref(b), C.byref(t)) == _lib.ERR_INVALID_ARG
+    nb, probe = C.c_uint64(), C.c_int()
+    assert L.msbwt_sparse_table_shape(25, 10, C.byref(nb), C.byref(probe)) == _lib.ERR_INVALID_ARG
+
+
+def test_run_block_device_build_decision():
+    """csrc/table_policy.hpp, run_build_fits_device, through msbwt_run_build_fits_device (no device): the device builder of the lean
+    format needs the plane blocks beside the run blocks for a moment -- 0.5 + 0.25 (+ an eighth of that in overflow blocks) bytes per
+    symbol, a 32nd of the free HBM as slack; an index that does not fit that is built on the host (and still loads)."""
+    fits = _lib.lib().msbwt_run_build_fits_device
+    human = 90_000_000_000
+    assert fits(human, 288 * 2 ** 30) == 1           # 45 + 25.3 GB
+    assert fits(human, 80 * 10 ** 9) == 1
+    assert fits(human, 60 * 10 ** 9) == 0            # the finished 28 GB index fits, its builder's peak does not: host build
+    assert fits(4 * human, 288 * 2 ** 30) == 1 and fits(5 * human, 288 * 2 ** 30) == 0
+    assert fits(0, 1 << 20) == 1 and fits(1000, 100) == 0
