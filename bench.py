@@ -53,7 +53,7 @@ HUMAN_SYMBOLS = 9e10
 # builders, and the policies that pick table depth and pair spacing
 # (order.hip -- the library's batch-ordering passes -- is not among them: they are off unless forced, and no default line runs them)
 KERNEL_SOURCES = ["kernels.hip", "lanes.hip", "search_common.hpp", "rank_ops.hpp", "kernels.hpp", "plane_index.hpp",
-                  "pair_index.hip", "device_build.hip", "table_policy.hpp"]
+                  "pair_index.hip", "device_build.hip", "table_policy.hpp", "sparse_table.hpp", "sparse_table.hip"]
 NARROW_MAX = 32767
 
 

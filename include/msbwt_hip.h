@@ -186,21 +186,21 @@ int msbwt_rle_allgather_counts(const msbwt_rle *bwt, void *comm, const void *d_m
 
 /* ---- batch order (no reference counterpart) ----
  * The order in which a batch is handed over does not change a single count, but it changes how fast they come: a batch whose
- * k-mers are ordered by (their last 17 symbols as a string, then the symbols before those going leftwards) reads the suffix
- * table in ascending order and keeps neighbouring queries on neighbouring index lines through the search -- measured 2.0x on
- * dense batches (10^8 read-derived 31-mers over a 2 x 10^9-symbol BWT), +15 % on 3 x 10^8 31-mers over a 9 x 10^10-symbol one.
- * The library does not reorder batches itself (sorting costs about what it saves on sparse batches); these calls hand out the
- * 64-bit key to sort by (ascending), for callers that hold a sorted k-mer list anyway or count a batch more than once.
+ * k-mers are ordered by (their last 17 symbols as a string, then the symbols before those going leftwards) keeps neighbouring
+ * queries on neighbouring index lines through the search -- measured up to 2.0x on dense batches over the DIRECT suffix table
+ * (10^8 read-derived 31-mers over a 2 x 10^9-symbol BWT, rounds 3-4).  msbwt_kmer_order_keys hands out the 64-bit key to sort by
+ * (ascending), for callers that hold a sorted k-mer list anyway or count a batch more than once.
  * kmers: n x k symbol codes; a '$' / 'N' / invalid symbol among the (at most 31) symbols the key reads gives UINT64_MAX. */
 int msbwt_kmer_order_keys(const uint8_t *kmers, size_t k, size_t n, uint64_t *out_keys);
-/* Since round 4 the library CAN order a batch itself, inside the launch: the queries are packed to two bits per symbol,
+/* The library can also order a batch itself, inside the launch (round 4): the queries are packed to two bits per symbol,
  * bucket-ordered on the device by the top 22 key bits (MSBWT_ORDER_BITS) in two passes, counted in index order, and every count
- * is returned to its query's own place in the caller's buffer -- the caller sees its order.  mode 1 = whenever the passes apply
- * (pair index, 12 <= k <= 64, 4096 <= n < 2^32); 0 = never; -1 = automatic (default), which today means never: measured on one box,
- * pass off / on, the densest batches gain a few per cent (10^8 read-derived 31-mers over a 2 x 10^9-symbol BWT 16.8 -> 16.1 ms, C3
- * 3.13 -> 2.97) while sparse or random batches lose much more (human scale 55.7 -> 79.9 ms, random 31-mers 3.4 -> 9.3 ms): ordering
- * 10^8 queries and un-ordering their counts costs about 6 ms of the 8 ms the ordered search saves.  A caller that
- * holds its batch sorted anyway still gets the 2x (the keys above).  MSBWT_ORDER=0|1|auto in the environment sets the initial mode.
+ * is returned to its query's own place in the caller's buffer -- the caller sees its order.  It is a SWITCH, off unless asked for:
+ * mode 1 = whenever the passes apply (pair index, 12 <= k <= 64, 4096 <= n < 2^32); 0 = never; -1 = the default, which is never
+ * too (kept as a value so that callers written against round 4 keep working).  There is no automatic mode: ordering 10^8 queries
+ * and un-ordering their counts costs about 6 ms of the 8 ms the ordered search saved on the densest batches of round 4, sparse or
+ * random batches lost 30 % to 2.7x -- and since round 5 the default index looks its queries up in a HASHED sparse suffix table,
+ * whose lookups an order cannot help: the same dense batches now LOSE 8-14 % with the pass forced on (BENCH_r05: c4_repeats 7.35 ->
+ * 6.32, c4_real_reads 7.60 -> 6.99 x 10^9 q/s).  MSBWT_ORDER=0|1 in the environment sets the initial mode.
  * Applies to msbwt_rle_count_kmers[_device] and the packed forms.  msbwt_rle_batch_order_for: 1 if a batch of n k-symbol queries
  * would be ordered now.  Results never change. */
 int msbwt_rle_set_batch_order(msbwt_rle *bwt, int mode);
@@ -326,7 +326,7 @@ int msbwt_auto_index_plan(uint64_t total_symbols, uint64_t free_hbm_bytes, uint6
  * reference's run_block_av_flat (src/run_block_av_flat.rs:43-56,97-125): 128-byte blocks of 512 positions
  * with per-block counts and 96 one-byte runs, ~0.3 byte per symbol on 30x short-read BWTs, single-symbol
  * steps only (no pair index).  Built on the device from the RLE bytes like the default format; for
- * 6 <= k <= 32 the lane-per-query kernel serves it too (each lane decodes its own block's runs from LDS):
+ * 6 <= k <= 64 the lane-per-query kernel serves it too (each lane decodes its own block's runs from LDS):
  * a 30x human-scale BWT in 44 GB at 1.8 x 10^9 present 31-mers/s (bit planes + pair blocks + table:
  * 238 GB, 5.4 x 10^9).  For replicas that must leave HBM to others.  Results never change. */
 /* msbwt_run_build_fits_device (pure, no device needed): 1 when the DEVICE builder of the run-block format fits `free_hbm_bytes` of free
@@ -337,7 +337,7 @@ int msbwt_run_build_fits_device(uint64_t total_symbols, uint64_t free_hbm_bytes)
 int msbwt_rle_set_block_format(msbwt_rle *bwt, int format);
 int msbwt_rle_get_block_format(const msbwt_rle *bwt);
 /* Search kernel for 1 <= k <= 64: 0 = automatic (default: 2 whenever a pair index exists and k >= 6, and on run
- * blocks for 6 <= k <= 32), 1 = 8 lanes per query, lines in registers (kernels.hip; one symbol per step; needs no pair index),
+ * blocks for k >= 6), 1 = 8 lanes per query, lines in registers (kernels.hip; one symbol per step; needs no pair index),
  * 2 = one query per lane, lines staged through LDS by LDS-DMA (lanes.hip; two symbols per step,
  * 8x more random lines in flight per wave).  MSBWT_SEARCH=groups|lanes in the environment
  * sets the initial mode.  Results never change. */

@@ -462,9 +462,9 @@ __global__ __launch_bounds__(256) void k_constrain_ranges(const uint4 *__restric
 inline bool long_search(const IndexView &ix, uint32_t k) { return ix.pair_blocks != nullptr && k >= 6u; }
 
 inline bool use_lanes_kernel(const IndexView &ix, uint32_t k) {
-    // run blocks (round 4): the lanes kernel decodes them lane by lane for 6 <= k <= 32 (single-symbol steps; the k <= 64
-    // instantiation has no registers to spare for it); everything else of that format stays with this file's kernel
-    if (ix.block_format != kBlocksPlanes) return ix.search_kernel != kSearchGroups && k >= 6u && k <= uint32_t(kMaxShortK);
+    // run blocks (round 4; k > 32 since round 5): the lanes kernel decodes them lane by lane for 6 <= k <= 64 (single-symbol steps);
+    // shorter k-mers of that format stay with this file's kernel
+    if (ix.block_format != kBlocksPlanes) return ix.search_kernel != kSearchGroups && k >= 6u && k <= uint32_t(kMaxTiledK);
     return ix.search_kernel == kSearchLanes || (ix.search_kernel == kSearchAuto && long_search(ix, k));
 }
 

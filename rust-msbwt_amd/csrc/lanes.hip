@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     using Scratch = LaneScratchT<kWords, kPacked>;
     // run blocks (run_index.hpp; launch-uniform): `blocks` are 128-byte lines of 512 positions with 96 one-byte runs, decoded
     // by the lane that owns the query; single-symbol steps only (the kPair instantiations never see them)
-    const bool runs = !kPair && !kPacked && kWords == 3 && format != 0u;  // (k <= 32 only: the long instantiation has no registers to spare)
+    const bool runs = !kPair && !kPacked && format != 0u;  // (round 5: k <= 64 -- the long instantiation fits the decode after all: 163 / 168 VGPRs, no spill)
     using RingItem = RingItemT<kWords, kPacked>;
     constexpr int kPieces = Scratch::kMaxK / 16;  // 16-byte pieces of a tile per lane: 2 or 4
     constexpr int kRegions = Scratch::kRegions, kLineSlots = Scratch::kLineSlots;
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
         const uint32_t r_l = uint32_t(l - start_l), r_h = uint32_t(h - (same ? start_l : (pair ? pair_block_start(bh, s96) : bh << 8)));
         uint64_t line_l = base + bl * 128u, line_h = base + bh * 128u;
         bool one_line = same;
-        if (!kPair && !kPacked && kWords == 3 && runs) {  // a bound's line: its run block, or -- found out in the iteration before -- its overflow plane block
+        if (!kPair && !kPacked && runs) {  // a bound's line: its run block, or -- found out in the iteration before -- its overflow plane block
             line_l = ovf_l != 0u ? reinterpret_cast<uint64_t>(run_overflow) + uint64_t(ovf_l - 1u) * 128u : reinterpret_cast<uint64_t>(blocks) + (l >> 9) * 128u;
             line_h = ovf_h != 0u ? reinterpret_cast<uint64_t>(run_overflow) + uint64_t(ovf_h - 1u) * 128u : reinterpret_cast<uint64_t>(blocks) + (h >> 9) * 128u;
             one_line = line_l == line_h;
@@ -868,7 +868,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 nh = pair_line_bound(L, far != 0u ? super_far : super_l, r_h);
                 consume_symbols<kWords>(w, 6);
                 rem -= 2u;
-            } else if (!kPair && !kPacked && kWords == 3 && runs) {
+            } else if (!kPair && !kPacked && runs) {
                 uint32_t need_l = 0, need_h = 0;
                 PlaneLine L;
                 nl = nh = 0;
