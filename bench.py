@@ -847,6 +847,48 @@ def main():
                       "kernel_ms": n_kms, "payload": "uint16" if n_narrow else "uint64", "equals_torch_path": same,
                       "note": "msbwt_rle_allgather_counts (ncclAllGather bound at run time inside libmsbwt_hip.so), in stream order "
                               "after the kernel -- no overlap with the next step"}
+            # What a caller with ONE batch sees (the timed steps above hide each gather behind the next step's kernel): kernel + gather +
+            # widening one after the other, against the library's pipelined form -- the shard counted in 4 pieces while the finished
+            # pieces' counts travel on a second stream (msbwt_rle_count_kmers_allgather_device) -- and that with the counts left narrow
+            # at the destination.  Best of 3, max over the ranks; the main batch's fused-reads form has no shard pointer: matrix only.
+            if hi - lo == cap and cap > 0 and main_batch.q is not None:
+                try:
+                    wire = 16 if n_narrow else 64
+                    qptr = main_batch.q.data_ptr() + (lo - main_batch.row0) * k
+                    d_m = torch.zeros(cap, dtype=torch.int64, device=dev)
+                    d_a = torch.empty(cap * world, dtype=torch.int64, device=dev)
+                    d_n = torch.empty(cap * world, dtype=torch.int16 if n_narrow else torch.int64, device=dev)
+
+                    def latency(fn):
+                        fn()
+                        best = None
+                        for _ in range(3):
+                            fence()
+                            t0 = time.perf_counter()
+                            fn()
+                            fence()
+                            dt1 = time.perf_counter() - t0
+                            best = dt1 if best is None else min(best, dt1)
+                        t = torch.tensor([best], dtype=torch.float64, device=dev)
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                        return t.item() * 1e3
+
+                    def serial():
+                        bwt.count_kmers_device(qptr, k, cap, d_m.data_ptr(), stream)
+                        bwt.allgather_counts(comm, d_m.data_ptr(), cap, d_a.data_ptr(), wire, stream)
+
+                    native["single_batch_latency_ms"] = latency(serial)
+                    native["single_batch_pipelined_ms"] = latency(lambda: bwt.count_kmers_allgather_device(comm, qptr, k, cap, d_m.data_ptr(), d_a.data_ptr(), wire, 64, 4, stream))
+                    native["single_batch_pipelined_equals_torch_path"] = bool(torch.equal(d_a, d_all))
+                    native["single_batch_pipelined_narrow_destination_ms"] = latency(lambda: bwt.count_kmers_allgather_device(comm, qptr, k, cap, d_m.data_ptr(), d_n.data_ptr(), wire, wire, 4, stream))
+                    native["single_batch_narrow_destination_equals_torch_path"] = bool(torch.equal(d_n.to(torch.int64), d_all))
+                    bwt.device_status(stream)
+                    native["single_batch_note"] = ("one batch, not a stream of them: kernel, all-gather and widening in stream order (single_batch_latency_ms) against the "
+                                                   "shard counted in 4 pieces while the finished pieces' counts travel on a second stream "
+                                                   "(msbwt_rle_count_kmers_allgather_device), and the same with the counts left %d bits wide at the destination" % wire)
+                    del d_m, d_a, d_n
+                except Exception as e:  # noqa: BLE001
+                    native["single_batch_error"] = repr(e)
             comm.close()
             del n_out, n_all
         except Exception as e:  # noqa: BLE001

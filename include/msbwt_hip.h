@@ -184,6 +184,19 @@ int msbwt_comm_destroy(void *comm);
 int msbwt_rle_allgather_counts(const msbwt_rle *bwt, void *comm, const void *d_mine, size_t n_mine, void *d_all, int wire_bits,
                                void *hip_stream);
 
+/* ONE batch counted and gathered as a pipeline.  A caller that counts its shard with msbwt_rle_count_kmers_device and then calls
+ * msbwt_rle_allgather_counts sees kernel + gather + widening one after the other (a steady stream of batches hides the gather behind the
+ * next batch's kernel; a single batch cannot).  This call cuts the rank's shard of n_mine queries into `pieces` (1..64; pieces of whole
+ * 16-query units) and searches piece i on hip_stream while the counts of piece i - 1 travel -- narrowed to wire_bits, ncclAllGather,
+ * put at their place -- on a second stream of the handle; hip_stream continues when the last piece has arrived.
+ * d_kmers: n_mine x k symbol codes (this rank's shard); d_mine_counts: n_mine u64 (this rank's counts, also an output);
+ * d_all[r * n_mine + i] = rank r's count i as out_bits-wide unsigned integers: 64, or the wire width ("narrow at destination": no
+ * widening pass and an array a quarter or half the size -- 8 GB less to write for the 10^9-query line of BASELINE configs[4]).
+ * Every rank passes the same n_mine, wire_bits, out_bits and pieces.  A count that does not fit the wire width makes
+ * msbwt_rle_device_status return MSBWT_ERR_OVERFLOW.  Calls on one handle must be ordered by the caller (they share scratch). */
+int msbwt_rle_count_kmers_allgather_device(const msbwt_rle *bwt, void *comm, const void *d_kmers, size_t k, size_t n_mine, void *d_mine_counts,
+                                           void *d_all, int wire_bits, int out_bits, int pieces, void *hip_stream);
+
 /* ---- batch order (no reference counterpart) ----
  * The order in which a batch is handed over does not change a single count, but it changes how fast they come: a batch whose
  * k-mers are ordered by (their last 17 symbols as a string, then the symbols before those going leftwards) keeps neighbouring

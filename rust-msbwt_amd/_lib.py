@@ -43,6 +43,7 @@ SIGNATURES = {
     "msbwt_comm_init_rank": (_int, [C.POINTER(C.c_void_p), _int, _vp, _int]),
     "msbwt_comm_destroy": (_int, [_vp]),
     "msbwt_rle_allgather_counts": (_int, [_vp, _vp, _vp, _sz, _vp, _int, _vp]),
+    "msbwt_rle_count_kmers_allgather_device": (_int, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _int, _int, _int, _vp]),
     "msbwt_kmers_pack_2bit": (_int, [_vp, _sz, _sz, _vp]),
     "msbwt_rle_count_kmers_packed": (_int, [_vp, _vp, _sz, _sz, _vp, _int]),
     "msbwt_rle_count_kmers_packed_device": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),

@@ -102,6 +102,8 @@ struct msbwt_rle {
     // read-back; one launch and one stream synchronisation per call.
     void *d_gather = nullptr;      // scratch of msbwt_rle_allgather_counts (narrow wire widths)
     size_t gather_bytes = 0;
+    hipStream_t gather_stream = nullptr;  // msbwt_rle_count_kmers_allgather_device: the all-gathers of a batch's pieces run here, beside the search
+    std::vector<hipEvent_t> piece_events;
     uint8_t *mail = nullptr;       // host address
     uint8_t *d_mail = nullptr;     // the same buffer as the device sees it
     uint64_t mail_seq = 0;         // completion word of the mailbox: the kernel of call i writes i
@@ -1115,6 +1117,8 @@ void msbwt_rle_free(msbwt_rle *h) {
         h->pipe.release();
         if (h->mail) (void)hipHostFree(h->mail);
         if (h->d_gather) (void)hipFree(h->d_gather);
+        for (hipEvent_t e : h->piece_events) (void)hipEventDestroy(e);
+        if (h->gather_stream) (void)hipStreamDestroy(h->gather_stream);
         if (h->d_stage) (void)hipFree(h->d_stage);
         if (h->d_flags) (void)hipFree(h->d_flags);
         if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1792,6 +1796,63 @@ int msbwt_rle_allgather_counts(const msbwt_rle *ch, void *comm, const void *d_mi
                                           h->d_gather, h->d_flags + kDeviceFlags, static_cast<hipStream_t>(hip_stream), &why);
     if (e == hipSuccess) return MSBWT_OK;
     return why.empty() ? hip_fail(h, e, "all-gather of the counts") : fail(h, MSBWT_ERR_RCCL, why);
+}
+
+// One batch counted and gathered as a PIPELINE (a caller with a single batch otherwise sees kernel + gather + widening one after the other):
+// the rank's shard is cut into pieces; piece i is searched on the caller's stream while the counts of piece i - 1 travel -- narrowed,
+// ncclAllGather, placed -- on a second stream of the handle.
+int msbwt_rle_count_kmers_allgather_device(const msbwt_rle *ch, void *comm, const void *d_kmers, size_t k, size_t n_mine, void *d_mine_counts, void *d_all,
+                                           int wire_bits, int out_bits, int pieces, void *hip_stream) {
+    msbwt_rle *h = const_cast<msbwt_rle *>(ch);
+    if (!h) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!h->loaded) return fail(h, MSBWT_ERR_NOT_LOADED, "no BWT loaded");
+    if (!comm || (wire_bits != 64 && wire_bits != 32 && wire_bits != 16) || (out_bits != 64 && out_bits != wire_bits) || pieces < 1 || pieces > 64 || k < 1 ||
+        (n_mine && (!d_kmers || !d_mine_counts || !d_all)))
+        return fail(h, MSBWT_ERR_INVALID_ARG, "count_kmers_allgather needs a communicator, buffers, a wire width of 64 / 32 / 16 bits, counts left at that width or widened to 64, 1..64 pieces");
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    int rc = ensure_runtime(h);
+    if (rc) return rc;
+    if (n_mine == 0) return MSBWT_OK;
+    std::string why;
+    const int nranks = comm_ranks(comm, &why);
+    if (nranks < 1) return fail(h, MSBWT_ERR_RCCL, why);
+    if (!h->gather_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->gather_stream, hipStreamNonBlocking));
+    while (h->piece_events.size() < size_t(pieces) + 1) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->piece_events.push_back(e);
+    }
+    const size_t need = allgather_pieces_scratch_bytes(n_mine, nranks, wire_bits);
+    if (need > h->gather_bytes) {  // (hipFree waits for the device: no gather still reads the old buffer)
+        if (h->d_gather) (void)hipFree(h->d_gather);
+        h->d_gather = nullptr;
+        h->gather_bytes = 0;
+        HIP_TRY(h, hipMalloc(&h->d_gather, need));
+        h->gather_bytes = need;
+    }
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    // pieces of whole 16-query units (rows of any k then start 16-byte aligned: the fast kernels), the last one takes what is left
+    const size_t unit = 16, per = std::max<size_t>(unit, (n_mine / size_t(pieces) + unit - 1) / unit * unit);
+    // the gather stream starts behind everything the caller has queued so far (its buffers may still be in use there)
+    HIP_TRY(h, hipEventRecord(h->piece_events[size_t(pieces)], stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->gather_stream, h->piece_events[size_t(pieces)], 0));
+    size_t piece = 0;
+    for (size_t off = 0; off < n_mine; off += per, ++piece) {
+        const size_t len = std::min(per, n_mine - off);
+        rc = launch_count(h, static_cast<const uint8_t *>(d_kmers) + off * k, k, len, static_cast<uint64_t *>(d_mine_counts) + off, stream, kDeviceFlags);
+        if (rc) return rc;
+        HIP_TRY(h, hipEventRecord(h->piece_events[piece], stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->gather_stream, h->piece_events[piece], 0));
+        const hipError_t e = allgather_piece(comm, nranks, static_cast<const uint64_t *>(d_mine_counts), n_mine, off, len, d_all, wire_bits, out_bits, h->d_gather,
+                                             h->d_flags + kDeviceFlags, h->gather_stream, &why);
+        if (e != hipSuccess) return why.empty() ? hip_fail(h, e, "all-gather of a piece of the counts") : fail(h, MSBWT_ERR_RCCL, why);
+    }
+    // the caller's stream continues once the last piece has arrived
+    HIP_TRY(h, hipEventRecord(h->piece_events[size_t(pieces)], h->gather_stream));
+    HIP_TRY(h, hipStreamWaitEvent(stream, h->piece_events[size_t(pieces)], 0));
+    return MSBWT_OK;
 }
 
 // ---- batch order keys (order.hip): sort a batch by them and it walks the index in ascending order -----------------------

@@ -89,6 +89,16 @@ __global__ __launch_bounds__(256) void k_widen_counts(const Narrow *__restrict__
     for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = uint64_t(in[i]);
 }
 
+// A gathered PIECE goes to its place: in[r * len + j] (rank r's counts of the piece) -> out[r * n_mine + off + j], widened to Out
+template <class In, class Out>
+__global__ __launch_bounds__(256) void k_place_piece(const In *__restrict__ in, Out *__restrict__ out, uint64_t len, uint64_t n_mine, uint64_t off, uint32_t nranks) {
+    const uint64_t stride = uint64_t(gridDim.x) * blockDim.x, n = len * nranks;
+    for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t r = i / len, j = i - r * len;
+        out[r * n_mine + off + j] = Out(in[i]);
+    }
+}
+
 uint32_t copy_grid(uint64_t n) { return uint32_t(std::min<uint64_t>(256 * 8, std::max<uint64_t>(1, (n + 255) / 256))); }
 
 }  // namespace
@@ -170,6 +180,40 @@ hipError_t allgather_counts(void *comm, int nranks, const uint64_t *d_mine, size
         return hipGetLastError();
     }
     return hipSuccess;
+}
+
+// One piece [off, off + len) of this rank's n_mine counts: narrowed to the wire width, all-gathered, and every rank's part of the piece
+// put at its place in d_all (out_bits wide: 64, or the wire width -- "narrow at destination", no widening pass).  d_scratch as sized by
+// allgather_pieces_scratch_bytes: [n_mine narrow | n_mine x nranks narrow]; pieces use disjoint parts of it, so several may be in flight.
+hipError_t allgather_piece(void *comm, int nranks, const uint64_t *d_mine, size_t n_mine, size_t off, size_t len, void *d_all, int wire_bits, int out_bits,
+                           void *d_scratch, uint32_t *flags, hipStream_t stream, std::string *why) {
+    const Rccl &r = rccl();
+    if (!r.lib) { *why = r.why; return hipErrorNotSupported; }
+    if (len == 0) return hipSuccess;
+    const size_t wb = size_t(wire_bits) / 8;
+    uint8_t *s = static_cast<uint8_t *>(d_scratch);
+    uint8_t *send = s + off * wb, *recv = s + (n_mine * wb + 255) / 256 * 256 + off * wb * size_t(nranks);
+    const dim3 g(copy_grid(len)), b(256);
+    if (wire_bits == 16) hipLaunchKernelGGL(k_narrow_counts<uint16_t>, g, b, 0, stream, d_mine + off, reinterpret_cast<uint16_t *>(send), len, flags);
+    else if (wire_bits == 32) hipLaunchKernelGGL(k_narrow_counts<uint32_t>, g, b, 0, stream, d_mine + off, reinterpret_cast<uint32_t *>(send), len, flags);
+    else hipLaunchKernelGGL(k_narrow_counts<uint64_t>, g, b, 0, stream, d_mine + off, reinterpret_cast<uint64_t *>(send), len, flags);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return he;
+    const ncclResult_t e = r.all_gather(send, recv, len * wb, ncclUint8, static_cast<ncclComm_t>(comm), stream);
+    if (e != ncclSuccess) { *why = describe(e); return hipErrorUnknown; }
+    const dim3 ga(copy_grid(len * size_t(nranks)));
+    const uint32_t nr = uint32_t(nranks);
+    if (wire_bits == 16 && out_bits == 64) hipLaunchKernelGGL((k_place_piece<uint16_t, uint64_t>), ga, b, 0, stream, reinterpret_cast<const uint16_t *>(recv), static_cast<uint64_t *>(d_all), len, n_mine, off, nr);
+    else if (wire_bits == 16) hipLaunchKernelGGL((k_place_piece<uint16_t, uint16_t>), ga, b, 0, stream, reinterpret_cast<const uint16_t *>(recv), static_cast<uint16_t *>(d_all), len, n_mine, off, nr);
+    else if (wire_bits == 32 && out_bits == 64) hipLaunchKernelGGL((k_place_piece<uint32_t, uint64_t>), ga, b, 0, stream, reinterpret_cast<const uint32_t *>(recv), static_cast<uint64_t *>(d_all), len, n_mine, off, nr);
+    else if (wire_bits == 32) hipLaunchKernelGGL((k_place_piece<uint32_t, uint32_t>), ga, b, 0, stream, reinterpret_cast<const uint32_t *>(recv), static_cast<uint32_t *>(d_all), len, n_mine, off, nr);
+    else hipLaunchKernelGGL((k_place_piece<uint64_t, uint64_t>), ga, b, 0, stream, reinterpret_cast<const uint64_t *>(recv), static_cast<uint64_t *>(d_all), len, n_mine, off, nr);
+    return hipGetLastError();
+}
+
+size_t allgather_pieces_scratch_bytes(size_t n_mine, int nranks, int wire_bits) {
+    const size_t wb = size_t(wire_bits) / 8;
+    return (n_mine * wb + 255) / 256 * 256 + n_mine * wb * size_t(nranks);
 }
 
 size_t allgather_scratch_bytes(size_t n_mine, int nranks, int wire_bits) {

@@ -22,6 +22,11 @@ int comm_ranks(void *comm, std::string *why);  // -1 on error
 hipError_t allgather_counts(void *comm, int nranks, const uint64_t *d_mine, size_t n_mine, uint64_t *d_all, int wire_bits, void *d_scratch,
                             uint32_t *flags, hipStream_t stream, std::string *why);
 size_t allgather_scratch_bytes(size_t n_mine, int nranks, int wire_bits);
+// The same for ONE piece [off, off + len) of the rank's counts (msbwt_rle_count_kmers_allgather_device: a batch counted and gathered as a
+// pipeline): narrowed, all-gathered, every rank's part put at d_all[r * n_mine + off + j] as out_bits-wide integers (64, or the wire width).
+hipError_t allgather_piece(void *comm, int nranks, const uint64_t *d_mine, size_t n_mine, size_t off, size_t len, void *d_all, int wire_bits, int out_bits,
+                           void *d_scratch, uint32_t *flags, hipStream_t stream, std::string *why);
+size_t allgather_pieces_scratch_bytes(size_t n_mine, int nranks, int wire_bits);
 // d_out[i] = d_in[i] as u32; a count that does not fit sets kFlagNarrowOverflow in *flags (the 32-bit count outputs of the
 // packed host entry point)
 hipError_t launch_narrow_counts32(const uint64_t *d_in, uint32_t *d_out, uint64_t n, uint32_t *flags, hipStream_t stream);

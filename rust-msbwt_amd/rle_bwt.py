@@ -241,6 +241,13 @@ class RleBWT(BWT):
         if rc:
             _raise(rc, self._h)
 
+    def count_kmers_allgather_device(self, comm, d_kmers, k, n_mine, d_mine_counts, d_all, wire_bits=16, out_bits=64, pieces=4, stream=0):
+        """msbwt_rle_count_kmers_allgather_device: this rank's shard counted piece by piece on `stream` while the finished pieces' counts
+        are all-gathered on a second stream; d_all[r * n_mine + i] as out_bits-wide integers (64 or the wire width)."""
+        rc = _lib.lib().msbwt_rle_count_kmers_allgather_device(self._h, comm._c, d_kmers, k, n_mine, d_mine_counts, d_all, wire_bits, out_bits, pieces, stream)
+        if rc:
+            _raise(rc, self._h)
+
     # ---- several GPUs of one node ---------------------------------------------------------
     def replicate(self, device):
         """A new RleBWT on `device` holding a GPU -> GPU copy of this index (no rebuild, no upload)."""

@@ -99,6 +99,47 @@ class ShardedCounter:
             pieces.append(gathered[r * cap:r * cap + (b - a)])
         return torch.cat(pieces)
 
+    def count_kmers_pipelined(self, kmers, pieces=4, wire="int32"):
+        """The same result as count_kmers, as a PIPELINE for a caller with one batch: this rank's shard is counted in `pieces`
+        pieces, and the all_gather of piece i (asynchronous) runs while piece i + 1 is counted.  The wire type is fixed beforehand
+        (it cannot wait for the largest count): "int16" / "int32" / "int64"; should a count not fit it, the batch is counted again
+        the plain way -- the result is always exact.  (The library's own form over RCCL: msbwt_rle_count_kmers_allgather_device.)"""
+        torch, dist = self.torch, self.dist
+        n = kmers.shape[0]
+        lo, hi = shard_bounds(n, self.world, self.rank)
+        if self.world == 1:
+            return self._count_local(kmers[lo:hi].contiguous())
+        cap = shard_capacity(n, self.world)
+        wire_t = {"int16": torch.int16, "int32": torch.int32, "int64": torch.int64}[wire]
+        limit = torch.iinfo(wire_t).max
+        per = max(SHARD_ALIGN, -(-cap // pieces // SHARD_ALIGN) * SHARD_ALIGN)   # the same cut on every rank: whole 16-query units
+        works, parts, fits = [], [], True
+        for off in range(0, cap, per):
+            length = min(per, cap - off)
+            a, b = min(hi, lo + off), min(hi, lo + off + length)
+            send = torch.zeros(length, dtype=wire_t, device=kmers.device)
+            if b > a:
+                mine = self._count_local(kmers[a:b].contiguous())
+                fits = fits and bool(((mine >= 0) & (mine <= limit)).all())
+                send[:b - a] = mine.to(wire_t)
+            recv = torch.empty(length * self.world, dtype=wire_t, device=kmers.device)
+            works.append(dist.all_gather_into_tensor(recv.view(torch.uint8), send.view(torch.uint8), group=self.group, async_op=True))
+            parts.append((off, length, recv))
+        for w in works:
+            w.wait()
+        ok = torch.tensor([1 if fits else 0], dtype=torch.int32, device=kmers.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok[0]) == 0:
+            return self.count_kmers(kmers)
+        out = torch.empty(n, dtype=torch.int64, device=kmers.device)
+        for r in range(self.world):
+            a, b = shard_bounds(n, self.world, r)
+            for off, length, recv in parts:
+                take = max(0, min(length, (b - a) - off))
+                if take:
+                    out[a + off:a + off + take] = recv[r * length:r * length + take].to(torch.int64)
+        return out
+
 
 def as_u64(t):
     """int64 tensor holding u64 bit patterns -> numpy uint64."""

@@ -730,6 +730,38 @@ def test_native_allgather_of_counts_over_rccl_one_rank(search_kernel):
     comm.close()
 
 
+def test_pipelined_count_and_allgather_over_rccl_one_rank(search_kernel):
+    """msbwt_rle_count_kmers_allgather_device on REAL RCCL (one-rank communicator): a batch counted piece by piece while the finished
+    pieces' counts are gathered on a second stream -- every piece count, every wire width, counts left narrow at the destination or
+    widened, ragged last pieces; all equal to the oracle."""
+    if search_kernel != "auto":
+        pytest.skip("the gather does not depend on the search kernel")
+    torch = pytest.importorskip("torch")
+    reads, rle = _real_bwt(43, 300, 80)
+    o = orc.OracleRleBWT()
+    o.load_vector(rle)
+    b = gpu_bwt(rle)
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    k = 25
+    comm = msbwt.RankComm(1, msbwt.RankComm.unique_id(), 0)
+    for n in (1, 17, 1000, 70_001):
+        qs = np.ascontiguousarray(np.concatenate([np.array([orc.convert_stoi(r[3:3 + k]) for r in reads], dtype=np.uint8), random_kmers(n, n, k)])[:n])
+        exp = o.count_kmers(qs)
+        d_q = torch.from_numpy(qs).to(dev)
+        for pieces in (1, 3, 4, 64):
+            for wire, out_bits in ((64, 64), (32, 64), (16, 64), (32, 32), (16, 16)):
+                d_mine = torch.full((n,), -1, dtype=torch.int64, device=dev)
+                d_all = torch.full((n,), -1, dtype={64: torch.int64, 32: torch.int32, 16: torch.int16}[out_bits], device=dev)
+                b.count_kmers_allgather_device(comm, d_q.data_ptr(), k, n, d_mine.data_ptr(), d_all.data_ptr(), wire, out_bits, pieces, stream)
+                b.device_status(stream)
+                assert np.array_equal(d_mine.cpu().numpy().astype(np.uint64), exp), (n, pieces, wire)
+                assert np.array_equal(d_all.cpu().numpy().astype(np.int64).astype(np.uint64), exp), (n, pieces, wire, out_bits)
+    with pytest.raises(msbwt.MsbwtError):
+        b.count_kmers_allgather_device(comm, d_q.data_ptr(), k, n, d_mine.data_ptr(), d_all.data_ptr(), 32, 16, 4, stream)   # widths must agree or be 64
+    comm.close()
+
+
 def test_batch_order_keys_and_ordered_batches(search_kernel):
     """msbwt_kmer_order_keys / _device: same keys on host and device; a batch sorted by them gives the same counts (permuted)."""
     if search_kernel != "auto":

@@ -53,6 +53,10 @@ def _worker(rank, world, port, n, k, ret):
         got = counter.count_kmers(torch.from_numpy(q))
         exp = ref.count_kmers(q)
         ok = np.array_equal(msbwt.sharded.as_u64(got), exp)
+        # the pipelined form (pieces counted while earlier pieces travel): same counts for every cut and wire type
+        for pieces in (1, 3, 4, 7):
+            for wire in ("int16", "int32", "int64"):
+                ok = ok and np.array_equal(msbwt.sharded.as_u64(counter.count_kmers_pipelined(torch.from_numpy(q), pieces=pieces, wire=wire)), exp)
         # a strided input (column slice of a wider matrix, a transposed matrix): the worker must see a dense copy
         wide = torch.from_numpy(np.concatenate([q, q[:, ::-1]], axis=1))
 
@@ -76,6 +80,8 @@ def _worker(rank, world, port, n, k, ret):
             c2 = ShardedCounter(count_local=fake_worker)
             out = c2.count_kmers(torch.from_numpy(big[sel]))
             ok = ok and out.tolist() == want
+            # (a count beyond the pipelined form's fixed wire type: counted again the plain way, still exact)
+            ok = ok and c2.count_kmers_pipelined(torch.from_numpy(big[sel]), pieces=2, wire="int16").tolist() == want
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
