@@ -147,3 +147,9 @@ def test_bench_rccl_calls_on_one_rank(payload):
     assert r["n_gpus"] == 1 and r["scaling"] == "strong" and r["parity"]["mismatches"] == 0 and r["value"] > 0
     assert "RCCL" in r["config"]["parallelism"] and ("int16" if payload == "auto" else "int64") in r["config"]["parallelism"]
     assert r["weak_scaling"]["value"] > 0
+    # the library's own RCCL call site, and what a caller with ONE batch sees: serial against the pipelined form (pieces counted while
+    # earlier pieces travel), counts widened or left narrow at the destination -- all equal to the torch path's vector
+    ng = r["native_gather"]
+    assert "error" not in ng and ng["equals_torch_path"], ng
+    assert "single_batch_error" not in ng and ng["single_batch_latency_ms"] > 0 and ng["single_batch_pipelined_ms"] > 0, ng
+    assert ng["single_batch_pipelined_equals_torch_path"] is True and ng["single_batch_narrow_destination_equals_torch_path"] is True, ng
