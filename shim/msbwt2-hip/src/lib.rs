@@ -53,8 +53,8 @@ extern "C" {
     fn msbwt_comm_destroy(comm: *mut c_void) -> c_int;
     fn msbwt_rle_allgather_counts(bwt: *const MsbwtRle, comm: *mut c_void, d_mine: *const c_void, n_mine: usize,
                                   d_all: *mut c_void, wire_bits: c_int, hip_stream: *mut c_void) -> c_int;
-    // batch order: sort a batch by these keys (ascending) and it walks the index in order (up to 2x faster on dense batches);
-    // since round 4 the library orders dense batches itself (-1 = automatic, 0 = never, 1 = whenever the pass applies)
+    // batch order: sort a batch by these keys (ascending) and it walks the index in order; the library's own ordering pass is a
+    // switch (1 = whenever the pass applies; 0 and -1, the default, = never: there is no automatic mode)
     fn msbwt_kmer_order_keys(kmers: *const u8, k: usize, n: usize, out_keys: *mut u64) -> c_int;
     fn msbwt_rle_set_batch_order(bwt: *mut MsbwtRle, mode: c_int) -> c_int;
     // compact queries: two bits per symbol -- 8 bytes per 31-mer over PCIe instead of 31, 32-bit counts on the way back
@@ -63,6 +63,14 @@ extern "C" {
                                     out_counts: *mut c_void, count_bits: c_int) -> c_int;
     // HBM the index may hold (0 = no budget): the space / time knob, as bin_power is the reference's
     fn msbwt_rle_set_memory_budget(bwt: *mut MsbwtRle, bytes: u64) -> c_int;
+    // sparse suffix table (round 5): ranges of the suffixes that occur, depth 16..24 (-1 = automatic, 0 = off); info = 64 u64 words
+    fn msbwt_rle_set_sparse_table(bwt: *mut MsbwtRle, depth: c_int) -> c_int;
+    fn msbwt_rle_get_sparse_table(bwt: *const MsbwtRle) -> c_int;
+    fn msbwt_rle_sparse_table_info(bwt: *const MsbwtRle, out: *mut u64) -> c_int;
+    // one batch counted and gathered as a pipeline (pieces searched while earlier pieces' counts travel over RCCL)
+    fn msbwt_rle_count_kmers_allgather_device(bwt: *const MsbwtRle, comm: *mut c_void, d_kmers: *const c_void, k: usize, n_mine: usize,
+                                              d_mine_counts: *mut c_void, d_all: *mut c_void, wire_bits: c_int, out_bits: c_int,
+                                              pieces: c_int, hip_stream: *mut c_void) -> c_int;
 }
 
 /// Same role as `RleBWT` (src/rle_bwt.rs:14-24); the index lives in HBM.
@@ -156,7 +164,7 @@ impl GpuRleBWT {
         out
     }
 
-    /// -1 = the library orders dense batches itself (default), 0 = never, 1 = whenever the pass applies.
+    /// 1 = the library orders a batch itself whenever the pass applies; 0 and -1 (the default) = never (include/msbwt_hip.h).
     pub fn set_batch_order(&mut self, mode: i32) {
         let rc = unsafe { msbwt_rle_set_batch_order(self.raw, mode) };
         if rc != MSBWT_OK { panic!("set_batch_order: {}", self.last_error()); }
@@ -166,6 +174,20 @@ impl GpuRleBWT {
     pub fn set_memory_budget(&mut self, bytes: u64) {
         let rc = unsafe { msbwt_rle_set_memory_budget(self.raw, bytes) };
         if rc != MSBWT_OK { panic!("set_memory_budget: {}", self.last_error()); }
+    }
+
+    /// Sparse suffix table: -1 = automatic (default), 0 = off, 16..=24 = exactly that depth.  Results never change.
+    pub fn set_sparse_table(&mut self, depth: i32) {
+        let rc = unsafe { msbwt_rle_set_sparse_table(self.raw, depth) };
+        if rc != MSBWT_OK { panic!("set_sparse_table: {}", self.last_error()); }
+    }
+
+    /// Depth of the sparse suffix table in HBM (0 = none) and how many distinct suffixes of that length occur.
+    pub fn sparse_table(&self) -> (i32, u64) {
+        let mut info = [0u64; 64];
+        let rc = unsafe { msbwt_rle_sparse_table_info(self.raw, info.as_mut_ptr()) };
+        if rc != MSBWT_OK { panic!("sparse_table_info: {}", self.last_error()); }
+        (unsafe { msbwt_rle_get_sparse_table(self.raw) }, info[1])
     }
 }
 
@@ -250,6 +272,16 @@ impl GpuRleBWT {
                                    wire_bits: i32, hip_stream: *mut c_void) {
         let rc = msbwt_rle_allgather_counts(self.raw, comm.raw, d_mine, n_mine, d_all, wire_bits as c_int, hip_stream);
         if rc != MSBWT_OK { panic!("allgather_counts: {}", self.last_error()); }
+    }
+
+    /// ONE batch counted and gathered as a pipeline: this rank's shard (`n_mine` k-mers of `k` symbol codes at `d_kmers`) is searched
+    /// in `pieces` pieces while the counts of the finished pieces travel over RCCL on a second stream; `d_all[r * n_mine + i]` holds
+    /// rank r's count i as `out_bits`-wide integers (64, or `wire_bits`: left as they arrived).
+    pub unsafe fn count_kmers_allgather(&self, comm: &RankComm, d_kmers: *const c_void, k: usize, n_mine: usize, d_mine_counts: *mut c_void,
+                                        d_all: *mut c_void, wire_bits: i32, out_bits: i32, pieces: i32, hip_stream: *mut c_void) {
+        let rc = msbwt_rle_count_kmers_allgather_device(self.raw, comm.raw, d_kmers, k, n_mine, d_mine_counts, d_all, wire_bits as c_int,
+                                                        out_bits as c_int, pieces as c_int, hip_stream);
+        if rc != MSBWT_OK { panic!("count_kmers_allgather: {}", self.last_error()); }
     }
 }
 
