@@ -396,7 +396,9 @@ int build_sparse(msbwt_rle *h, uint64_t keep_free, uint64_t allowance) {
                 if (p) (void)hipFree(p);
         }
     } tmp;
-    const size_t work_bytes = sparse_work_bytes(free_b);
+    // (never more scratch than the index can fill: the nodes of a level are disjoint non-empty ranges, at most `total` of them -- a toy
+    // index must not pay for a 6 GB allocation per build)
+    const size_t work_bytes = std::min<size_t>(sparse_work_bytes(free_b), 4096 + 2 * 24 * size_t(std::max<uint64_t>(h->totals.total + 1024, 4096)));
     auto optional = [&](hipError_t e, const char *what) -> int {  // an optional structure gives way; an explicit wish does not
         (void)hipGetLastError();
         if (explicit_depth) return hip_fail(h, e, what);
@@ -416,7 +418,8 @@ int build_sparse(msbwt_rle *h, uint64_t keep_free, uint64_t allowance) {
     }
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return MSBWT_OK;
     const uint64_t spare = keep_free + total_b / 8;  // an eighth of the HBM stays free for the caller's batches
-    const uint64_t avail = std::min<uint64_t>(allowance, uint64_t(free_b) > spare ? uint64_t(free_b) - spare : 0);
+    // (an explicit depth wins over a memory budget, like the other explicit settings: only the HBM itself limits it)
+    const uint64_t avail = std::min<uint64_t>(explicit_depth ? kNoBudget : allowance, uint64_t(free_b) > spare ? uint64_t(free_b) - spare : 0);
     int chosen = 0;
     uint64_t nbuckets = 0;
     for (int d = max_depth; d >= kSparseMinDepth && d > flat_depth; --d) {

@@ -61,11 +61,12 @@ def main():
             b.set_search_kernel(str(rng.choice(["auto", "groups", "lanes", "lanes"])))
             b.set_table_side(int(rng.integers(0, 2)))              # round 4: escape lines from the side array, or restarted
             b.set_batch_order(int(rng.choice([-1, 0, 1, 1])))      # ... the library's own ordering pass forced on half the time
+            b.set_sparse_table(int(rng.choice([-1, -1, 0, 16, 17, 18, 19, 20, 23])))   # round 5: sparse suffix table: automatic, off, or a depth
             if rng.random() < 0.15:                                # ... and a memory budget now and then (rebuilds the optional structures)
                 b.set_memory_budget(int(b.device_bytes() * float(rng.choice([0.2, 0.5, 0.9]))) + 1)
             elif b.get_memory_budget():
                 b.set_memory_budget(0)
-            k = int(rng.integers(1, 72))
+            k = int(rng.integers(1, 72)) if rng.random() < 0.6 else int(rng.integers(16, 40))   # (often at and above the sparse table's depths)
             # mostly small batches, sometimes many tiles per wave (ring refill, setup running ahead)
             n = int(rng.integers(1, 700)) if rng.random() < 0.8 else int(rng.integers(5000, 60000))
             qs = [random_kmers(int(rng.integers(0, 1 << 30)), n, k),
