@@ -172,8 +172,11 @@ class RleBWT final : public BWT {
     void set_search_kernel(int mode) { check(msbwt_rle_set_search_kernel(raw_, mode)); }
     /// HBM the loaded index may hold (0 = no budget): the space / time knob, as bin_power is the reference's (rle_bwt.rs:309-322)
     void set_memory_budget(std::uint64_t bytes) { check(msbwt_rle_set_memory_budget(raw_, bytes)); }
-    /// -1 = automatic (today: never), 0 = never, 1 = the library orders every batch it can before counting it
+    /// 1 = the library orders every batch it can before counting it; 0 and -1 (the default) = never: a switch, there is no automatic mode
     void set_batch_order(int mode) { check(msbwt_rle_set_batch_order(raw_, mode)); }
+    /// sparse suffix table (the suffixes that occur, one hashed 128-byte bucket per lookup): -1 = automatic (default), 0 = off, 16..24 = that depth
+    void set_sparse_table(int depth) { check(msbwt_rle_set_sparse_table(raw_, depth)); }
+    int get_sparse_table() const { return msbwt_rle_get_sparse_table(raw_); }
     void set_table_side(int mode) { check(msbwt_rle_set_table_side(raw_, mode)); }
     std::uint64_t device_bytes() const { return msbwt_rle_device_bytes(raw_); }
     int search_kernel_for(size_t k) const { return msbwt_rle_search_kernel_for(raw_, k); }

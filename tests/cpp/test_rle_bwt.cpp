@@ -135,6 +135,10 @@ static void error_behaviour(const std::string &dir) {
     CHECK(three.count_kmers(acgt, 3) == packed && three.device_bytes() > 0);
     three.set_memory_budget(0);
     three.set_batch_order(-1);
+    // round 5: a sparse suffix table of the smallest depth (every string here is shorter: nothing occurs) changes nothing either
+    three.set_sparse_table(16);
+    CHECK(three.get_sparse_table() == 16 && three.count_kmers(acgt, 3) == packed && three.count_kmer(convert_stoi("ACGACGACG")) == 1);
+    three.set_sparse_table(-1);
     const auto both = three.count_read_kmers("CCGTACGTAGGTACAGTA", 9, 3);
     CHECK(both.first.size() == 14 && both.first[2] == three.count_kmer(convert_stoi("GTA")));
     CHECK(both.second[0] == three.count_kmer(reverse_complement_i(convert_stoi("CCG"))));
