@@ -239,7 +239,9 @@ int msbwt_rle_get_table_depth(const msbwt_rle *bwt);
  * parent table is then built as deep as that packed table needs, up to 15 levels, and freed;
  * MSBWT_TABLE_PACKED=0/1 overrides).
  * msbwt_rle_get_table_depth reports the effective depth (flat depth + 2).  Lines whose deltas do not
- * fit 16 bits are marked and their queries search from scratch.  Results never change. */
+ * fit 16 bits are marked ESCAPE and keep their ranges in a side array (msbwt_rle_set_table_side, below).  Results never change.
+ * Beside a sparse suffix table (msbwt_rle_set_sparse_table, the default since round 5) the automatic direct table stays at packed
+ * depth 15 at most: only queries shorter than the sparse table's depth still read it. */
 int msbwt_rle_set_table_packed(msbwt_rle *bwt, int mode);
 /* Escape lines of the packed table -- lines holding a range 2^16 or more wide, or further than that from the line's
  * first range: the suffixes of high-copy repeats (Alu-, L1-like families, satellites) -- keep their 30 ranges as flat
@@ -325,7 +327,12 @@ int msbwt_auto_pair_stride(uint64_t total_symbols, uint64_t free_hbm_bytes, uint
  * always built; what the budget leaves goes, in this order, to the pair blocks (whenever they fit), to the
  * deepest packed suffix table that fits, and to overlapping pair blocks when the data keep ranges wide -- one plan, made
  * at load time (or at once, if an index is loaded: the optional structures are rebuilt).  Explicit settings
- * (msbwt_rle_set_table_depth, _set_pair_index, _set_pair_stride) still win over the plan.
+ * (msbwt_rle_set_table_depth, _set_pair_index, _set_pair_stride, an explicit _set_sparse_table depth) still win over the plan.
+ * The sparse suffix table takes what the budget leaves once blocks, pair blocks and a direct table of packed depth 15 are paid for
+ * (the deepest depth that fits; none if nothing does -- the direct table is then as deep as the plan says).  Not counted against
+ * the budget: the presence filter (2 MiB at most) and the side arrays of the tables (bytes per high-copy suffix).  A budget below
+ * the plane blocks cannot be met -- they are built all the same -- and run blocks have no optional structure to plan: both are
+ * said by msbwt_rle_last_error after the call, which still returns MSBWT_OK.
  * msbwt_auto_index_plan: the plan as a pure function (no device needed) for an index of `total_symbols` symbols with
  * `free_hbm_bytes` free once its plane blocks are in place; *index_bytes (optional) = what the planned index holds
  * (presence filter, at most 2 MiB, and the table's side array not counted). */

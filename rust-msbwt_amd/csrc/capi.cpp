@@ -1959,8 +1959,14 @@ int msbwt_rle_set_memory_budget(msbwt_rle *h, uint64_t bytes) {
     h->table_side_bytes = h->table_lines = h->table_escape_lines = 0;
     h->pair_bytes = h->pair_overlap_bytes = 0;
     make_plan(h);
-    const int rc = rebuild_pair_index(h);
-    return rc ? rc : rebuild_table(h);
+    int rc = rebuild_pair_index(h);
+    if (!rc) rc = rebuild_table(h);
+    if (rc) return rc;
+    // a budget that cannot be met is said, not silently exceeded (the call still succeeds: the index works)
+    h->err.clear();
+    if (bytes != 0 && h->block_format != kBlocksPlanes) h->err = "memory budget: the run-block format has no optional structures to plan; the budget is not applied";
+    else if (bytes != 0 && bytes < h->nblocks * kBlockBytes) h->err = "memory budget: below the plane blocks themselves, which are built all the same";
+    return MSBWT_OK;
 }
 
 uint64_t msbwt_rle_get_memory_budget(const msbwt_rle *h) { return h ? h->memory_budget : 0; }
