@@ -158,75 +158,103 @@ __device__ __forceinline__ uint64_t plane_line_bound(const PlaneLine &L, uint32_
     return ((uint64_t(hi) << 32) | lo) + cnt;
 }
 
-// ---- rank of one bound from a staged RUN-block line (run_index.hpp: header + 96 one-byte runs for 512 positions) ----------
-// The lane decodes its own line: per dword of four runs, the lengths (x >> 3 & 31 per byte), a byte mask of the runs whose
-// symbol is s, and two sums of absolute differences -- all four lengths, and the matching ones.  A dword that ends at or
-// before the position adds its matching lengths whole; the ONE dword that straddles the position is kept and finished run
-// by run afterwards.  An OVERFLOW block (more than 96 pieces) holds no runs: *need receives the 1-based number of the plane
-// block, in the side array, that holds the position (the caller fetches that line in its next iteration).
-// Measured at human scale on one box (tools/build_variant.sh, 10^8 present 31-mers): one decode per bound 1.79 x 10^9 q/s
-// (chunk loop unrolled by three: 1.77), ONE decode for both bounds of a range inside one block 1.59-1.60 whatever the
-// unrolling -- fully unrolled it spills, and the lane-varying "both" costs more than the second decode saves.
-#ifndef MSBWT_RUNS_FUSED  // 1 = one decode for both bounds of a range inside one block, 0 = one per bound
-#define MSBWT_RUNS_FUSED 0
-#endif
-#ifndef MSBWT_RUNS_UNROLL  // 16-byte chunks of runs per loop iteration (6 = all at once)
-#define MSBWT_RUNS_UNROLL 6
-#endif
-// Both bounds of a range at once when they lie in ONE run block (`both`; most ranges do: 512 positions per block): lengths,
-// match masks and sums are computed once per dword, only the comparisons with the two positions are done twice.
-__device__ __forceinline__ void run_line_bounds(const uint4 *lines, uint32_t slot, uint32_t s, uint64_t pos_l, uint64_t pos_h, bool both,
-                                                uint64_t &out_l, uint64_t &out_h, uint32_t &need_l, uint32_t &need_h) {
+// ---- ranks from a staged RUN-block line (run_index.hpp: header + 96 one-byte runs for 512 positions) ----------------------------
+// The lane decodes its own line.  FIRST bound (run_line_first): per dword of four runs, the lengths (x >> 3 & 31 per byte), a byte
+// mask of the runs whose symbol is s, and two sums of absolute differences -- all four lengths, and the matching ones; a dword that
+// ends at or before the position adds its matching lengths whole, the first dword that reaches beyond it is kept and finished run
+// by run afterwards.  It also notes where it stood (RunCont: that dword, its first position, the matches before it).
+// SECOND bound (run_line_continue, round 5): a range is narrow, so h lies a dword or two behind l -- its rank CONTINUES from where l's
+// decode stood (same run block: 94 % of the steps) or, in another block, starts at that block's first dword; either way a short
+// lane-varying loop over the few dwords up to h instead of a second decode of all 24 (round 4 decoded twice: 1.82e9 q/s at human
+// scale; one decode for both bounds inside one block had been tried and lost to the lane-varying select, 1.59e9).
+// An OVERFLOW block (more than 96 pieces) holds no runs: *need receives the 1-based number of the plane block, in the side array,
+// that holds the position (the caller fetches that line in its next iteration).
+struct RunCont {
+    uint32_t dword, at, acc;  // first dword (0..23; 24: none) that reaches beyond the first bound, its first position, matches before it
+};
+
+__device__ __forceinline__ void run_dword(uint32_t x, uint32_t sx, uint32_t &all, uint32_t &mine) {
+    const uint32_t lens = (x >> 3) & 0x1F1F1F1Fu, t = (x & 0x07070707u) ^ sx;
+    const uint32_t other = ((t + 0x7F7F7F7Fu) | t) & 0x80808080u;        // bit 7 of a byte: its run's symbol is NOT s
+    const uint32_t match = ((other ^ 0x80808080u) >> 7) * 0xFFu;          // 0xFF in the bytes of the runs of s
+    all = __builtin_amdgcn_sad_u8(lens, 0u, 0u);
+    mine = __builtin_amdgcn_sad_u8(lens & match, 0u, 0u);
+}
+
+// matches among the positions [at, r) of the four runs of dword x that starts at position `at`
+__device__ __forceinline__ uint32_t run_dword_clip(uint32_t x, uint32_t s, uint32_t at, uint32_t r) {
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const uint32_t run = (x >> (8 * b)) & 0xFFu, len = run >> 3;
+        cnt += (run & 7u) == s ? uint32_t(min(max(int(r) - int(at), 0), int(len))) : 0u;
+        at += len;
+    }
+    return cnt;
+}
+
+__device__ __forceinline__ void run_line_first(const uint4 *lines, uint32_t slot, uint32_t s, uint64_t pos, uint64_t &out, uint32_t &need, RunCont &cont) {
     const uint32_t base = line_base(slot), g = slot & 7u;
     const uint4 c0 = lines[base + (0u ^ g)], c1 = lines[base + (1u ^ g)];
+    cont = RunCont{24u, 0u, 0u};
     if ((c1.w & 0x80000000u) != 0u) {
-        const uint32_t first = lines[base + (2u ^ g)].x * 2u + 1u;
-        need_l = first + ((uint32_t(pos_l) & 511u) >> 8);
-        if (both) need_h = first + ((uint32_t(pos_h) & 511u) >> 8);
+        need = lines[base + (2u ^ g)].x * 2u + 1u + ((uint32_t(pos) & 511u) >> 8);
         return;
     }
     const uint32_t lo = s == 0u ? c0.x : s == 1u ? c0.y : s == 2u ? c0.z : s == 3u ? c0.w : s == 4u ? c1.x : c1.y;
     const uint32_t hi = (((s >> 2) ? c1.w : c1.z) >> ((s & 3u) * 8u)) & 0xFFu;
-    const uint32_t r0 = uint32_t(pos_l) & 511u, r1 = uint32_t(pos_h) & 511u, sx = s * 0x01010101u;
-    uint32_t cnt0 = 0, cnt1 = 0, cur = 0, str0 = 0, at0 = 0, str1 = 0, at1 = 0;
-#pragma unroll MSBWT_RUNS_UNROLL  // (fully unrolled, the six 16-byte LDS reads are all hoisted to the top: with both bounds in one pass the kernel spills)
+    const uint32_t r0 = uint32_t(pos) & 511u, sx = s * 0x01010101u;
+    uint32_t cnt = 0, cur = 0, str = 0;
+#pragma unroll
     for (uint32_t j = 2; j < 8; ++j) {
         const uint4 c = lines[base + (j ^ g)];
         const uint32_t word[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t x = word[i], lens = (x >> 3) & 0x1F1F1F1Fu, t = (x & 0x07070707u) ^ sx;
-            const uint32_t other = ((t + 0x7F7F7F7Fu) | t) & 0x80808080u;        // bit 7 of a byte: its run's symbol is NOT s
-            const uint32_t match = ((other ^ 0x80808080u) >> 7) * 0xFFu;          // 0xFF in the bytes of the runs of s
-            const uint32_t all = __builtin_amdgcn_sad_u8(lens, 0u, 0u), mine = __builtin_amdgcn_sad_u8(lens & match, 0u, 0u);
+        for (uint32_t i = 0; i < 4; ++i) {
+            uint32_t all, mine;
+            run_dword(word[i], sx, all, mine);
             const uint32_t end = cur + all;
-            cnt0 += end <= r0 ? mine : 0u;
-            const bool across0 = cur < r0 && end > r0;
-            str0 = across0 ? x : str0;
-            at0 = across0 ? cur : at0;
-            if (both) {
-                cnt1 += end <= r1 ? mine : 0u;
-                const bool across1 = cur < r1 && end > r1;
-                str1 = across1 ? x : str1;
-                at1 = across1 ? cur : at1;
-            }
+            cnt += end <= r0 ? mine : 0u;
+            const bool here = end > r0 && cont.dword == 24u;  // the first dword that reaches beyond the position
+            str = here ? word[i] : str;
+            cont.at = here ? cur : cont.at;
+            cont.dword = here ? 4u * (j - 2u) + i : cont.dword;
             cur = end;
         }
     }
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {  // (a straddler of 0 when no dword straddles the position: four empty runs)
-        const uint32_t run0 = (str0 >> (8 * b)) & 0xFFu, len0 = run0 >> 3;
-        cnt0 += (run0 & 7u) == s ? uint32_t(min(max(int(r0) - int(at0), 0), int(len0))) : 0u;
-        at0 += len0;
-        if (both) {
-            const uint32_t run1 = (str1 >> (8 * b)) & 0xFFu, len1 = run1 >> 3;
-            cnt1 += (run1 & 7u) == s ? uint32_t(min(max(int(r1) - int(at1), 0), int(len1))) : 0u;
-            at1 += len1;
+    cont.acc = cnt;
+    out = ((uint64_t(hi) << 32) | lo) + cnt + run_dword_clip(str, s, cont.at, r0);  // (no such dword: four empty runs, nothing added)
+}
+
+// same_line: `slot` is the line run_line_first decoded and pos lies at or behind its position (cont says where it stood);
+// otherwise the rank starts at the line's first dword
+__device__ __forceinline__ void run_line_continue(const uint4 *lines, uint32_t slot, uint32_t s, uint64_t pos, bool same_line, const RunCont &cont, uint64_t &out,
+                                                  uint32_t &need) {
+    const uint32_t base = line_base(slot), g = slot & 7u;
+    const uint4 c0 = lines[base + (0u ^ g)], c1 = lines[base + (1u ^ g)];
+    if ((c1.w & 0x80000000u) != 0u) {
+        need = lines[base + (2u ^ g)].x * 2u + 1u + ((uint32_t(pos) & 511u) >> 8);
+        return;
+    }
+    const uint32_t lo = s == 0u ? c0.x : s == 1u ? c0.y : s == 2u ? c0.z : s == 3u ? c0.w : s == 4u ? c1.x : c1.y;
+    const uint32_t hi = (((s >> 2) ? c1.w : c1.z) >> ((s & 3u) * 8u)) & 0xFFu;
+    const uint32_t r1 = uint32_t(pos) & 511u, sx = s * 0x01010101u;
+    uint32_t d = same_line ? cont.dword : 0u, cur = same_line ? cont.at : 0u, acc = same_line ? cont.acc : 0u;
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(lines);
+    while (d < 24u) {  // lane-varying, a dword or two for a narrow range
+        const uint32_t x = words[(base + ((2u + (d >> 2)) ^ g)) * 4u + (d & 3u)];
+        uint32_t all, mine;
+        run_dword(x, sx, all, mine);
+        if (cur + all <= r1) {
+            acc += mine;
+            cur += all;
+            ++d;
+        } else {
+            acc += run_dword_clip(x, s, cur, r1);
+            break;
         }
     }
-    const uint64_t a = (uint64_t(hi) << 32) | lo;
-    out_l = a + cnt0;
-    if (both) out_h = a + cnt1;
+    out = ((uint64_t(hi) << 32) | lo) + acc;
 }
 
 // ---- rank of one bound from a staged pair-block line (two-symbol step, rank_ops.hpp layout) -----
@@ -272,19 +300,19 @@ __device__ __forceinline__ bool sparse_scan(const uint4 *lines, uint32_t slot, u
     const uint32_t base = line_base(slot), g = slot & 7u;
     const uint4 c0 = lines[base + (0u ^ g)], c1 = lines[base + (1u ^ g)], c2 = lines[base + (2u ^ g)], c3 = lines[base + (3u ^ g)];
     const uint32_t tags[kSparseSlots] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y};
+    // Three instructions per slot (and, compare, select), from the highest slot down so that the LOWEST matching slot wins: a
+    // bucket fills from slot 0 up, so an entry always beats an empty slot (tag 0, width 0), which a key whose tag is 0 matches too.
     uint32_t hit = kSparseSlots;
-    width = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < kSparseSlots; ++i) {
-        const uint32_t t = tags[i];
-        const bool match = ((t ^ want) << (32u - kSparseTagBits)) == 0u && (t >> kSparseTagBits) != 0u;
-        hit = match ? i : hit;
-        width = match ? t >> kSparseTagBits : width;
-    }
+    for (int i = int(kSparseSlots) - 1; i >= 0; --i) hit = (tags[i] & ((1u << kSparseTagBits) - 1u)) == want ? uint32_t(i) : hit;
     header = lines[base + (7u ^ g)].w >> 16;
+    width = 0;
     if (hit >= kSparseSlots) return false;
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(lines);
+    width = words[(base + ((hit >> 2) ^ g)) * 4u + (hit & 3u)] >> kSparseTagBits;
+    if (width == 0u) return false;  // an empty slot: the key is not in this bucket (and none was displaced from a bucket with room)
     const uint32_t word = kSparseL0Word + hit;
-    const uint32_t lo = reinterpret_cast<const uint32_t *>(lines)[(base + ((word >> 2) ^ g)) * 4u + (word & 3u)];
+    const uint32_t lo = words[(base + ((word >> 2) ^ g)) * 4u + (word & 3u)];
     const uint32_t hi = reinterpret_cast<const uint8_t *>(lines)[(base + (7u ^ g)) * 16u + hit];
     l = (uint64_t(hi) << 32) | lo;
     return true;
@@ -872,20 +900,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 uint32_t need_l = 0, need_h = 0;
                 PlaneLine L;
                 nl = nh = 0;
-                const bool together = MSBWT_RUNS_FUSED != 0 && one_line && ovf_l == 0u && ovf_h == 0u;  // both bounds from one run block: one decode
+                RunCont cont{24u, 0u, 0u};
                 if (ovf_l != 0u) {
                     read_plane_line(ws.lines, slot_l, s1, L);
                     nl = plane_line_bound(L, s1, l);
                 } else {
-                    run_line_bounds(ws.lines, slot_l, s1, l, h, together, nl, nh, need_l, need_h);
+                    run_line_first(ws.lines, slot_l, s1, l, nl, need_l, cont);
                 }
                 if (ovf_h != 0u) {
                     read_plane_line(ws.lines, slot_h, s1, L);
                     nh = plane_line_bound(L, s1, h);
-                } else if (!together) {
-                    uint64_t unused = 0;
-                    uint32_t unused_need = 0;
-                    run_line_bounds(ws.lines, slot_h, s1, h, h, false, nh, unused, need_h, unused_need);
+                } else {  // h's rank continues l's decode inside the same run block, or starts at its own block's first dword
+                    run_line_continue(ws.lines, slot_h, s1, h, one_line && ovf_l == 0u, cont, nh, need_h);
                 }
                 if ((need_l | need_h) != 0u) {  // an overflow block: the step is taken again with that bound's plane block fetched
                     ovf_l = ovf_l != 0u ? ovf_l : need_l;
