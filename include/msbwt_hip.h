@@ -212,8 +212,8 @@ int msbwt_kmer_order_keys(const uint8_t *kmers, size_t k, size_t n, uint64_t *ou
  * too (kept as a value so that callers written against round 4 keep working).  There is no automatic mode: ordering 10^8 queries
  * and un-ordering their counts costs about 6 ms of the 8 ms the ordered search saved on the densest batches of round 4, sparse or
  * random batches lost 30 % to 2.7x -- and since round 5 the default index looks its queries up in a HASHED sparse suffix table,
- * whose lookups an order cannot help: the same dense batches now LOSE 8-14 % with the pass forced on (BENCH_r05: c4_repeats 7.35 ->
- * 6.32, c4_real_reads 7.60 -> 6.99 x 10^9 q/s).  MSBWT_ORDER=0|1 in the environment sets the initial mode.
+ * whose lookups an order cannot help: the same dense batches now LOSE 6-14 % with the pass forced on (round 5, `library_ordered` beside
+ * the c4_* lines of bench.py: 7.5 -> 6.8 and 7.9 -> 7.4 x 10^9 q/s).  MSBWT_ORDER=0|1 in the environment sets the initial mode.
  * Applies to msbwt_rle_count_kmers[_device] and the packed forms.  msbwt_rle_batch_order_for: 1 if a batch of n k-symbol queries
  * would be ordered now.  Results never change. */
 int msbwt_rle_set_batch_order(msbwt_rle *bwt, int mode);
