@@ -553,7 +553,12 @@ int rebuild_table(msbwt_rle *h, bool allow_sparse = true) {
         }
         rc = build_sparse(h, (pack && h->d_table) ? packed_table_bytes(depth + 2) : 0, allowance);
         if (rc) return rc;
-        if (!h->d_sparse && capped) return rebuild_table(h, false);
+        if (!h->d_sparse && capped) {  // no depth fit: the direct table as if there were no sparse one (the distinct counts stay on record)
+            const SparseBuildReport counted = h->sparse_report;
+            const int again = rebuild_table(h, false);
+            h->sparse_report = counted;
+            return again;
+        }
     }
     if (!h->d_table || !pack) return rc;
     // Packed form, two levels deeper (kernels.hpp, launch_pack_table): every level removes a line fetch
