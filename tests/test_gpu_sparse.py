@@ -223,3 +223,37 @@ def test_automatic_depth_follows_the_data_and_short_queries_use_the_direct_table
         assert np.array_equal(b.count_kmers(q), ref.count_kmers(q)), k
     with pytest.raises(msbwt.MsbwtError):
         b.set_sparse_table(12)
+
+
+def test_when_no_depth_fits_the_direct_table_is_built_instead_and_the_counts_stay_on_record(monkeypatch):
+    """A memory budget that leaves the pair blocks but no room for any sparse depth: the loader builds the direct table the plan allows,
+    the handle has no sparse table, the distinct counts of the sizing pass are still reported, counts equal the oracle's."""
+    monkeypatch.setenv("MSBWT_SEARCH", "auto")
+    monkeypatch.delenv("MSBWT_SPARSE_TABLE", raising=False)
+    reads = read_set(8, 60000, 20000, 100, err=0.005)
+    rle = bwt_of(reads)
+    ref = orc.OracleRleBWT()
+    ref.load_vector(rle)
+    b = RleBWT()
+    b.load_vector(rle)
+    assert b.get_sparse_table() >= 16 and b.get_pair_index()
+    full = b.device_bytes()
+    planes = (b.get_total_size() // 256 + 1) * 128
+    found = None
+    for budget in range(full, planes, -(64 << 10)):   # downwards in 64 KiB steps until the sparse table no longer fits beside the pair blocks
+        b.set_memory_budget(budget)
+        if b.get_pair_index() and b.get_sparse_table() == 0:
+            found = budget
+            break
+        if not b.get_pair_index():
+            break
+    assert found is not None, "no budget keeps the pair blocks without a sparse table"
+    info = b.sparse_table_info()
+    assert info["depth"] == 0 and info["entries"] == 0 and len(info["distinct"]) >= 2 and max(info["distinct"].values()) > 10000, info
+    assert b.device_bytes() <= found + (4 << 20)
+    for k in (12, 25, 31):
+        windows = np.lib.stride_tricks.sliding_window_view(reads, k, axis=1).reshape(-1, k)
+        q = np.ascontiguousarray(np.concatenate([windows[::97], random_kmers(k, 3000, k)]))
+        assert np.array_equal(b.count_kmers(q), ref.count_kmers(q)), k
+    b.set_memory_budget(0)
+    assert b.get_sparse_table() >= 16 and b.device_bytes() == full
