@@ -287,6 +287,10 @@ int msbwt_rle_get_sparse_table(const msbwt_rle *bwt);
 int msbwt_rle_sparse_table_info(const msbwt_rle *bwt, uint64_t *out);
 int msbwt_sparse_hash(uint64_t key, int depth, uint64_t nbuckets, uint32_t *bucket, uint32_t *tag);
 int msbwt_sparse_table_shape(int depth, uint64_t entries, uint64_t *nbuckets, int *probe);
+/* The automatic depth as a pure function (no device needed; rust-msbwt_amd/csrc/sparse_policy.hpp): distinct[d] / wide[d] for d = 0..24
+ * as msbwt_rle_sparse_table_info reports them ([10 + d], [35 + d]), the depth of the direct table the count started from, and the bytes
+ * the table and its build scratch may take -> the depth the loader would build (0 = none fits) and the bytes of that table. */
+int msbwt_auto_sparse_depth(const uint64_t *distinct, const uint64_t *wide, int parent_depth, uint64_t avail_bytes, int *depth, uint64_t *table_bytes);
 size_t msbwt_rle_download_sparse_table(const msbwt_rle *bwt, void *out_lines, size_t cap_bytes, void *out_side, size_t cap_side_bytes);
 /* Presence filter: one bit per ACGT suffix of length min(12, table depth), set when some table
  * entry with that suffix is a non-empty range; at most 2 MiB, so it lives in L2 and decides

@@ -27,6 +27,7 @@
 #include "run_build.hpp"
 #include "run_index.hpp"
 #include "sparse_build.hpp"
+#include "sparse_policy.hpp"
 
 using namespace msbwt;
 
@@ -420,23 +421,11 @@ int build_sparse(msbwt_rle *h, uint64_t keep_free, uint64_t allowance) {
     const uint64_t spare = keep_free + total_b / 8;  // an eighth of the HBM stays free for the caller's batches
     // (an explicit depth wins over a memory budget, like the other explicit settings: only the HBM itself limits it)
     const uint64_t avail = std::min<uint64_t>(explicit_depth ? kNoBudget : allowance, uint64_t(free_b) > spare ? uint64_t(free_b) - spare : 0);
-    int chosen = 0;
-    uint64_t nbuckets = 0;
-    for (int d = max_depth; d >= kSparseMinDepth && d > flat_depth; --d) {
-        if (explicit_depth ? d != max_depth : rep.distinct[d] == 0) continue;  // not a level of this pass (the other parity), or nothing occurs
-        const uint64_t needed = uint64_t(double(rep.distinct[d]) / kSparseLoad) + 1, nb = sparse_buckets_for(d, rep.distinct[d]);
-        const uint64_t lines = nb + kSparseMaxProbe;
-        if (lines > 0xFFFFFFFFull) continue;
-        // a table that the tags force to be much larger than its entries need is not worth its depth (toy indexes stay small)
-        if (!explicit_depth && sparse_min_buckets(d) > std::max<uint64_t>(16 * needed, 65536)) continue;
-        if (lines * 128 + rep.escapes[d] * 16 + lines * sizeof(uint32_t) > avail) {
-            if (explicit_depth) return fail(h, MSBWT_ERR_HIP, "the sparse table of the requested depth does not fit in HBM");
-            continue;
-        }
-        chosen = d;
-        nbuckets = nb;
-        break;
-    }
+    // the depth: a pure function of the counts and the bytes (sparse_policy.hpp, pinned by a CPU test through msbwt_auto_sparse_depth)
+    const SparseChoice choice = choose_sparse_depth(rep.distinct, rep.escapes, flat_depth, max_depth, avail, explicit_depth ? max_depth : 0);
+    const int chosen = choice.depth;
+    uint64_t nbuckets = choice.nbuckets;
+    if (!chosen && explicit_depth) return fail(h, MSBWT_ERR_HIP, "the sparse table of the requested depth does not fit in HBM");
     if (!chosen) {
         h->sparse_report = rep;  // (the distinct counts are worth keeping: msbwt_rle_sparse_table_info)
         if (verbose) std::fprintf(stderr, "[msbwt] sparse table: no depth fits %.2f GB -- none built\n", double(avail) / 1e9);
@@ -2052,6 +2041,14 @@ int msbwt_sparse_hash(uint64_t key, int depth, uint64_t nbuckets, uint32_t *buck
     const uint64_t x = sparse_mix(key, uint32_t(2 * depth));
     *bucket = sparse_bucket(x, uint32_t(2 * depth), uint32_t(nbuckets));
     *tag = sparse_tag(x);
+    return MSBWT_OK;
+}
+
+int msbwt_auto_sparse_depth(const uint64_t *distinct, const uint64_t *wide, int parent_depth, uint64_t avail_bytes, int *depth, uint64_t *table_bytes) {
+    if (!distinct || !wide || !depth || parent_depth < 0 || parent_depth > 16) return MSBWT_ERR_INVALID_ARG;
+    const SparseChoice c = choose_sparse_depth(distinct, wide, parent_depth, kSparseAutoDepth, avail_bytes, 0);
+    *depth = c.depth;
+    if (table_bytes) *table_bytes = c.bytes;
     return MSBWT_OK;
 }
 

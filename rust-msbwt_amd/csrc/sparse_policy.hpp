@@ -1,0 +1,50 @@
+// Which depth does the sparse suffix table (sparse_table.hpp) get?  Host only, no HIP: a pure function of what the sizing pass counted
+// and of the bytes that are free, pinned by a CPU test through msbwt_auto_sparse_depth.
+//
+// The table's size follows the DATA -- 14.2 bytes per distinct d-symbol suffix that occurs -- not the depth: on an error-free read
+// set the distinct count saturates at the genome's size (human scale: 2.74e9 17-mers, 2.98e9 23-mers), on reads with errors every
+// error adds up to d novel d-mers (C4: 2.4e8 distinct 23-mers for a 6.4e7-bp genome).  So the automatic choice is the DEEPEST depth
+// the sizing pass reached (it advances two symbols at a time from the direct table's depth, at most to 23) whose table fits the
+// bytes available, skipping depths whose smallest permissible table (the tags need 2^(2d - 21) buckets) would be more than 16 x
+// larger than its entries need (toy indexes stay small); none fits -> no sparse table (the loader then builds the deep direct table).
+#pragma once
+#include <algorithm>
+#include <cstdint>
+
+#include "sparse_table.hpp"
+
+namespace msbwt {
+
+struct SparseChoice {
+    int depth = 0;            // 0 = none
+    uint64_t nbuckets = 0;    // of the table at that depth
+    uint64_t bytes = 0;       // bucket lines + side array
+    uint64_t build_bytes = 0; // ... + the slot counters the fill pass needs beside them
+};
+
+// distinct[d] / wide[d]: non-empty ranges at depth d and how many of them are 255 or more wide (0 for depths the pass did not reach);
+// parent_depth: the direct table the pass started from; avail: bytes the table (and its build scratch) may take;
+// explicit_depth: 0 = automatic, else exactly that depth or nothing.
+inline SparseChoice choose_sparse_depth(const uint64_t *distinct, const uint64_t *wide, int parent_depth, int max_depth, uint64_t avail, int explicit_depth) {
+    SparseChoice none;
+    for (int d = std::min(max_depth, kSparseMaxDepth); d >= kSparseMinDepth && d > parent_depth; --d) {
+        if (explicit_depth ? d != explicit_depth : distinct[d] == 0) continue;  // not a level of the pass (the other parity), or nothing occurs
+        const uint64_t needed = uint64_t(double(distinct[d]) / kSparseLoad) + 1, nb = sparse_buckets_for(d, distinct[d]);
+        const uint64_t lines = nb + kSparseMaxProbe;
+        if (lines > 0xFFFFFFFFull) continue;
+        if (!explicit_depth && sparse_min_buckets(d) > std::max<uint64_t>(16 * needed, 65536)) continue;
+        SparseChoice c;
+        c.depth = d;
+        c.nbuckets = nb;
+        c.bytes = lines * 128 + wide[d] * 16;
+        c.build_bytes = c.bytes + lines * sizeof(uint32_t);
+        if (c.build_bytes > avail) {
+            if (explicit_depth) return none;
+            continue;
+        }
+        return c;
+    }
+    return none;
+}
+
+}  // namespace msbwt

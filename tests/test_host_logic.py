@@ -471,3 +471,43 @@ def test_run_block_device_build_decision():
     assert fits(human, 60 * 10 ** 9) == 0            # the finished 28 GB index fits, its builder's peak does not: host build
     assert fits(4 * human, 288 * 2 ** 30) == 1 and fits(5 * human, 288 * 2 ** 30) == 0
     assert fits(0, 1 << 20) == 1 and fits(1000, 100) == 0
+
+
+def test_automatic_sparse_depth_follows_the_distinct_counts():
+    """csrc/sparse_policy.hpp through msbwt_auto_sparse_depth (no device): the depth of the sparse suffix table is the deepest one the
+    sizing pass reached whose table fits -- with the distinct counts the device builder measured on this repo's indexes (DESIGN.md 2,
+    profiles/r05_lab/sparse_table.log), and with what a 30x human read set WITH errors would count (about 1.3e10 distinct 23-mers)."""
+    def choose(distinct, avail, parent=13, wide=None):
+        d, w = (C.c_uint64 * 25)(), (C.c_uint64 * 25)()
+        for k, v in distinct.items():
+            d[k] = v
+        for k, v in (wide or {}).items():
+            w[k] = v
+        depth, nbytes = C.c_int(), C.c_uint64()
+        assert _lib.lib().msbwt_auto_sparse_depth(d, w, parent, avail, C.byref(depth), C.byref(nbytes)) == 0
+        return depth.value, nbytes.value
+
+    GB = 10 ** 9
+    human = {13: 67108864, 15: 1006827312, 17: 2735962851, 19: 2964035516, 21: 2979123385, 23: 2980069347}
+    depth, nbytes = choose(human, 80 * GB)
+    assert depth == 23 and 42 * GB < nbytes < 43 * GB            # 9 entries per 128-byte bucket: 14.2 bytes per distinct 23-mer
+    assert choose(human, 41 * GB)[0] == 17                       # 19 and 21 are as large as 23 (the counts have saturated); 17 takes 38.9 + 1.2 GB
+    assert choose(human, 30 * GB)[0] == 0                        # nothing fits: the loader builds the deep direct table instead
+    c4 = {13: 62114725, 15: 173178299, 17: 201574823, 19: 215988570, 21: 228772228, 23: 240890440}
+    depth, nbytes = choose(c4, 200 * GB)
+    assert depth == 23 and 4.2 * GB < nbytes < 4.4 * GB           # 2^25 buckets: the least the 24-bit tags allow at depth 23
+    assert choose(c4, 4 * GB)[0] == 21
+    c4r_wide = {23: 121783}
+    assert choose({13: 57811435, 15: 139915525, 17: 165712263, 19: 182311770, 21: 197456191, 23: 211785309}, 200 * GB, wide=c4r_wide) == (23, (2 ** 25 + 15) * 128 + 121783 * 16)
+    c2 = {13: 8236020, 15: 9416785, 17: 10083004, 19: 10669535, 21: 11211118, 23: 11710447}
+    assert choose(c2, 200 * GB)[0] == 21                         # depth 23 would need 16 x more buckets than its 1.2e7 entries fill
+    c3 = {13: 15517768, 15: 19198740, 17: 21012907, 19: 22607694, 21: 24122220, 23: 25566761}
+    assert choose(c3, 200 * GB)[0] == 23
+    toy = {6: 2000, 8: 2900, 10: 2950, 12: 2960, 14: 2970, 16: 2975, 18: 2980, 20: 2985, 22: 2990, 23: 2992}
+    depth, nbytes = choose(toy, 200 * GB, parent=6)
+    assert depth == 18 and nbytes < 5 << 20                      # a toy index gets a toy table
+    # reads with 0.5 % substitutions at human scale: errors, not the genome, set the counts
+    noisy = {13: 67108864, 15: 1.07e9, 17: 9.0e9, 19: 1.05e10, 21: 1.17e10, 23: 1.29e10}
+    noisy = {k: int(v) for k, v in noisy.items()}
+    assert choose(noisy, 100 * GB)[0] == 0 and choose(noisy, 200 * GB)[0] == 23
+    assert choose({}, 200 * GB)[0] == 0
