@@ -377,7 +377,10 @@ def roofline_block(orc, ref, queries, k, ncpu, per_launch_q, kern_s, kernel_ms, 
         "note": "achieved/frac = measured HBM-side traffic of one launch (rocprofv3 PMC: FETCH_SIZE x 2 + WRITE_SIZE, separate passes) / "
                 "kernel time measured live with HIP events on the launch stream / 8 TB/s",
         "random_lines": None if traffic is None else {
-            "per_s": traffic / 128.0 / kern_s, "peak_per_s": RANDOM_LINE_PEAK, "frac": traffic / 128.0 / kern_s / RANDOM_LINE_PEAK},
+            "per_s": traffic / 128.0 / kern_s, "peak_per_s": RANDOM_LINE_PEAK, "frac": traffic / 128.0 / kern_s / RANDOM_LINE_PEAK,
+            "note": "peak_per_s = random 128-byte lines/s of independent gathers over tables of 8-250 GiB (tools/ubench_granule.hip): an "
+                                                              "index whose hot arrays are a few GB gets part of its lines from the 256 MB Infinity Cache, which FETCH_SIZE counts "
+                                                              "too, so such a line can come close to 1"},
     }
 
 
