@@ -383,6 +383,15 @@ int msbwt_rle_search_kernel_for(const msbwt_rle *bwt, size_t k);
 #define MSBWT_SEARCH_COUNTERS 16
 int msbwt_rle_set_search_counters(msbwt_rle *bwt, int enabled);
 int msbwt_rle_search_counters(const msbwt_rle *bwt, uint64_t *out, void *hip_stream);
+/* Cache policy of the index lines.  The one-query-per-lane kernel uses every line it fetches once; on an index whose random-access
+ * arrays (the pair blocks, else the blocks themselves) are far larger than L2 and the 256 MB Infinity Cache those lines only evict what
+ * IS reused (the superblock table, the query stream), so they are fetched with the non-temporal hint: at 30x-human scale 36.1 ms per
+ * 3 x 10^8 present 31-mers (35.6-36.6 over four alternating runs) against 38.4 ms (36.7-39.8) with the default policy; a small index,
+ * whose pair blocks half live in the Infinity Cache, LOSES (C3 fused 14.9 -> 19.8 ms).  mode -1 = automatic (default: from 4 GiB of such
+ * arrays on), 0 = never, 1 = always; MSBWT_STREAM_LINES=0|1|auto in the environment sets the initial mode.  get: what launches on the
+ * loaded index do now.  Results never change. */
+int msbwt_rle_set_line_streaming(msbwt_rle *bwt, int mode);
+int msbwt_rle_get_line_streaming(const msbwt_rle *bwt);
 /* Placement diagnostic: random 128-byte lines per second the memory system serves right now from one of the index's arrays
  * (which: 0 = plane / run blocks, 1 = pair blocks, 2 = the sparse table's bucket lines, 3 = the direct suffix table; 0.0 when the
  * index has no such array) -- about a millisecond of gathering, nothing is written.  (Round 5 used it on the "two modes" of C4-sized

@@ -84,6 +84,8 @@ SIGNATURES = {
     "msbwt_rle_get_pair_stride": (_int, [_vp]),
     "msbwt_rle_get_typical_range_width": (C.c_double, [_vp]),
     "msbwt_auto_pair_stride": (_int, [_u64, _u64, _u64, C.c_double, C.POINTER(C.c_int)]),
+    "msbwt_rle_set_line_streaming": (_int, [_vp, _int]),
+    "msbwt_rle_get_line_streaming": (_int, [_vp]),
     "msbwt_rle_probe_line_rate": (_int, [_vp, _int, C.POINTER(C.c_double)]),
     "msbwt_rle_device_bytes": (_u64, [_vp]),
     "msbwt_rle_kernel_time_ms": (_int, [_vp, C.POINTER(C.c_double), _pu64]),

@@ -64,6 +64,7 @@ struct msbwt_rle {
     uint64_t sparse_bytes = 0, sparse_side_bytes = 0;
     uint32_t sparse_nbuckets = 0, sparse_probe = 0;
     int sparse_depth = 0;
+    int wanted_streaming = -1;       // index lines fetched non-temporally: -1 = when the random-access arrays dwarf the caches, 0 = never, 1 = always
     int wanted_sparse = -1;          // -1 = automatic (beside a pair index, as deep as the data and HBM allow, at most 23), 0 = off, 16..24 = that depth
     SparseBuildReport sparse_report{};
     bool counting = false;           // search counters wanted (msbwt_rle_set_search_counters)
@@ -119,6 +120,7 @@ struct msbwt_rle {
 namespace {
 
 constexpr int kMaxTableDepth = 16;  // 4^16 x 16 B = 64 GiB
+constexpr uint64_t kStreamLinesFrom = uint64_t(4) << 30;  // random-access arrays from here on are read with the non-temporal hint (view_of)
 
 constexpr size_t kStatusBytes = 1024;  // flag words, debug record (bytes 64..128), search counters (bytes 128..256)
 constexpr size_t kCountersOffset = 128;
@@ -244,6 +246,11 @@ IndexView view_of(msbwt_rle *h) {
     v.pair_super = static_cast<const uint64_t *>(h->d_pair_super);
     v.pair_stride96 = h->d_pair_blocks && h->pair_stride == 96;
     v.search_kernel = h->search_kernel;
+    {   // lines used once should not evict what is reused -- once the arrays the search reads at random (pair blocks, else the blocks
+        // themselves) are far beyond what L2 (8 x 4 MB) and the Infinity Cache (256 MB) hold: 4 GiB and up
+        const uint64_t hot = h->d_pair_blocks ? h->pair_bytes : h->nblocks * kBlockBytes;
+        v.stream_lines = h->wanted_streaming > 0 || (h->wanted_streaming < 0 && hot >= kStreamLinesFrom);
+    }
     if (h->d_sparse && h->d_pair_blocks) {
         v.sparse.lines = h->d_sparse;
         v.sparse.nbuckets = h->sparse_nbuckets;
@@ -1082,6 +1089,7 @@ msbwt_rle *msbwt_rle_new_on_device(uint8_t bin_power, int device) {
     if (const char *env = std::getenv("MSBWT_TABLE_DEPTH")) h->wanted_table_depth = std::max(-1, std::min(std::atoi(env), kMaxTableDepth));
     if (const char *env = std::getenv("MSBWT_TABLE_PACKED")) h->wanted_table_packed = std::atoi(env) ? 1 : 0;
     if (const char *env = std::getenv("MSBWT_TABLE_SIDE")) h->wanted_table_side = std::atoi(env) ? 1 : 0;
+    if (const char *env = std::getenv("MSBWT_STREAM_LINES")) h->wanted_streaming = std::strcmp(env, "auto") == 0 ? -1 : (std::atoi(env) ? 1 : 0);
     if (const char *env = std::getenv("MSBWT_SPARSE_TABLE")) {
         const int d = std::strcmp(env, "auto") == 0 ? -1 : std::atoi(env);
         h->wanted_sparse = (d == 0 || d == -1 || (d >= kSparseMinDepth && d <= kSparseMaxDepth)) ? d : -1;
@@ -1558,6 +1566,7 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
     h->wanted_table_packed = src->wanted_table_packed;
     h->wanted_table_side = src->wanted_table_side;
     h->wanted_sparse = src->wanted_sparse;
+    h->wanted_streaming = src->wanted_streaming;
     h->wanted_block_format = src->wanted_block_format;
     h->block_format = src->block_format;
     h->wanted_pair = src->wanted_pair;
@@ -2070,6 +2079,20 @@ size_t msbwt_rle_download_sparse_table(const msbwt_rle *ch, void *out_lines, siz
         hipMemcpy(out_side, h->d_sparse_side, h->sparse_side_bytes, hipMemcpyDeviceToHost) != hipSuccess)
         return SIZE_MAX;
     return size_t(h->sparse_bytes);
+}
+
+int msbwt_rle_set_line_streaming(msbwt_rle *h, int mode) {
+    if (!h || mode < -1 || mode > 1) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->wanted_streaming = mode;
+    return MSBWT_OK;
+}
+
+int msbwt_rle_get_line_streaming(const msbwt_rle *ch) {
+    msbwt_rle *h = const_cast<msbwt_rle *>(ch);
+    if (!h || !h->loaded) return 0;
+    std::lock_guard<std::mutex> lock(h->mu);
+    return view_of(h).stream_lines ? 1 : 0;
 }
 
 int msbwt_rle_probe_line_rate(const msbwt_rle *ch, int which, double *lines_per_second) {

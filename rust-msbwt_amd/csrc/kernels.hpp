@@ -62,6 +62,9 @@ struct IndexView {
     // optional search counters of the lanes kernel (kSearchCounters u64, added to by every wave): what a batch did to
     // the index -- steps, second lines, escape lines ... (msbwt_rle_search_counters); nullptr = not wanted
     uint64_t *counters = nullptr;
+    // The index's random-access arrays are far larger than L2 and Infinity Cache: the lanes kernel fetches their lines with the
+    // non-temporal hint, so that lines used once do not evict what is reused (capi.cpp decides; lanes.hip has the measurements).
+    bool stream_lines = false;
     // optional sparse suffix table (sparse_table.hpp): the ranges of the suffixes that occur, deeper than the direct table
     // reaches; the lanes kernel looks up queries of at least its depth there (beside a pair index), shorter ones in `table`
     SparseView sparse;

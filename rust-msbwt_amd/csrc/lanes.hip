@@ -355,7 +355,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     const uint8_t *stage_bytes = reinterpret_cast<const uint8_t *>(ws.lines) + kStageLead;  // pack_query reads in front of a query
     const uint64_t ntiles = (n + kTile - 1) / kTile;
     const bool use_table = table != nullptr && depth > 0 && k >= depth;
-    const TableEnv env{table, depth, use_table, table_packed != 0u, filter, filter_mask, total, table_side};
+    const TableEnv env{table, depth, use_table, (table_packed & 1u) != 0u, filter, filter_mask, total, table_side};
+    // bit 1 of the same argument: the index is far larger than the caches (IndexView::stream_lines), so its lines are fetched with the
+    // non-temporal hint -- a line is used once, and left to the default policy it evicts what IS reused (the superblock table, the query
+    // stream).  Round 5, human scale, alternating on one box: 38.4 ms (36.7-39.8) by default, 36.1 ms (35.6-36.6) streaming; C3 fused,
+    // whose pair blocks half live in the Infinity Cache, 14.9 -> 19.8 ms -- hence a launch-uniform switch, not a constant.
+    const bool stream_lines = (table_packed & 2u) != 0u;
     // optional search counters (kernels.hpp, SearchCounter): wave sums kept in LDS, added to the caller's block at the end
     const bool counting = kCounting && counters != nullptr;
     if (counting && lane < uint32_t(kSearchCounters)) ws.cnt[lane] = 0u;
@@ -813,7 +818,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
 #pragma unroll
             for (int i = 0; i < kRegions; ++i) {
                 const bool wanted = i < 8 ? ((busy >> (8 * i)) & 0xFFull) != 0ull : nextra > uint32_t(8 * (i - 8));  // wave-uniform
-                if (wanted) __builtin_amdgcn_global_load_lds((global_void *)addr[i], (lds_void *)&ws.lines[region_base(i)], 16, 0, 0);
+                if (wanted) {  // (the cache policy is an immediate of the instruction: two copies of the load)
+                    if (stream_lines) __builtin_amdgcn_global_load_lds((global_void *)addr[i], (lds_void *)&ws.lines[region_base(i)], 16, 0, 2);
+                    else __builtin_amdgcn_global_load_lds((global_void *)addr[i], (lds_void *)&ws.lines[region_base(i)], 16, 0, 0);
+                }
             }
         }
         __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): every line has landed in LDS (and the table entries of step C are here)
@@ -1005,7 +1013,7 @@ hipError_t launch_variant(hipStream_t stream, const IndexView &ix, const QuerySo
     const uint32_t grain = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(16, tiles / (waves * 8))));
     const uint4 *side = static_cast<const uint4 *>(kSparse ? ix.sparse.side : (table ? ix.table.side : nullptr));
     hipLaunchKernelGGL((k_count_kmers_lanes<kReads, kPair, kWords, kStride96, kPacked, kSparse>), dim3(uint32_t(waves)), dim3(64), 0, stream,
-                       static_cast<const uint4 *>(ix.blocks), ix.total, table, kSparse ? ix.sparse.depth : uint32_t(ix.table.depth), (!kSparse && ix.table.packed) ? 1u : 0u,
+                       static_cast<const uint4 *>(ix.blocks), ix.total, table, kSparse ? ix.sparse.depth : uint32_t(ix.table.depth), ((!kSparse && ix.table.packed) ? 1u : 0u) | (ix.stream_lines ? 2u : 0u),
                        filter, filter_mask, side, static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags, ix.debug,
                        tickets ? static_cast<unsigned long long *>(ix.tile_counter) : nullptr, grain, waves == 1 ? ix.done : nullptr, ix.done_seq, ix.counters,
                        uint32_t(ix.block_format), static_cast<const uint4 *>(ix.overflow), ix.sparse.nbuckets, ix.sparse.probe);

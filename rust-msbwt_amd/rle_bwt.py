@@ -413,6 +413,15 @@ class RleBWT(BWT):
             _raise(rc, self._h)
         return {0: "generic", 1: "groups", 2: "lanes"}[rc]
 
+    def set_line_streaming(self, mode):
+        """-1 = automatic (index lines are fetched non-temporally once the random-access arrays reach 4 GiB), 0 = never, 1 = always."""
+        rc = _lib.lib().msbwt_rle_set_line_streaming(self._h, int(mode))
+        if rc:
+            _raise(rc, self._h)
+
+    def get_line_streaming(self):
+        return bool(_lib.lib().msbwt_rle_get_line_streaming(self._h))
+
     PROBE_ARRAYS = {"blocks": 0, "pair_blocks": 1, "sparse_table": 2, "table": 3}
 
     def probe_line_rate(self, which):

@@ -175,6 +175,7 @@ def test_human_scale_9e10_symbols_against_the_oracle():
     bwt.load_vector(rle)
     # the default index since round 5: sparse suffix table of depth 23 (3e9 distinct 23-mers, ~42 GB), a small direct table beside it
     assert bwt.get_total_size() == total and bwt.get_pair_index() and bwt.get_sparse_table() == 23 and bwt.get_table_depth() == 15
+    assert bwt.get_line_streaming()   # 120 GB of pair blocks: their lines are fetched with the non-temporal hint
     info = bwt.sparse_table_info()
     assert 2.9e9 < info["entries"] < 3.1e9 and info["entries"] == info["distinct"][23] and info["bytes"] < 50e9, info
     # a real 30x BWT: present k-mers keep ranges ~ coverage wide, and the loader answers with overlapping pair blocks

@@ -1045,6 +1045,8 @@ def test_run_block_format_is_selectable_and_lean():
         b.set_pair_index(1)
         assert b.get_pair_index() == (fmt == "planes")
         assert np.array_equal(b.count_kmers(q1), exp[0])
+        b.set_line_streaming(1)   # (non-temporal line loads: the automatic choice of indexes of 4 GiB and more, forced here)
+        assert b.get_line_streaming() and np.array_equal(b.count_kmers(q1), exp[0])
     assert 0.25 * total < sizes["runs"] < 0.36 * total and 0.49 * total < sizes["planes"] < 0.51 * total
 
 

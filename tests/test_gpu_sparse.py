@@ -151,6 +151,12 @@ def test_counts_with_the_sparse_table_equal_the_oracle(depth, stride, monkeypatc
     assert np.array_equal(fwd, ref.count_kmers(windows.reshape(-1, k)).reshape(fwd.shape))
     rcq = np.array([orc.reverse_complement_i(w) for w in windows.reshape(-1, k)], dtype=np.uint8)
     assert np.array_equal(rc, ref.count_kmers(rcq).reshape(rc.shape))
+    # the cache policy of the index lines (non-temporal loads, automatic on indexes of 4 GiB and more) changes nothing either
+    assert not b.get_line_streaming()
+    b.set_line_streaming(1)
+    assert b.get_line_streaming()
+    assert np.array_equal(b.count_kmers(np.ascontiguousarray(windows.reshape(-1, k)[:6000])), ref.count_kmers(np.ascontiguousarray(windows.reshape(-1, k)[:6000])))
+    b.set_line_streaming(-1)
     # switching the table off (and on again) changes nothing but the table
     b.set_sparse_table(0)
     assert b.get_sparse_table() == 0
