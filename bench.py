@@ -119,6 +119,11 @@ def parse_args(argv=None):
                     help="human / big: what the index is built from.  reads (default) = the EXACT multi-string BWT of an error-free 30x read "
                          "set (150-bp reads of a random genome), built on the GPU without suffix-sorting the reads (synth/bwt_reads.py); "
                          "histogram / geometric = a stream of independent symbols with run lengths from C4's measured histogram / a geometric law")
+    ap.add_argument("--genome", default="random", choices=["random", "repeats"],
+                    help="human / big with --stream reads: the genome the error-free reads come from.  random (default: the metric's line) or repeats = "
+                         "synth.repeat_genome, the human repeat classes at their own proportions and copy numbers (SINE-, LINE-, LTR-, DNA-element-like "
+                         "families, segmental duplications, satellite arrays, microsatellites); its exact MSBWT takes the genome's suffix order to the "
+                         "read length (synth/bwt_reads.py, msbwt_rle_repeats).  A lab line: never the default, no committed PMC summary")
     ap.add_argument("--stats-sample", type=int, default=2_000_000, help="queries used for the algorithmic-byte counters (0 = all)")
     ap.add_argument("--queries", type=int, default=0, help="queries per step, whole job (0 = the config's)")
     ap.add_argument("--k", type=int, default=0, help="override k")
@@ -282,7 +287,7 @@ def lookup_traffic(workload, k, bwt, kind, total, fused, full_size):
     return per_query, src, note, stamp
 
 
-def live_pmc_traffic(extra_args, queries, kernel_substr="k_count_kmers", counters=("FETCH_SIZE", "WRITE_SIZE")):
+def live_pmc_traffic(extra_args, queries, kernel_substr="k_count_kmers", counters=("FETCH_SIZE", "WRITE_SIZE"), patience=300):
     """HBM-side bytes per query of the count kernel, measured NOW: two rocprofv3 --pmc child passes (FETCH_SIZE and
     WRITE_SIZE separately, as MI355X_MICROARCH.md prescribes; the program goes directly after `--`) over a shortened copy
     of this run -- same index (same seeds), `queries` present k-mers, one warm-up and two timed launches.  The caller
@@ -301,7 +306,7 @@ def live_pmc_traffic(extra_args, queries, kernel_substr="k_count_kmers", counter
                "--", sys.executable, os.path.abspath(__file__), "--no-oracle", "--no-c5", "--no-c4", "--no-live-pmc", "--no-sorted", "--queries", str(queries),
                "--steps", "2", "--warmup", "1"] + list(extra_args)
         try:
-            done = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+            done = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=patience)
         except (OSError, subprocess.TimeoutExpired) as e:
             shutil.rmtree(out_dir, ignore_errors=True)
             return None, "%s pass failed: %r" % (counter, e)
@@ -515,8 +520,13 @@ def main():
             # sort of the 9e10 read suffixes: synth/bwt_reads.py).  Same seed, same device type => identical replicas.
             from synth import bwt_reads
             genome_len = max(2000, int(symbols * read_len / (coverage * (read_len + 1))))
-            genome, cnt = bwt_reads.read_set(genome_len, read_len, coverage, 77, device=dev)
-            rle, _, n_reads_total = bwt_reads.msbwt_rle(genome, cnt, read_len, log=lambda m: log("rank %d: bwt: %s" % (rank, m)))
+            if args.genome == "repeats":
+                genome, cnt = bwt_reads.repeat_read_set(genome_len, read_len, coverage, 77, device=dev)
+                log("rank %d: repeat-bearing genome of %d bases in %.1fs" % (rank, genome_len, time.time() - t0))
+                rle, _, n_reads_total = bwt_reads.msbwt_rle_repeats(genome, cnt, read_len, log=lambda m: log("rank %d: bwt: %s" % (rank, m)))
+            else:
+                genome, cnt = bwt_reads.read_set(genome_len, read_len, coverage, 77, device=dev)
+                rle, _, n_reads_total = bwt_reads.msbwt_rle(genome, cnt, read_len, log=lambda m: log("rank %d: bwt: %s" % (rank, m)))
             del genome, cnt
             torch.cuda.empty_cache()
             log("rank %d: exact MSBWT of %d error-free %d-bp reads: %d RLE bytes in %.1fs" % (rank, n_reads_total, read_len, len(rle), time.time() - t0))
@@ -899,7 +909,14 @@ def main():
             log("native gather failed: %r" % (e,))
 
     kind_text = {"walk": "present (LF-walk)", "random": "random", "reads": "read-derived"}[kind]
-    if exact_bwt:
+    if exact_bwt and args.genome == "repeats":
+        wl = ("%s: EXACT multi-string BWT of %d error-free synthetic %d-bp reads (%.0fx of a REPEAT-BEARING %d-bp genome: synth.repeat_genome, the human "
+              "repeat classes at their own proportions and copy numbers -- SINE-, LINE-, LTR-, DNA-element-like families, segmental duplications, satellite "
+              "arrays, microsatellites; built on the GPU from the genome's suffix order to the read length, synth/bwt_reads.py msbwt_rle_repeats), "
+              "%d symbols; %d %s %d-mers per step (drawn like read windows: a k-mer's chance follows its number of occurrences).  A lab line beside the "
+              "metric's repeat-free one; forward strand, no read errors"
+              % (args.workload, n_reads_total, read_len, coverage, genome_len, total, nq, kind_text, k))
+    elif exact_bwt:
         wl = ("%s: EXACT multi-string BWT of %d error-free synthetic %d-bp reads (%.0fx of a random %d-bp genome; built on the GPU from the genome's "
               "suffix order, synth/bwt_reads.py), %d symbols; %d %s %d-mers per step.  The genome is REPEAT-FREE and the reads carry no errors: what "
               "repeat families and read errors do to this path at the largest exact size that can be built here is in `c4_repeats` (cost by copy "
@@ -1041,7 +1058,7 @@ def main():
             rc = 1
         per_launch_q = mine_n if strong else nq
         kern_s = kernel_ms / 1e3 if launches else elapsed / args.steps
-        tq, tsrc, tnote, stamp = lookup_traffic(args.workload, k, bwt, kind, total, fused, args.scale == 1.0)
+        tq, tsrc, tnote, stamp = lookup_traffic(args.workload + ("+repeats" if args.genome == "repeats" else ""), k, bwt, kind, total, fused, args.scale == 1.0)
         result["roofline"] = roofline_block(orc, ref, queries, k, ncpu, per_launch_q, kern_s, kernel_ms, launches, tq, tsrc, tnote, stamp,
                                             kernel_label(bwt, k, fused), args.stats_sample, lookup_depth(bwt, k), bwt.get_pair_index(),
                                             (not fused) and bwt.batch_order_for(k, per_launch_q), sparse=lookup_depth(bwt, k) == bwt.get_sparse_table() != 0)
@@ -1255,8 +1272,12 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         t0 = time.time()
-        child_args = (["--k", str(args.k)] if args.k else []) + (["--table-depth", str(args.table_depth)] if args.table_depth > -2 else [])
-        per_q, detail = live_pmc_traffic(child_args, 100_000_000)
+        child_args = ((["--k", str(args.k)] if args.k else []) + (["--table-depth", str(args.table_depth)] if args.table_depth > -2 else []) +
+                      (["--genome", args.genome] if args.genome != "random" else []))
+        if args.genome == "repeats":   # (a lab line whose index takes longer to build: the read pass only, the writes are the counts)
+            per_q, detail = live_pmc_traffic(child_args, 100_000_000, counters=("FETCH_SIZE",), patience=900)
+        else:
+            per_q, detail = live_pmc_traffic(child_args, 100_000_000)
         roof = result["roofline"]
         if per_q is None:
             roof["traffic_live"] = {"error": detail}

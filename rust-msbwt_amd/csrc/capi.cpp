@@ -436,7 +436,7 @@ int build_sparse(msbwt_rle *h, uint64_t keep_free, uint64_t allowance) {
     if (!chosen) {
         h->sparse_report = rep;  // (the distinct counts are worth keeping: msbwt_rle_sparse_table_info)
         if (verbose) std::fprintf(stderr, "[msbwt] sparse table: no depth fits %.2f GB -- none built\n", double(avail) / 1e9);
-        return explicit_depth ? fail(h, MSBWT_ERR_HIP, "no sparse table could be built") : MSBWT_OK;
+        return MSBWT_OK;
     }
     const uint64_t nside = rep.escapes[chosen];
     if (nside) {
@@ -2070,8 +2070,9 @@ int msbwt_sparse_table_shape(int depth, uint64_t entries, uint64_t *nbuckets, in
 
 size_t msbwt_rle_download_sparse_table(const msbwt_rle *ch, void *out_lines, size_t cap_bytes, void *out_side, size_t cap_side_bytes) {
     msbwt_rle *h = const_cast<msbwt_rle *>(ch);
-    if (!h || !h->loaded || !h->d_sparse) return SIZE_MAX;
+    if (!h) return SIZE_MAX;
     std::lock_guard<std::mutex> lock(h->mu);
+    if (!h->loaded || !h->d_sparse) return SIZE_MAX;
     DeviceScope scope(h->device);
     if (!scope.ok()) return SIZE_MAX;
     if (out_lines && cap_bytes >= h->sparse_bytes && hipMemcpy(out_lines, h->d_sparse, h->sparse_bytes, hipMemcpyDeviceToHost) != hipSuccess) return SIZE_MAX;

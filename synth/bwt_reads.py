@@ -235,3 +235,258 @@ def msbwt_rle(genome, cnt, read_len, log=None):
     rle, totals = out.finish()
     assert int(totals.sum()) == n_reads * (L + 1) and int(totals[DOLLAR]) == n_reads
     return rle, totals, n_reads
+
+
+# ---- the same for a genome WITH repeats ----------------------------------------------------------------------------------------
+# msbwt_rle above leans on the genome being random: 28 bases place a suffix.  A genome with repeat families, segmental duplications,
+# satellite arrays and microsatellites (synth.repeat_genome) shares stretches far longer than that, up to and beyond the read length.
+# What changes: (1) the genome positions are ordered by their first >= read_len bases (prefix doubling over the 31-mer ranks: 31 ->
+# 62 -> 124 -> 248 bases), not by 31; (2) with a[r] = the number of leading bases rank r shares with rank r - 1 (capped at read_len)
+# and c[r] = max(a[r], a[r + 1]), the rows (p, m) of rank r with m > max(c[r], 28) are still one run at r -- their strings are unique
+# -- while every row with m <= c[r] shares its string's bases with a neighbour and is placed EXPLICITLY, like the short rows: in front
+# of rank i = the first rank of the interval of positions that continue its m bases (the last rank <= r with a[i] < m), ordered there
+# by (m, r).  [Why (i, m, r) is the order: rows with different i compare like the genome suffixes at i; a row of m bases is a proper
+# prefix of everything in its interval that is longer, and '$' is the smallest symbol; equal strings may stand in any fixed order.]
+
+
+def repeat_read_set(genome_len, read_len, coverage, seed, device="cpu"):
+    """Like read_set, over synth.repeat_genome (human repeat classes at their own proportions, copy numbers scaled to the length):
+    bases 0..3 with read_len + 256 random spare bases at the end, and cnt[s] = reads starting at s."""
+    import torch
+    import synth
+    dev = torch.device(device)
+    codes = synth.repeat_genome(genome_len, seed)                      # symbol codes 1 2 3 5
+    base_of_code = np.array([0, 0, 1, 2, 0, 3], dtype=np.uint8)
+    n = genome_len + read_len + 256
+    genome = torch.empty(n, dtype=torch.uint8, device=dev)
+    step = 1 << 28
+    for lo in range(0, genome_len, step):
+        genome[lo:min(lo + step, genome_len)] = torch.from_numpy(base_of_code[codes[lo:lo + step]]).to(dev)
+    del codes
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    genome[genome_len:] = torch.randint(0, 4, (n - genome_len,), generator=gen, device=dev, dtype=torch.uint8)
+    cnt = torch.zeros(genome_len, dtype=torch.uint8, device=dev)
+    lam = coverage / read_len
+    for lo in range(0, genome_len, step):
+        m = min(step, genome_len - lo)
+        cnt[lo:lo + m] = torch.poisson(torch.full((m,), lam, device=dev, dtype=torch.float32), generator=gen).clamp_(max=255).to(torch.uint8)
+    return genome, cnt
+
+
+PAD_POSITIONS = 192   # positions behind the last suffix that are ordered along with the rest (they anchor nothing: no read reaches them)
+
+
+def _run_starts(torch, first):
+    """first[j]: element j opens a run (first[0] is set) -> for every element the index of its run's first element"""
+    starts = torch.nonzero(first).squeeze(1)
+    return starts[torch.cumsum(first.to(torch.int64), 0) - 1]
+
+
+def _common_bases(torch, x, y):
+    """leading bases two 31-mer keys share (0..31)"""
+    d = x ^ y
+    hi, lo = d >> 31, d & 0x7FFFFFFF
+    top = torch.where(hi > 0, hi, lo).to(torch.float64)
+    msb = torch.frexp(torch.clamp(top, min=1.0))[1].to(torch.int64) - 1 + torch.where(hi > 0, 31, 0)
+    return torch.where(d == 0, torch.full_like(msb, KEY_BASES), (2 * KEY_BASES - 1 - msb) >> 1)
+
+
+def msbwt_rle_repeats(genome, cnt, read_len, log=None):
+    """msbwt_rle for ANY genome: RLE bytes, symbol totals, number of reads.  genome: bases 0..3, at least
+    cnt.numel() + read_len + 1 + PAD_POSITIONS + 31 of them (repeat_read_set)."""
+    import torch
+    dev = genome.device
+    L = read_len
+    g = cnt.numel()
+    npos = g + L + 1                      # suffix start positions p = 0 .. g + L
+    N = npos + PAD_POSITIONS              # positions that are ordered
+    assert genome.numel() >= N + KEY_BASES and L > M_SHORT + 1 and L <= 5 * KEY_BASES
+    i64 = torch.int64
+    say = log or (lambda msg: None)
+
+    cntp = torch.zeros(N + L + 1, dtype=torch.uint8, device=dev)
+    cntp[L:L + g] = cnt
+    n_reads = int(cnt.sum(dtype=i64).item())
+    cp = torch.zeros(cntp.numel() + 1, dtype=torch.int32 if n_reads < 2**31 else i64, device=dev)
+    torch.cumsum(cntp, 0, dtype=cp.dtype, out=cp[1:])
+    codes = torch.tensor(CODE_OF_BASE, dtype=torch.uint8, device=dev)
+    prev = torch.empty(N, dtype=torch.uint8, device=dev)
+    prev[0] = codes[0]
+    prev[1:] = codes[genome[:N - 1].to(i64)]
+    key = genome[:N + KEY_BASES].to(i64)
+    have = 1
+    while have < KEY_BASES:
+        take = min(have, KEY_BASES - have)
+        nxt = key[have:have + (key.numel() - have)]
+        if take < have:
+            nxt = nxt >> (2 * (have - take))
+        key = (key[:nxt.numel()] << (2 * take)) | nxt
+        have += take
+    key = key[:N].contiguous()
+    say("keys of %d positions ready (%d reads)" % (N, n_reads))
+    shift_m = lambda m: 2 * (KEY_BASES - m)
+
+    # ---- the positions in the order of their first 31 bases, group by group (leading 3-mer) ----
+    top3 = (key >> shift_m(3)).to(torch.uint8)
+    sa_all = torch.empty(N, dtype=i64, device=dev)
+    rank = torch.empty(N, dtype=i64, device=dev)      # rank[p] = index in sa_all of the first position that equals p as far as compared
+    tied = torch.zeros(N, dtype=torch.bool, device=dev)  # per index of sa_all: its position still equals a neighbour
+    bounds = [0]
+    for grp in range(64):
+        idx = _nonzero(torch, top3 == grp)
+        n = idx.numel()
+        base = bounds[-1]
+        bounds.append(base + n)
+        if n == 0:
+            continue
+        ks, order = torch.sort(key[idx], stable=True)
+        sa = idx[order]
+        del idx, order
+        first = torch.ones(n, dtype=torch.bool, device=dev)
+        first[1:] = ks[1:] != ks[:-1]
+        start = _run_starts(torch, first)
+        last = torch.ones(n, dtype=torch.bool, device=dev)
+        last[:-1] = first[1:]
+        sa_all[base:base + n] = sa
+        rank[sa] = base + start
+        tied[base:base + n] = ~(first & last)
+        del ks, sa, first, last, start
+    del top3
+    say("31-mer order ready: %d positions equal a neighbour" % int(tied.sum().item()))
+
+    # ---- prefix doubling: ties are ordered by the rank of what follows (31 -> 62 -> 124 -> 248 bases >= read_len) ----
+    off = KEY_BASES
+    while off < L:
+        left = 0
+        for grp in range(64):
+            base, n = bounds[grp], bounds[grp + 1] - bounds[grp]
+            if n == 0:
+                continue
+            t = torch.nonzero(tied[base:base + n]).squeeze(1)
+            if t.numel() == 0:
+                continue
+            p = sa_all[base + t]
+            assert int(p.max().item()) + off < N, "a position in the padding equals another one: another seed, please"
+            k2 = ((rank[p] - base) << 32) | rank[p + off]
+            k2, perm = torch.sort(k2, stable=True)
+            p = p[perm]
+            sa_all[base + t] = p
+            m = t.numel()
+            first = torch.ones(m, dtype=torch.bool, device=dev)
+            first[1:] = k2[1:] != k2[:-1]
+            start = t[_run_starts(torch, first)]
+            last = torch.ones(m, dtype=torch.bool, device=dev)
+            last[:-1] = first[1:]
+            rank[p] = base + start
+            still = ~(first & last)
+            tied[base + t] = still
+            left += int(still.sum().item())
+            del t, p, k2, perm, first, last, start, still
+        off *= 2
+        say("order by %d bases ready: %d positions still equal a neighbour" % (min(off, 8 * KEY_BASES), left))
+    del rank, tied
+
+    out = _RunWriter(torch)
+
+    def level_rows(m):
+        p = _nonzero(torch, cntp[m:m + npos])
+        k, order = torch.sort(key[p], stable=True)
+        p = p[order]
+        return k, prev[p], cntp[p + m].to(i64)
+
+    low = [level_rows(m) for m in range(3)]
+    say("levels 0-2 sorted")
+
+    def low_segment(m, prefix):
+        k, sym, mult = low[m]
+        lo = int(torch.searchsorted(k, torch.tensor([prefix << shift_m(m)], dtype=i64, device=dev))[0].item()) if m else 0
+        hi = int(torch.searchsorted(k, torch.tensor([(prefix + 1) << shift_m(m)], dtype=i64, device=dev))[0].item()) if m else k.numel()
+        return sym[lo:hi], mult[lo:hi]
+
+    out.add(*low_segment(0, 0))
+    explicit_long = 0
+    for grp in range(64):
+        if grp % 16 == 0:
+            out.add(*low_segment(1, grp // 16))
+        if grp % 4 == 0:
+            out.add(*low_segment(2, grp // 4))
+        base, n = bounds[grp], bounds[grp + 1] - bounds[grp]
+        if n == 0:
+            continue
+        sa = sa_all[base:base + n]
+        ks = key[sa]
+        # a[r]: leading bases shared with the rank before (0 for the first of a group: another leading 3-mer), capped at L
+        a = torch.zeros(n, dtype=i64, device=dev)
+        a[1:] = _common_bases(torch, ks[1:], ks[:-1])
+        deep = torch.nonzero(a == KEY_BASES).squeeze(1)
+        for t in range(KEY_BASES, L, KEY_BASES):
+            if deep.numel() == 0:
+                break
+            more = _common_bases(torch, key[sa[deep] + t], key[sa[deep - 1] + t])
+            a[deep] += more
+            deep = deep[more == KEY_BASES]
+        a.clamp_(max=L)
+        c = a.clone()
+        c[:-1] = torch.maximum(c[:-1], a[1:])
+        lo_m = c.clamp(min=M_SHORT)                              # rows with m <= lo_m are placed explicitly
+        wlong = (cp[sa + L] - cp[sa + torch.clamp(lo_m + 1, max=L)]).to(i64)   # rows with lo_m < m < L
+        dollars = torch.where(c >= L, torch.zeros_like(c), cntp[sa + L].to(i64))
+        keys, jl, mu, sy = [], [], [], []
+        k28 = ks >> shift_m(M_SHORT)
+        for m in range(3, M_SHORT + 1):
+            cm = cntp[sa + m]
+            nz = torch.nonzero(cm).squeeze(1)
+            if nz.numel() == 0:
+                continue
+            pre = (k28[nz] >> (2 * (M_SHORT - m))) << (2 * (M_SHORT - m))   # first m bases, padded with 'A'
+            ins = torch.searchsorted(k28, pre, right=False)                 # the first rank that continues them
+            keys.append((ins << 8) | m)
+            jl.append(nz)
+            mu.append(cm[nz].to(i64))
+            sy.append(prev[sa[nz]])
+        rep = torch.nonzero(c > M_SHORT).squeeze(1)              # ranks inside repeats: more levels are explicit
+        if rep.numel():
+            a_rep, c_rep, p_rep = a[rep], c[rep], sa[rep]
+            for m in range(M_SHORT + 1, int(c_rep.max().item()) + 1):
+                sel = torch.nonzero((c_rep >= m) & (cntp[p_rep + m] > 0)).squeeze(1)
+                if sel.numel() == 0:
+                    continue
+                # the interval of the m bases starts at the last rank at or before r that shares fewer than m bases with its predecessor
+                # -- itself a member of `rep` (its successor shares m with it), as is the first of `rep` (c of its predecessor <= 28)
+                breaks = torch.nonzero(a_rep < m).squeeze(1)
+                start = breaks[torch.searchsorted(breaks, sel, right=True) - 1]
+                keys.append((rep[start] << 8) | m)
+                jl.append(rep[sel])
+                mu.append(cntp[p_rep[sel] + m].to(i64))
+                sy.append(prev[p_rep[sel]] if m < L else torch.full((sel.numel(),), DOLLAR, dtype=torch.uint8, device=dev))
+                explicit_long += int(sel.numel())
+            del a_rep, c_rep, p_rep
+        if keys:
+            keys, perm = torch.sort(torch.cat(keys), stable=True)   # (i, m), then r as generated
+            mu, sy = torch.cat(mu)[perm], torch.cat(sy)[perm]
+            ins = keys >> 8
+            r = keys.numel()
+            del jl, perm
+        else:
+            mu = ins = torch.zeros(0, dtype=i64, device=dev)
+            sy = torch.zeros(0, dtype=torch.uint8, device=dev)
+            r = 0
+        arange_n = torch.arange(n, dtype=i64, device=dev)
+        pile_at = 2 * arange_n + torch.searchsorted(ins, arange_n, right=True)
+        short_at = torch.arange(r, dtype=i64, device=dev) + 2 * ins
+        sym = torch.empty(r + 2 * n, dtype=torch.uint8, device=dev)
+        length = torch.empty(r + 2 * n, dtype=i64, device=dev)
+        sym[short_at] = sy
+        length[short_at] = mu
+        sym[pile_at] = prev[sa]
+        length[pile_at] = wlong
+        sym[pile_at + 1] = DOLLAR
+        length[pile_at + 1] = dollars
+        out.add(sym, length)
+        if grp % 8 == 7:
+            say("group %d of 64 done" % (grp + 1))
+    rle, totals = out.finish()
+    say("%d rows above %d bases were placed one by one" % (explicit_long, M_SHORT))
+    assert int(totals.sum()) == n_reads * (L + 1) and int(totals[DOLLAR]) == n_reads
+    return rle, totals, n_reads

@@ -140,6 +140,57 @@ def test_exact_bwt_of_a_read_set_without_suffix_sorting_the_reads(g, L, cov, see
     assert (got >= covering).all() and (got == covering).mean() > 0.9
 
 
+def _crafted_repeat_genome(g, L, seed):
+    """random bases with exact copies far longer than a read, (AC)n, a homopolymer, an exact tandem array, a copy near the end"""
+    rng = np.random.default_rng(seed)
+    G = rng.integers(0, 4, size=g + L + 256).astype(np.uint8)
+    seg = rng.integers(0, 4, size=700).astype(np.uint8)
+    for at in (300, 1500, 2900, 3700):
+        G[at:at + 700] = seg
+    G[4500:4800] = np.tile(np.array([0, 1], dtype=np.uint8), 150)
+    G[4900:4990] = 2
+    G[5100:5100 + 37 * 12] = np.tile(rng.integers(0, 4, size=37).astype(np.uint8), 12)
+    G[g - 200:g - 20] = seg[:180]
+    return G
+
+
+@pytest.mark.parametrize("kind,g,L,cov,seed", [("families", 40000, 60, 15, 2), ("families", 60000, 150, 20, 4), ("crafted", 6000, 40, 12, 5),
+                                               ("crafted", 7000, 150, 30, 6)])
+def test_exact_bwt_of_a_read_set_from_a_genome_with_repeats(kind, g, L, cov, seed):
+    """synth/bwt_reads.py msbwt_rle_repeats (bench.py --genome repeats: the human-scale index over synth.repeat_genome) against the
+    suffix-sorting builder on the same reads: stretches shared beyond 28 bases, beyond the read length, tandem arrays, homopolymers --
+    same symbol totals, the same count for every k-mer tried around every depth the builder treats differently."""
+    import torch
+    from synth import bwt_reads
+    from oracle import oracle as orc
+    if kind == "families":
+        genome, cnt = bwt_reads.repeat_read_set(g, L, cov, seed)
+    else:
+        genome = torch.from_numpy(_crafted_repeat_genome(g, L, seed))
+        cnt = torch.from_numpy(np.random.default_rng(seed).poisson(cov / L, size=g).clip(max=255).astype(np.uint8))
+    notes = []
+    rle, totals, nreads = bwt_reads.msbwt_rle_repeats(genome, cnt, L, log=notes.append)
+    assert any("placed one by one" in m and not m.startswith("0 ") for m in notes)      # the genome did exercise the explicit levels
+    reads = bwt_reads.reads_of(genome, cnt, L)
+    true = synth.rle_encode(synth.build_msbwt_symbols(reads))
+    a, b = orc.OracleRleBWT(), orc.OracleRleBWT()
+    a.load_vector(rle)
+    b.load_vector(true)
+    assert a.get_total_size() == b.get_total_size() == nreads * (L + 1)
+    assert [a.get_symbol_count(s) for s in range(6)] == [b.get_symbol_count(s) for s in range(6)] == [int(t) for t in totals]
+    for k in (1, 2, 3, 4, 8, 17, 27, 28, 29, 30, 31, 32, 33, 40, 59, 60, 61, 62, 63, 93, 124, 125, L - 1, L):
+        if k > L:
+            continue
+        q = np.concatenate([synth.read_kmers(reads, k, limit=4000, seed=k), synth.random_kmers(300, k, seed + k)])
+        assert np.array_equal(a.count_kmers(q), b.count_kmers(q)), k
+    # the random-genome builder and this one agree where the former applies
+    g2, c2 = bwt_reads.read_set(3000, L, cov, seed)
+    g2 = torch.cat([g2, torch.randint(0, 4, (256,), dtype=torch.uint8, generator=torch.Generator().manual_seed(seed + 1000))])
+    r1, t1, n1 = bwt_reads.msbwt_rle(g2, c2, L)
+    r2, t2, n2 = bwt_reads.msbwt_rle_repeats(g2, c2, L)
+    assert n1 == n2 and np.array_equal(t1, t2) and np.array_equal(r1, r2)
+
+
 def test_histogram_stream_follows_the_measured_run_lengths():
     """synth.rle_stream(histogram=...): the independent-symbol stand-in draws (symbol, run length) from the committed histogram
     of config C4's real MSBWT (synth/c4_run_histogram.json): exact symbol total, no two neighbouring runs of
