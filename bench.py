@@ -19,7 +19,9 @@ geometric select the independent-symbol stand-ins of rounds 1-2) -- and 3e8 PRES
                  were freed and rebuilt: launches on a C4-sized index run in one of two modes 15 % apart, decided by the memory
                  the pair blocks were given (DESIGN.md section 5) -- a ratio far from 1 says the line was measured in the other one;
   c4_real_reads  the same on the random genome of rounds 2-3.
-Other workloads: c2, c3 (--fused = configs[2]), c4, big.
+Other workloads: c2, c3 (--fused = configs[2]), c4, big.  --genome repeats: the default index over a genome WITH repeats
+(synth.repeat_genome at 2.98e9 bp: the human repeat classes at human copy numbers; exact MSBWT by synth/bwt_reads.py msbwt_rle_repeats)
+-- a lab line beside the metric's, profiles/r05_lab/human_repeats.json.
 
 --gpus N: one rank per GPU.  Launched plainly (no torchrun) the script starts torch.distributed.run
 itself as a child process and relays its JSON line.  The index is replicated; ONE fixed batch is
@@ -919,8 +921,9 @@ def main():
     elif exact_bwt:
         wl = ("%s: EXACT multi-string BWT of %d error-free synthetic %d-bp reads (%.0fx of a random %d-bp genome; built on the GPU from the genome's "
               "suffix order, synth/bwt_reads.py), %d symbols; %d %s %d-mers per step.  The genome is REPEAT-FREE and the reads carry no errors: what "
-              "repeat families and read errors do to this path at the largest exact size that can be built here is in `c4_repeats` (cost by copy "
-              "number: its `copy_number_bins`)"
+              "repeat families and read errors do to this path is in `c4_repeats` (a real MSBWT of reads with errors; cost by copy number: its "
+              "`copy_number_bins`) and, at THIS size with human copy numbers, in the lab line `bench.py --genome repeats` "
+              "(profiles/r05_lab/human_repeats.json: 7.12e9 q/s at the same 0.72 of the HBM peak)"
               % (args.workload, n_reads_total, read_len, coverage, genome_len, total, nq, kind_text, k))
     elif big:
         wl = ("%s: structure-equivalent synthetic RLE stream (NOT a real BWT; 30x-human-scale stand-in), %d symbols, run lengths %s; "
