@@ -764,6 +764,37 @@ def main():
     lo, hi, cap = shard(nq)
     mine_n = hi - lo
     telemetry_before = telemetry()
+    def copy_number_bins(the_bwt, d_batch, d_batch_counts, kk, ranges, want_b=10_000_000):
+        """What a k-mer costs by COPY NUMBER: sub-batches of a line's own queries picked by their count in the read set, each timed
+        (5 steps) and counted by the kernel's own counters.  -> (record, counts equal the main run's)"""
+        bins, ok = [], True
+        for lo_c, hi_c in ranges:
+            ids = torch.nonzero((d_batch_counts >= lo_c) & (d_batch_counts < hi_c)).flatten()
+            have_b = int(ids.numel())
+            head = {"count_from": lo_c, "count_below": None if hi_c > 10**12 else hi_c, "queries_in_batch": have_b}
+            if have_b < 1000:
+                bins.append(head)
+                continue
+            pick = ids[torch.randint(0, have_b, (want_b,), device=dev, generator=torch.Generator(device=dev).manual_seed(lo_c))] if have_b < want_b else ids[:want_b]
+            d_qb = d_batch[pick].contiguous()
+            bb = Batch(the_bwt, d_qb, 0, None, kk)
+            saved = args.steps
+            args.steps = min(args.steps, 5)
+            try:
+                ob, _, elb, kmsb, _, _ = measure(bb, 0, want_b, want_b)
+                cb = counted_pass(the_bwt, bb, 0, want_b, want_b)
+                same = bool(torch.equal(ob, d_batch_counts[pick]))
+                bins.append(dict(head, queries_timed=want_b, value=want_b * args.steps / elb, ms_per_step=elb / args.steps * 1e3, kernel_ms=kmsb,
+                                 lines_per_query=cb["lines_per_query"], second_line_rate=cb["second_line_rate"], escape_query_fraction=cb["escape_query_fraction"],
+                                 steps_per_searched_query=cb.get("steps_per_searched_query"), mean_count=float(ob.float().mean().item()), counts_equal_main_run=same))
+                ok = ok and same
+            finally:
+                args.steps = saved
+            del d_qb, ob, pick, ids
+        return {"bins": bins, "note": "sub-batches of the line's own queries by their count in the read set (10^7 queries each, sampled with repetition "
+                                      "where the batch holds fewer), each timed over 5 steps and counted by the kernel's own counters; their counts are "
+                                      "those of the main run, whose parity sample the oracle checks"}, ok
+
     d_out, d_all, elapsed, kernel_ms, launches, narrow = measure(main_batch, lo, hi, cap)
     telemetry_after, telemetry_during = telemetry(), dict(last_sampled)
     # cross-rank consistency: a failed check does not abort the run (a crashed rank leaves no record at all); it is
@@ -778,6 +809,10 @@ def main():
     job_queries = nq if (strong or not multi) else nq * world
     value = job_queries * args.steps / elapsed
     d_counts = stitch(d_all, d_out, nq, cap)
+    # the repeat-genome lab line: what a k-mer costs by copy number AT THIS SIZE (human copy numbers: 10^5 and more occurrences)
+    main_bins = None
+    if exact_bwt and args.genome == "repeats" and not multi and d_q is not None:
+        main_bins, main_bins_ok = copy_number_bins(bwt, d_q, d_counts, k, ((1, 100), (100, 1000), (1000, 10_000), (10_000, 100_000), (100_000, 1_000_000), (1_000_000, 1 << 62)))
 
     # per-rank view of the timed region: the count kernel alone (HIP events on the launch stream), and the exchange
     # step alone (the same all_gather + widening, timed without kernels) -- so that a sub-linear curve can be read
@@ -980,6 +1015,11 @@ def main():
                                    "of the main line ran, and snapshots right before and after; the extra lines carry their own"}
     if counters is not None:
         result["search_counters"] = counters
+    if main_bins is not None:
+        result["copy_number_bins"] = main_bins
+        if not main_bins_ok:
+            log("PARITY FAILURE: a copy-number sub-batch counts differently from the main run")
+            result["value"] = None
     if sorted_batch is not None:
         result["sorted_batch"] = sorted_batch
         if not sorted_batch["counts_equal_unordered_run"]:
@@ -1159,35 +1199,11 @@ def main():
             # that occur 1-99, 100-999, 1 000-9 999 and >= 10 000 times in the read set (a young-SINE or satellite 31-mer occurs tens of
             # thousands of times here; at human scale copy numbers are another ~50 x higher), each timed and counted on its own.
             if cfg4.get("repeats"):
-                bins = []
-                for lo_c, hi_c in ((1, 100), (100, 1000), (1000, 10_000), (10_000, 1 << 62)):
-                    ids = torch.nonzero((o4 >= lo_c) & (o4 < hi_c)).flatten()
-                    have_b = int(ids.numel())
-                    if have_b < 1000:
-                        bins.append({"count_from": lo_c, "count_below": None if hi_c > 10**9 else hi_c, "queries_in_batch": have_b})
-                        continue
-                    want_b = 10_000_000
-                    pick = ids[torch.randint(0, have_b, (want_b,), device=dev, generator=torch.Generator(device=dev).manual_seed(lo_c))] if have_b < want_b else ids[:want_b]
-                    d_qb = d_q4[pick].contiguous()
-                    bb = Batch(bwt4, d_qb, 0, None, 31)
-                    saved = args.steps
-                    args.steps = min(args.steps, 5)
-                    ob, _, elb, kmsb, _, _ = measure(bb, 0, want_b, want_b)
-                    cb = counted_pass(bwt4, bb, 0, want_b, want_b)
-                    entry = {"count_from": lo_c, "count_below": None if hi_c > 10**9 else hi_c, "queries_in_batch": have_b, "queries_timed": want_b,
-                             "value": want_b * args.steps / elb, "ms_per_step": elb / args.steps * 1e3, "kernel_ms": kmsb,
-                             "lines_per_query": cb["lines_per_query"], "second_line_rate": cb["second_line_rate"], "escape_query_fraction": cb["escape_query_fraction"],
-                             "mean_count": float(ob.float().mean().item()), "counts_equal_main_run": bool(torch.equal(ob, o4[pick]))}
-                    args.steps = saved
-                    if not entry["counts_equal_main_run"]:
-                        log("PARITY FAILURE on %s: a copy-number sub-batch counts differently from the main run" % key)
-                        result["value"] = None
-                        rc = 1
-                    bins.append(entry)
-                    del d_qb, ob, pick, ids
-                line["copy_number_bins"] = {"bins": bins, "note": "sub-batches of the line's own read-derived 31-mers by their count in the read set (10^7 queries each, "
-                                                                  "sampled with repetition where the batch holds fewer), each timed over 5 steps and counted by the kernel's own "
-                                                                  "counters; their counts are those of the main run, whose parity sample the oracle checks"}
+                line["copy_number_bins"], bins_ok = copy_number_bins(bwt4, d_q4, o4, 31, ((1, 100), (100, 1000), (1000, 10_000), (10_000, 1 << 62)))
+                if not bins_ok:
+                    log("PARITY FAILURE on %s: a copy-number sub-batch counts differently from the main run" % key)
+                    result["value"] = None
+                    rc = 1
             # Which of this line's two modes the build is in (the time of a launch on a C4-sized index follows the physical
             # memory its pair blocks were given, 15 % apart): the pair blocks (+ table) rebuilt once, the same batch timed again -- a slow
             # line can then be told from a regression by its own record.
