@@ -150,6 +150,44 @@ def test_stream_beyond_2_pow_33_symbols_hbm_regime():
     assert int(gl.max()) > 2**32
 
 
+def test_repeat_genome_read_set_built_on_the_gpu_and_counted():
+    """bench.py --genome repeats in small: a 4e6-bp genome with the human repeat classes (synth.repeat_genome), 30x error-free reads,
+    its exact MSBWT built by synth/bwt_reads.py msbwt_rle_repeats ON THE GPU -- the same bytes as the CPU build of the same tensors --
+    loaded, and read-derived / walked / random k-mers counted against the oracle: high-copy k-mers (counts in the thousands), wide
+    sparse-table entries in the side array, second lines at every step."""
+    from synth import bwt_reads
+    torch, dev = _torch()
+    L = 150
+    genome, cnt = bwt_reads.repeat_read_set(4_000_000, L, 30.0, 5)
+    rle_cpu, totals, n_reads = bwt_reads.msbwt_rle_repeats(genome, cnt, L)
+    rle, totals_gpu, n_gpu = bwt_reads.msbwt_rle_repeats(genome.to(dev), cnt.to(dev), L)
+    assert n_gpu == n_reads and np.array_equal(totals, totals_gpu) and np.array_equal(rle, rle_cpu)
+    total = int(totals.sum())
+    bwt = RleBWT(device=0)
+    bwt.load_vector(rle)
+    ref = orc.OracleRleBWT()
+    ref.load_vector(rle)
+    assert bwt.get_total_size() == ref.get_total_size() == total == n_reads * (L + 1)
+    assert bwt.get_sparse_table() >= 19
+    info = bwt.sparse_table_info()
+    assert info["side_entries"] > 0          # suffixes of high-copy repeats: 255 or more wide
+    sys.path.insert(0, ROOT)
+    import bench
+    for k in (23, 31, 59):
+        walked = bench.walk_kmers(torch, np, bwt, dev, total, 300_000, k, 11 + k)      # drawn like read windows: repeats over-represented
+        d_q = torch.cat([walked, bench.device_random_kmers(torch, dev, 0, 50_000, k, 3 + k)])
+        exp = ref.count_kmers(d_q.cpu().numpy(), nthreads=NCPU)
+        assert exp[:300_000].min() >= 1 and exp.max() > 1000
+        for mode in ("lanes", "groups"):
+            bwt.set_search_kernel(mode)
+            got = _count_matrix(torch, dev, bwt, d_q).cpu().numpy().astype(np.uint64)
+            assert np.array_equal(got, exp), (k, mode)
+    bwt.set_search_kernel("auto")
+    # a whole read as the query: as many occurrences as reads spell it
+    reads = bwt_reads.reads_of(genome[:200_000 + L], cnt[:200_000], L)[:20_000]
+    assert np.array_equal(bwt.count_kmers(reads), ref.count_kmers(reads, nthreads=NCPU))
+
+
 def test_human_scale_9e10_symbols_against_the_oracle():
     """The size and the index the metric is quoted on: the exact MSBWT of 5.96e8 error-free reads, 9e10 symbols (positions
     beyond 2^36, 40-bit header counts with high bytes up to 20, the full index: sparse suffix table of depth 23 -- and, with it switched off, the 238 GB index of
