@@ -132,6 +132,7 @@ def parse_args(argv=None):
     ap.add_argument("--query-kind", default="", choices=["", "random", "reads", "walk"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the index (tests)")
     ap.add_argument("--table-depth", type=int, default=-2, help="-2 = library default")
+    ap.add_argument("--sparse-depth", type=int, default=-2, help="msbwt_rle_set_sparse_table before the load: 0 = off, 16..28 = that depth (default: the library's automatic choice)")
     ap.add_argument("--blocks", default="planes", choices=["planes", "runs"],
                     help="index block format: planes (default) or the memory-lean run blocks (no pair index)")
     ap.add_argument("--fused", action="store_true",
@@ -512,6 +513,8 @@ def main():
     bwt.set_block_format(args.blocks)
     if args.table_depth > -2:
         bwt.set_table_depth(args.table_depth)
+    if args.sparse_depth > -2:
+        bwt.set_sparse_table(args.sparse_depth)
     if args.no_table_side:
         bwt.set_table_side(0)
     t0 = time.time()
@@ -1292,6 +1295,7 @@ def main():
         torch.cuda.empty_cache()
         t0 = time.time()
         child_args = ((["--k", str(args.k)] if args.k else []) + (["--table-depth", str(args.table_depth)] if args.table_depth > -2 else []) +
+                      (["--sparse-depth", str(args.sparse_depth)] if args.sparse_depth > -2 else []) +
                       (["--genome", args.genome] if args.genome != "random" else []))
         if args.genome == "repeats":   # (a lab line whose index takes longer to build: the read pass only, the writes are the counts)
             per_q, detail = live_pmc_traffic(child_args, 100_000_000, counters=("FETCH_SIZE",), patience=900)

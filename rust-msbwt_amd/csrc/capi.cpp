@@ -125,6 +125,7 @@ constexpr uint64_t kStreamLinesFrom = uint64_t(4) << 30;  // random-access array
 constexpr size_t kStatusBytes = 1024;  // flag words, debug record (bytes 64..128), search counters (bytes 128..256)
 constexpr size_t kCountersOffset = 128;
 static_assert(MSBWT_SEARCH_COUNTERS == kSearchCounters, "the header's counter block is the kernels'");
+static_assert(10 + kSparseMaxDepth + 1 <= 45 && 45 + kSparseMaxDepth + 1 <= MSBWT_SPARSE_INFO_WORDS, "msbwt_rle_sparse_table_info: [10 + d] distinct, [45 + d] wide");
 constexpr size_t kPackScratchOffset = 256;  // two u64 of the table packer (escape-line count, side-array cursor)
 constexpr size_t kMaxTimedEvents = 256;  // start/stop pairs kept before timed_launch folds them into the running sum
 constexpr int kHostFlags = 0, kDeviceFlags = 1;  // words of the status block
@@ -2040,7 +2041,7 @@ int msbwt_rle_sparse_table_info(const msbwt_rle *ch, uint64_t *out) {
     out[7] = uint64_t(r.parent_depth);
     for (int d = 0; d <= kSparseMaxDepth; ++d) {
         out[10 + d] = r.distinct[d];
-        out[10 + kSparseMaxDepth + 1 + d] = r.escapes[d];
+        out[45 + d] = r.escapes[d];
     }
     return MSBWT_OK;
 }
@@ -2049,7 +2050,7 @@ int msbwt_sparse_hash(uint64_t key, int depth, uint64_t nbuckets, uint32_t *buck
     if (depth < kSparseMinDepth || depth > kSparseMaxDepth || nbuckets == 0 || nbuckets > 0xFFFFFFFFull || !bucket || !tag) return MSBWT_ERR_INVALID_ARG;
     const uint64_t x = sparse_mix(key, uint32_t(2 * depth));
     *bucket = sparse_bucket(x, uint32_t(2 * depth), uint32_t(nbuckets));
-    *tag = sparse_tag(x);
+    *tag = sparse_tag(x, uint32_t(depth));
     return MSBWT_OK;
 }
 

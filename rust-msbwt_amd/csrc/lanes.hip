@@ -318,6 +318,29 @@ __device__ __forceinline__ bool sparse_scan(const uint4 *lines, uint32_t slot, u
     return true;
 }
 
+// The WIDE layout of depths 25..28 (sparse_table.hpp): 12 entries, the tag is the whole word, the width a byte of its own.
+__device__ __forceinline__ bool sparse_scan_wide(const uint4 *lines, uint32_t slot, uint32_t want, uint64_t &l, uint32_t &width, uint32_t &header) {
+    const uint32_t base = line_base(slot), g = slot & 7u;
+    const uint4 c0 = lines[base + (0u ^ g)], c1 = lines[base + (1u ^ g)], c2 = lines[base + (2u ^ g)];
+    const uint32_t tags[kSparseWideSlots] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w};
+    uint32_t hit = kSparseWideSlots;
+#pragma unroll
+    for (int i = int(kSparseWideSlots) - 1; i >= 0; --i) hit = tags[i] == want ? uint32_t(i) : hit;  // the lowest matching slot: an entry beats an empty slot
+    header = lines[base + (7u ^ g)].w >> 16;
+    width = 0;
+    if (hit >= kSparseWideSlots) return false;
+    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(lines);
+    const uint32_t wb = kSparseWideWidthByte + hit, hb = kSparseWideHiByte + hit;
+    width = bytes[(base + ((wb >> 4) ^ g)) * 16u + (wb & 15u)];
+    if (width == 0u) return false;  // an empty slot (a key whose tag is 0 matches it)
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(lines);
+    const uint32_t word = kSparseWideL0Word + hit;
+    const uint32_t lo = words[(base + ((word >> 2) ^ g)) * 4u + (word & 3u)];
+    const uint32_t hi = bytes[(base + ((hb >> 4) ^ g)) * 16u + (hb & 15u)];
+    l = (uint64_t(hi) << 32) | lo;
+    return true;
+}
+
 // kPacked (matrix mode only): the queries come as 2-bit words (QuerySource::packed), possibly with a place for each count.
 // A compile-time switch, not a launch-uniform branch: with both ways of fetching a tile in one kernel the compiler merged
 // their results through register copies, i.e. WAITED for the tile's bytes right after asking for them -- setup no longer
@@ -361,6 +384,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     // stream).  Round 5, human scale, alternating on one box: 38.4 ms (36.7-39.8) by default, 36.1 ms (35.6-36.6) streaming; C3 fused,
     // whose pair blocks half live in the Infinity Cache, 14.9 -> 19.8 ms -- hence a launch-uniform switch, not a constant.
     const bool stream_lines = (table_packed & 2u) != 0u;
+    // the sparse table's layout follows its depth (launch-uniform): 14 entries with 24-bit tags up to depth 24, 12 with 32-bit tags beyond
+    const bool sparse_wide_layout = kSparse && sparse_wide(depth);
+    const uint32_t sparse_nslots = sparse_slots(depth);
+    auto scan_bucket = [&](uint32_t slot, uint32_t want, uint64_t &tl, uint32_t &tw, uint32_t &header) -> bool {
+        return sparse_wide_layout ? sparse_scan_wide(ws.lines, slot, want, tl, tw, header) : sparse_scan(ws.lines, slot, want, tl, tw, header);
+    };
     // optional search counters (kernels.hpp, SearchCounter): wave sums kept in LDS, added to the caller's block at the end
     const bool counting = kCounting && counters != nullptr;
     if (counting && lane < uint32_t(kSearchCounters)) ws.cnt[lane] = 0u;
@@ -698,7 +727,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                         if constexpr (kSparse) {  // nothing to fetch here: the bucket line is the query's first search step
                             const uint64_t x = sparse_mix(pq.tidx, 2u * depth);
                             prep_entry.x = sparse_bucket(x, 2u * depth, sparse_nbuckets);
-                            prep_entry.y = sparse_tag(x);
+                            prep_entry.y = sparse_tag(x, depth);
                             prep_entry.z = 0u;  // buckets gone beyond its own
                             prep_kind = 3;
                         } else {
@@ -843,11 +872,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             if (riding) {
                 uint64_t tl = 0;
                 uint32_t tw = 0, header = 0;
-                if (sparse_scan(ws.lines, slot_ride, prep_entry.y, tl, tw, header)) {
+                if (scan_bucket(slot_ride, prep_entry.y, tl, tw, header)) {
                     prep_entry.x = uint32_t(tl);
                     prep_entry.y = uint32_t(tl >> 32) | (tw << 8);
                     prep_kind = 4;
-                } else if (header > kSparseSlots && prep_entry.z < sparse_probe) {  // entries of this bucket were displaced: the next one, next time
+                } else if (header > sparse_nslots && prep_entry.z < sparse_probe) {  // entries of this bucket were displaced: the next one, next time
                     ++prep_entry.x;
                     ++prep_entry.z;
                 } else {  // a miss in a complete table: the suffix does not occur (msbwt_core.rs:151-153)
@@ -866,7 +895,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             if (kSparse && looking) {  // this step fetched the query's own bucket
                 uint64_t tl = 0;
                 uint32_t width = 0, header = 0;
-                const bool hit = sparse_scan(ws.lines, slot_l, uint32_t(h), tl, width, header);
+                const bool hit = scan_bucket(slot_l, uint32_t(h), tl, width, header);
                 nl = nh = 0;
                 step_done = false;
                 if (hit) {
@@ -882,7 +911,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                         store_count<kReads>(src, qid, h - l);
                         have = false;
                     }
-                } else if (header > kSparseSlots && tdist < sparse_probe) {  // entries of this bucket were displaced: the next one
+                } else if (header > sparse_nslots && tdist < sparse_probe) {  // entries of this bucket were displaced: the next one
                     ++l;
                     ++tdist;
                 } else {  // a miss in a complete table: the suffix does not occur (msbwt_core.rs:151-153)

@@ -29,7 +29,7 @@ inline SparseChoice choose_sparse_depth(const uint64_t *distinct, const uint64_t
     SparseChoice none;
     for (int d = std::min(max_depth, kSparseMaxDepth); d >= kSparseMinDepth && d > parent_depth; --d) {
         if (explicit_depth ? d != explicit_depth : distinct[d] == 0) continue;  // not a level of the pass (the other parity), or nothing occurs
-        const uint64_t needed = uint64_t(double(distinct[d]) / kSparseLoad) + 1, nb = sparse_buckets_for(d, distinct[d]);
+        const uint64_t needed = uint64_t(double(distinct[d]) / sparse_load(d)) + 1, nb = sparse_buckets_for(d, distinct[d]);
         const uint64_t lines = nb + kSparseMaxProbe;
         if (lines > 0xFFFFFFFFull) continue;
         if (!explicit_depth && sparse_min_buckets(d) > std::max<uint64_t>(16 * needed, 65536)) continue;

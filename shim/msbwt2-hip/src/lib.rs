@@ -63,7 +63,7 @@ extern "C" {
                                     out_counts: *mut c_void, count_bits: c_int) -> c_int;
     // HBM the index may hold (0 = no budget): the space / time knob, as bin_power is the reference's
     fn msbwt_rle_set_memory_budget(bwt: *mut MsbwtRle, bytes: u64) -> c_int;
-    // sparse suffix table (round 5): ranges of the suffixes that occur, depth 16..24 (-1 = automatic, 0 = off); info = 64 u64 words
+    // sparse suffix table (round 5): ranges of the suffixes that occur, depth 16..28 (-1 = automatic, 0 = off); info = 80 u64 words
     fn msbwt_rle_set_sparse_table(bwt: *mut MsbwtRle, depth: c_int) -> c_int;
     fn msbwt_rle_get_sparse_table(bwt: *const MsbwtRle) -> c_int;
     fn msbwt_rle_sparse_table_info(bwt: *const MsbwtRle, out: *mut u64) -> c_int;
@@ -184,7 +184,7 @@ impl GpuRleBWT {
 
     /// Depth of the sparse suffix table in HBM (0 = none) and how many distinct suffixes of that length occur.
     pub fn sparse_table(&self) -> (i32, u64) {
-        let mut info = [0u64; 64];
+        let mut info = [0u64; 80];
         let rc = unsafe { msbwt_rle_sparse_table_info(self.raw, info.as_mut_ptr()) };
         if rc != MSBWT_OK { panic!("sparse_table_info: {}", self.last_error()); }
         (unsafe { msbwt_rle_get_sparse_table(self.raw) }, info[1])

@@ -73,24 +73,36 @@ def host_lookup(lines, side, info, key):
     b, tag = C.c_uint32(), C.c_uint32()
     assert _lib.lib().msbwt_sparse_hash(int(key), info["depth"], info["buckets"], C.byref(b), C.byref(tag)) == 0
     bucket = b.value
+    wide = info["depth"] >= 25           # sparse_table.hpp: 12 entries with 32-bit tags and a width byte of their own
+    nslots = 12 if wide else 14
     for dist in range(info["probe"] + 1):
         line = lines[bucket + dist]
         raw = line.view(np.uint8)
-        for slot in range(14):
+        for slot in range(nslots):
             t = int(line[slot])
-            if (t >> 24) != 0 and (t & 0xFFFFFF) == tag.value:
+            if wide:
+                width, hit = int(raw[108 + slot]), t == tag.value
+                lo = int(line[12 + slot]) | (int(raw[96 + slot]) << 32)
+            else:
+                width, hit = t >> 24, (t & 0xFFFFFF) == tag.value
                 lo = int(line[14 + slot]) | (int(raw[112 + slot]) << 32)
-                width = t >> 24
+            if width != 0 and hit:
                 if width == 255:
                     return int(side[lo][0]), int(side[lo][1])
                 return lo, lo + width
         header = int(raw[126]) | (int(raw[127]) << 8)
-        if header <= 14:
+        if header <= nslots:
             return None
     return None
 
 
-@pytest.mark.parametrize("depth", [16, 17, 20])
+def slots_in_use(lines, info):
+    if info["depth"] >= 25:
+        return int((lines.view(np.uint8).reshape(len(lines), 128)[:, 108:120] != 0).sum())
+    return int(((lines[:, :14] >> 24) != 0).sum())
+
+
+@pytest.mark.parametrize("depth", [16, 17, 20, 25, 27, 28])
 def test_every_entry_of_the_table_is_the_oracles_range(depth, monkeypatch):
     reads = read_set(11, 3000, 700, 60, repeats=4, err=0.01)
     b, ref = load_pair(bwt_of(reads), monkeypatch, depth)
@@ -110,7 +122,7 @@ def test_every_entry_of_the_table_is_the_oracles_range(depth, monkeypatch):
     for key, el, eh in zip(table_key(absent), al, ah):
         got = host_lookup(lines, side, info, key)
         assert got == ((int(el), int(eh)) if eh > el else None)
-    assert int(((lines[:, :14] >> 24) != 0).sum()) == info["entries"]
+    assert slots_in_use(lines, info) == info["entries"]
     # distinct counts of the shallower levels the build passed through
     for d, n in info["distinct"].items():
         if 4 <= d <= depth:
@@ -118,7 +130,7 @@ def test_every_entry_of_the_table_is_the_oracles_range(depth, monkeypatch):
 
 
 @pytest.mark.parametrize("stride", [96, 128])
-@pytest.mark.parametrize("depth", [16, 19, 23, 24])
+@pytest.mark.parametrize("depth", [16, 19, 23, 24, 25, 26, 27, 28])
 def test_counts_with_the_sparse_table_equal_the_oracle(depth, stride, monkeypatch):
     reads = read_set(21 + depth, 5000, 900, 80, repeats=6, err=0.005)
     b, ref = load_pair(bwt_of(reads), monkeypatch, depth, MSBWT_PAIR_STRIDE=stride)

@@ -431,14 +431,15 @@ def test_sparse_table_hash_and_shape_are_pure_functions():
     shape the builder picks leaves every lookup a probe limit of 7 buckets or more with tags unambiguous."""
     L = _lib.lib()
     rng = np.random.default_rng(1)
-    for depth in (16, 19, 23, 24):
+    for depth in (16, 19, 23, 24, 25, 27, 28):
         n = 2 * depth
+        tag_bits = 24 if depth <= 24 else 32                       # depths 25..28: the wide layout, 12 entries with 32-bit tags
         for entries in (0, 1000, 3 * 10 ** 7, 3 * 10 ** 9):
             nb, probe = C.c_uint64(), C.c_int()
             assert L.msbwt_sparse_table_shape(depth, entries, C.byref(nb), C.byref(probe)) == 0
-            assert nb.value >= entries / 9.0 and 7 <= probe.value <= 15 and nb.value + probe.value < 2 ** 32
+            assert nb.value >= entries / (9.0 if depth <= 24 else 9.0 * 12 / 14) - 1 and 7 <= probe.value <= 15 and nb.value + probe.value < 2 ** 32
             window = (-(-2 ** 32 // nb.value)) << (n - 32)        # widest range of mixed keys one bucket takes
-            assert (probe.value + 1) * window <= 2 ** 24            # ... so that the 24-bit tags of one probe sequence never collide
+            assert (probe.value + 1) * window <= 2 ** tag_bits      # ... so that the tags of one probe sequence never collide
         # the mix loses nothing: with (nearly) 2^32 buckets the bucket is the mixed key's top 32 bits and the tag its low 24 -- together
         # every bit of a key of at most 48 bits -- so distinct keys must give distinct pairs
         keys = np.unique(rng.integers(0, 2 ** n, size=5000, dtype=np.uint64))
@@ -446,7 +447,7 @@ def test_sparse_table_hash_and_shape_are_pure_functions():
         mixes = set()
         for key in keys.tolist():
             assert L.msbwt_sparse_hash(key, depth, 2 ** 32 - 1, C.byref(b), C.byref(t)) == 0
-            assert t.value < 2 ** 24
+            assert t.value < 2 ** tag_bits
             mixes.add((b.value, t.value))
         assert len(mixes) >= len(keys) - 1   # (the scaling by 2^32 - 1 folds the two lowest top values together)
         # and it spreads structured keys: consecutive keys (one symbol apart in the first position searched) over 1000 buckets
@@ -457,7 +458,7 @@ def test_sparse_table_hash_and_shape_are_pure_functions():
         assert hits.max() <= 60 and hits.min() >= 2, (hits.min(), hits.max())
     assert L.msbwt_sparse_hash(0, 15, 10, C.byref(b), C.byref(t)) == _lib.ERR_INVALID_ARG
     nb, probe = C.c_uint64(), C.c_int()
-    assert L.msbwt_sparse_table_shape(25, 10, C.byref(nb), C.byref(probe)) == _lib.ERR_INVALID_ARG
+    assert L.msbwt_sparse_table_shape(29, 10, C.byref(nb), C.byref(probe)) == _lib.ERR_INVALID_ARG
 
 
 def test_run_block_device_build_decision():
@@ -478,7 +479,7 @@ def test_automatic_sparse_depth_follows_the_distinct_counts():
     sizing pass reached whose table fits -- with the distinct counts the device builder measured on this repo's indexes (DESIGN.md 2,
     profiles/r05_lab/sparse_table.log), and with what a 30x human read set WITH errors would count (about 1.3e10 distinct 23-mers)."""
     def choose(distinct, avail, parent=13, wide=None):
-        d, w = (C.c_uint64 * 25)(), (C.c_uint64 * 25)()
+        d, w = (C.c_uint64 * 29)(), (C.c_uint64 * 29)()
         for k, v in distinct.items():
             d[k] = v
         for k, v in (wide or {}).items():
