@@ -291,7 +291,17 @@ int msbwt_sparse_table_shape(int depth, uint64_t entries, uint64_t *nbuckets, in
 /* The automatic depth as a pure function (no device needed; rust-msbwt_amd/csrc/sparse_policy.hpp): distinct[d] / wide[d] for d = 0..28
  * as msbwt_rle_sparse_table_info reports them ([10 + d], [45 + d]), the depth of the direct table the count started from, and the bytes
  * the table and its build scratch may take -> the depth the loader would build (0 = none fits) and the bytes of that table. */
-int msbwt_auto_sparse_depth(const uint64_t *distinct, const uint64_t *wide, int parent_depth, uint64_t avail_bytes, int *depth, uint64_t *table_bytes);
+int msbwt_auto_sparse_depth(const uint64_t *distinct, const uint64_t *wide, int parent_depth, uint64_t avail_bytes, int query_length, int *depth, uint64_t *table_bytes);
+/* The k the index will mostly be asked about (0 = unknown, the default; MSBWT_QUERY_K in the environment sets the initial value).  The
+ * reference's count_kmer takes any k per call and so does this library -- results never depend on the hint -- but a hashed table of
+ * d-mers serves k >= d only, and every two symbols of depth save a present k-mer one index line: with k unknown the automatic sparse
+ * table stops at depth 23 (every k >= 23 is served: 5 lines for a present 31-mer); a caller that declares k = 31 gets depth 27 (3 lines:
+ * 1.34e10 instead of 8.4e9 present 31-mers/s at 30x-human scale) and k = 21 gets depth 21.  Shorter k-mers than the table's depth use the
+ * direct table as before.  Only the AUTOMATIC depth follows the hint (msbwt_rle_set_sparse_table(-1)); it takes effect immediately if an
+ * index is loaded (the tables are rebuilt).  msbwt_auto_sparse_max_depth: the rule as a pure function. */
+int msbwt_rle_set_query_length(msbwt_rle *bwt, int k);
+int msbwt_rle_get_query_length(const msbwt_rle *bwt);
+int msbwt_auto_sparse_max_depth(int query_length);
 size_t msbwt_rle_download_sparse_table(const msbwt_rle *bwt, void *out_lines, size_t cap_bytes, void *out_side, size_t cap_side_bytes);
 /* Presence filter: one bit per ACGT suffix of length min(12, table depth), set when some table
  * entry with that suffix is a non-empty range; at most 2 MiB, so it lives in L2 and decides

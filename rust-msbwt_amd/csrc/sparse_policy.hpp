@@ -22,6 +22,16 @@ struct SparseChoice {
     uint64_t build_bytes = 0; // ... + the slot counters the fill pass needs beside them
 };
 
+// How deep the AUTOMATIC table may go, given the k the index will mostly be asked about (msbwt_rle_set_query_length; 0 = unknown).
+// A hashed table of d-mers serves k >= d only, and every two symbols of depth save a present k-mer one index line: unknown -> 23 (serves
+// every k >= 23; what round 5 shipped), a declared k -> that k, within what the format and the distinct counts make sensible (16..27: a
+// present 31-mer behind depth 27 needs 3 lines instead of 5 -- 1.34e10 against 8.4e9 q/s at human scale -- and 28 would only add a
+// single-symbol step).
+inline int sparse_auto_max_depth(int query_length) {
+    if (query_length <= 0) return kSparseAutoDepth;
+    return std::max(kSparseMinDepth, std::min(query_length, 27));
+}
+
 // distinct[d] / wide[d]: non-empty ranges at depth d and how many of them are 255 or more wide (0 for depths the pass did not reach);
 // parent_depth: the direct table the pass started from; avail: bytes the table (and its build scratch) may take;
 // explicit_depth: 0 = automatic, else exactly that depth or nothing.

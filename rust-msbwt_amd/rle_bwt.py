@@ -310,6 +310,16 @@ class RleBWT(BWT):
         if rc:
             _raise(rc, self._h)
 
+    def set_query_length(self, k):
+        """The k this index will mostly be asked about (0 = unknown): the AUTOMATIC sparse table goes as deep as min(k, 27) instead of 23
+        -- a table of d-mers serves k >= d only.  Results never depend on it."""
+        rc = _lib.lib().msbwt_rle_set_query_length(self._h, int(k))
+        if rc:
+            _raise(rc, self._h)
+
+    def get_query_length(self):
+        return int(_lib.lib().msbwt_rle_get_query_length(self._h))
+
     def get_sparse_table(self):
         """Depth of the sparse suffix table in HBM, 0 = none."""
         return int(_lib.lib().msbwt_rle_get_sparse_table(self._h))

@@ -36,6 +36,12 @@ def bwt_of(reads):
     return orc.convert_to_vec(orc.naive_bwt(text))
 
 
+def synth_bwt(reads):
+    """the same by the suffix-sorting builder (read sets too large for the naive one)"""
+    import synth
+    return synth.rle_encode(synth.build_msbwt_symbols(reads))
+
+
 def load_pair(rle, monkeypatch, depth, **env):
     monkeypatch.setenv("MSBWT_SEARCH", "lanes")
     monkeypatch.setenv("MSBWT_SPARSE_TABLE", str(depth))
@@ -127,6 +133,31 @@ def test_every_entry_of_the_table_is_the_oracles_range(depth, monkeypatch):
     for d, n in info["distinct"].items():
         if 4 <= d <= depth:
             assert n == len(np.unique(np.lib.stride_tricks.sliding_window_view(reads, d, axis=1).reshape(-1, d), axis=0)), d
+
+
+def test_the_automatic_depth_follows_the_declared_query_length(monkeypatch):
+    """msbwt_rle_set_query_length: a table of d-mers serves k >= d only, so the AUTOMATIC depth stops at 23 while k is unknown and reaches
+    min(k, 27) for a declared k; an explicit depth does not follow the hint; counts never change."""
+    reads = read_set(77, 2_000_000, 500_000, 100, repeats=30, err=0.002)
+    rle = synth_bwt(reads)
+    b, ref = load_pair(rle, monkeypatch, "auto")
+    d0 = b.get_sparse_table()
+    assert b.get_query_length() == 0 and 16 <= d0 <= 23
+    windows = {k: np.ascontiguousarray(np.lib.stride_tricks.sliding_window_view(reads[:300], k, axis=1).reshape(-1, k)) for k in (21, 25, 31, 59)}
+    exp = {k: ref.count_kmers(q) for k, q in windows.items()}
+    seen = {}
+    for hint in (31, 21, 25, 59, 0):
+        b.set_query_length(hint)
+        assert b.get_query_length() == hint
+        seen[hint] = b.get_sparse_table()
+        for k, q in windows.items():
+            assert np.array_equal(b.count_kmers(q), exp[k]), (hint, k)
+    assert seen[0] == d0 and seen[31] == seen[59] and d0 <= seen[31] <= 27 and seen[21] <= 21 and seen[25] <= 25
+    assert seen[31] >= 25, seen           # 5e7 symbols, 2e6 distinct 27-mers: deep enough for the wide layout to pay
+    b.set_sparse_table(19)
+    b.set_query_length(31)
+    assert b.get_sparse_table() == 19
+    assert np.array_equal(b.count_kmers(windows[31]), exp[31])
 
 
 @pytest.mark.parametrize("stride", [96, 128])

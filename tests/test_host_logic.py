@@ -478,14 +478,14 @@ def test_automatic_sparse_depth_follows_the_distinct_counts():
     """csrc/sparse_policy.hpp through msbwt_auto_sparse_depth (no device): the depth of the sparse suffix table is the deepest one the
     sizing pass reached whose table fits -- with the distinct counts the device builder measured on this repo's indexes (DESIGN.md 2,
     profiles/r05_lab/sparse_table.log), and with what a 30x human read set WITH errors would count (about 1.3e10 distinct 23-mers)."""
-    def choose(distinct, avail, parent=13, wide=None):
+    def choose(distinct, avail, parent=13, wide=None, query_length=0):
         d, w = (C.c_uint64 * 29)(), (C.c_uint64 * 29)()
         for k, v in distinct.items():
             d[k] = v
         for k, v in (wide or {}).items():
             w[k] = v
         depth, nbytes = C.c_int(), C.c_uint64()
-        assert _lib.lib().msbwt_auto_sparse_depth(d, w, parent, avail, C.byref(depth), C.byref(nbytes)) == 0
+        assert _lib.lib().msbwt_auto_sparse_depth(d, w, parent, avail, query_length, C.byref(depth), C.byref(nbytes)) == 0
         return depth.value, nbytes.value
 
     GB = 10 ** 9
@@ -512,3 +512,14 @@ def test_automatic_sparse_depth_follows_the_distinct_counts():
     noisy = {k: int(v) for k, v in noisy.items()}
     assert choose(noisy, 100 * GB)[0] == 0 and choose(noisy, 200 * GB)[0] == 23
     assert choose({}, 200 * GB)[0] == 0
+    # a declared k moves the limit of the automatic depth (msbwt_rle_set_query_length): 31-mers get depth 27 -- 12 entries of 10 bytes per
+    # bucket at the same 64 % load: 16.6 bytes per distinct 27-mer --, 21-mers depth 21, and k unknown stays at 23
+    rule = _lib.lib().msbwt_auto_sparse_max_depth
+    assert [rule(k) for k in (0, 12, 16, 21, 23, 25, 27, 31, 59)] == [23, 16, 16, 21, 23, 25, 27, 27, 27]
+    human27 = dict(human)
+    human27.update({25: 2980128505, 27: 2980132285})
+    depth, nbytes = choose(human27, 80 * GB, query_length=31)
+    assert depth == 27 and 49 * GB < nbytes < 50 * GB
+    assert choose(human27, 80 * GB)[0] == 23 and choose(human27, 80 * GB, query_length=25)[0] == 25
+    assert choose(human27, 45 * GB, query_length=31)[0] == 23      # depth 27 does not fit: the deepest that does
+    assert choose(c2, 200 * GB, query_length=21)[0] == 21
