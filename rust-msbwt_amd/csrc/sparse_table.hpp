@@ -1,4 +1,4 @@
-// Sparse suffix table: the ranges of the d-symbol suffixes that OCCUR, d up to 28 -- the reference's stubbed kmer_cache
+// Sparse suffix table: the ranges of the d-symbol suffixes that OCCUR, d up to 29 -- the reference's stubbed kmer_cache
 // (src/msbwt_core.rs:133-146, src/rle_bwt.rs:332-346) taken past what a direct-address table can hold.
 //
 // The direct table (kernels.hpp, TableView) has 4^d entries whatever the data: at d = 17 that is 73 GB of which at most
@@ -23,7 +23,7 @@
 // An entry whose range is 255 or more wide (a suffix of a high-copy repeat) names a flat {l, h} entry of 16 bytes in a side
 // array: one more line for that query, like the escape lines of the packed direct table.
 //
-// Depths 25..28 (round 6: a present 31-mer behind a depth-27 table needs 3 lines instead of 5 -- measured with 27-mers on the
+// Depths 25..29 (round 6: a present 31-mer behind a depth-27 table needs 3 lines instead of 5 -- measured with 27-mers on the
 // depth-23 table: 1.46e10 q/s at human scale) -- a 50..56-bit key leaves 24-bit tags no room ((probe + 1) * W <= 2^24 with W =
 // 2^(n-32) * 13 fails from n = 50 on), so these depths keep the low 32 bits of the mixed key as the tag: 10 bytes per entry, 12 per
 // bucket ("wide" layout):
@@ -32,7 +32,9 @@
 //     bytes  96..107 l_hi[i]
 //     bytes 108..119 width[i]  (1..254; 255 = ESCAPE; 0 = empty slot)
 //     bytes 126..127 header    (as above; > 12 = entries were displaced)
-// Uniqueness: (probe + 1) * W <= 2^32.
+// Uniqueness: (probe + 1) * W <= 2^32.  Depth 29 (a 58-bit key: one pair step left of a 31-mer) is the last this tag width reaches:
+// W <= 2^6 / 8 means 2^29 buckets at least -- 69 GB, which a human-scale index still has room for (5.5 entries per bucket) and a
+// small one has no use for: the automatic choice stops at 27, 29 is by request.
 #pragma once
 #include <cstdint>
 
@@ -47,13 +49,13 @@ namespace msbwt {
 
 constexpr uint32_t kSparseSlots = 14;        // entries per 128-byte bucket (depths up to 24)
 constexpr uint32_t kSparseTagBits = 24;
-constexpr uint32_t kSparseWideSlots = 12;    // ... and of the wide layout (depths 25..28): 32-bit tags
+constexpr uint32_t kSparseWideSlots = 12;    // ... and of the wide layout (depths 25..29): 32-bit tags
 constexpr uint32_t kSparseWideL0Word = 12, kSparseWideHiByte = 96, kSparseWideWidthByte = 108;
 constexpr int kSparseWideFrom = 25;
 constexpr uint32_t kSparseEscapeWidth = 255;  // width field of an entry whose range lives in the side array
 constexpr uint32_t kSparseMaxProbe = 15;      // a key lives at most this many buckets behind its own
-constexpr int kSparseMinDepth = 16, kSparseMaxDepth = 28;
-constexpr int kSparseAutoDepth = 23;          // the automatic choice never goes deeper (msbwt_rle_set_sparse_table takes 16..28)
+constexpr int kSparseMinDepth = 16, kSparseMaxDepth = 29;
+constexpr int kSparseAutoDepth = 23;          // the automatic choice never goes deeper (msbwt_rle_set_sparse_table takes 16..29)
 constexpr double kSparseLoad = 9.0;           // entries per bucket the builder aims for (64 % of the slots: 0.9 % of the entries displaced)
 
 MSBWT_HD bool sparse_wide(uint32_t depth) { return depth >= uint32_t(kSparseWideFrom); }
@@ -70,7 +72,7 @@ struct SparseView {
     const void *side = nullptr;    // 16-byte {l, h} entries of the ESCAPE entries
 };
 
-// the bijection of n-bit words (n = 2 depth, 32 <= n <= 56)
+// the bijection of n-bit words (n = 2 depth, 32 <= n <= 58)
 MSBWT_HD uint64_t sparse_mix(uint64_t key, uint32_t n) {
     const uint64_t mask = (uint64_t(1) << n) - 1u;
     uint64_t x = key & mask;

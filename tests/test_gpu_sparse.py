@@ -161,8 +161,12 @@ def test_the_automatic_depth_follows_the_declared_query_length(monkeypatch):
 
 
 @pytest.mark.parametrize("stride", [96, 128])
-@pytest.mark.parametrize("depth", [16, 19, 23, 24, 25, 26, 27, 28])
+@pytest.mark.parametrize("depth", [16, 19, 23, 24, 25, 26, 27, 28, 29])
 def test_counts_with_the_sparse_table_equal_the_oracle(depth, stride, monkeypatch):
+    if depth == 29:   # the last depth 32-bit tags reach needs 2^29 buckets whatever the index: 69 GB (+ 2 GB of slot counters while it is built)
+        import torch
+        if torch.cuda.mem_get_info(0)[0] < 90 * 10**9:
+            pytest.skip("needs 90 GB of free HBM")
     reads = read_set(21 + depth, 5000, 900, 80, repeats=6, err=0.005)
     b, ref = load_pair(bwt_of(reads), monkeypatch, depth, MSBWT_PAIR_STRIDE=stride)
     assert b.get_sparse_table() == depth and b.get_pair_stride() == stride

@@ -431,7 +431,7 @@ def test_sparse_table_hash_and_shape_are_pure_functions():
     shape the builder picks leaves every lookup a probe limit of 7 buckets or more with tags unambiguous."""
     L = _lib.lib()
     rng = np.random.default_rng(1)
-    for depth in (16, 19, 23, 24, 25, 27, 28):
+    for depth in (16, 19, 23, 24, 25, 27, 28, 29):
         n = 2 * depth
         tag_bits = 24 if depth <= 24 else 32                       # depths 25..28: the wide layout, 12 entries with 32-bit tags
         for entries in (0, 1000, 3 * 10 ** 7, 3 * 10 ** 9):
@@ -458,7 +458,7 @@ def test_sparse_table_hash_and_shape_are_pure_functions():
         assert hits.max() <= 60 and hits.min() >= 2, (hits.min(), hits.max())
     assert L.msbwt_sparse_hash(0, 15, 10, C.byref(b), C.byref(t)) == _lib.ERR_INVALID_ARG
     nb, probe = C.c_uint64(), C.c_int()
-    assert L.msbwt_sparse_table_shape(29, 10, C.byref(nb), C.byref(probe)) == _lib.ERR_INVALID_ARG
+    assert L.msbwt_sparse_table_shape(30, 10, C.byref(nb), C.byref(probe)) == _lib.ERR_INVALID_ARG
 
 
 def test_run_block_device_build_decision():
@@ -479,7 +479,7 @@ def test_automatic_sparse_depth_follows_the_distinct_counts():
     sizing pass reached whose table fits -- with the distinct counts the device builder measured on this repo's indexes (DESIGN.md 2,
     profiles/r05_lab/sparse_table.log), and with what a 30x human read set WITH errors would count (about 1.3e10 distinct 23-mers)."""
     def choose(distinct, avail, parent=13, wide=None, query_length=0):
-        d, w = (C.c_uint64 * 29)(), (C.c_uint64 * 29)()
+        d, w = (C.c_uint64 * 30)(), (C.c_uint64 * 30)()
         for k, v in distinct.items():
             d[k] = v
         for k, v in (wide or {}).items():

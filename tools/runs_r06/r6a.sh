@@ -10,3 +10,7 @@ for seed in 111 112 113; do
   echo "seed $seed rc=$rc: $(tail -1 $out/soak_seed$seed.log)"
   [ $rc -eq 0 ] || { tail -20 $out/soak_seed$seed.log; exit 1; }
 done
+# depth 29 has never run on a GPU: its counts test, then the metric's line with it
+timeout -k 10 200 python -m pytest tests/test_gpu_sparse.py -x -q -m gpu -k "counts_with and 29" 2>&1 | tail -2
+timeout -k 10 400 python bench.py --sparse-depth 29 --no-c4 --no-c5 --no-sorted --no-live-pmc --no-cpu-baseline --counters --parity-sample 2000000 > $out/human_depth29.json 2> $out/human_depth29.log
+python -c "import json;r=json.loads(open('$out/human_depth29.json').read().strip().splitlines()[-1]);print('depth 29:', r['value'], r['ms_per_step'], r['search_counters']['lines_per_query'], r['parity'], r['config']['index_bytes'])"
