@@ -295,8 +295,8 @@ int msbwt_auto_sparse_depth(const uint64_t *distinct, const uint64_t *wide, int 
 /* The k the index will mostly be asked about (0 = unknown, the default; MSBWT_QUERY_K in the environment sets the initial value).  The
  * reference's count_kmer takes any k per call and so does this library -- results never depend on the hint -- but a hashed table of
  * d-mers serves k >= d only, and every two symbols of depth save a present k-mer one index line: with k unknown the automatic sparse
- * table stops at depth 23 (every k >= 23 is served: 5 lines for a present 31-mer); a caller that declares k = 31 gets depth 27 (3 lines:
- * 1.34e10 instead of 8.4e9 present 31-mers/s at 30x-human scale) and k = 21 gets depth 21.  Shorter k-mers than the table's depth use the
+ * table stops at depth 23 (every k >= 23 is served: 5 lines for a present 31-mer); a caller that declares k = 31 gets depth 29 where its 69 GB are worth it (2 lines: 1.92e10
+ * instead of 8.4e9 present 31-mers/s at 30x-human scale), else depth 27 (3 lines: 1.34e10), and k = 21 gets depth 21.  Shorter k-mers than the table's depth use the
  * direct table as before.  Only the AUTOMATIC depth follows the hint (msbwt_rle_set_sparse_table(-1)); it takes effect immediately if an
  * index is loaded (the tables are rebuilt).  msbwt_auto_sparse_max_depth: the rule as a pure function. */
 int msbwt_rle_set_query_length(msbwt_rle *bwt, int k);

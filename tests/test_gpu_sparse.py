@@ -152,7 +152,7 @@ def test_the_automatic_depth_follows_the_declared_query_length(monkeypatch):
         seen[hint] = b.get_sparse_table()
         for k, q in windows.items():
             assert np.array_equal(b.count_kmers(q), exp[k]), (hint, k)
-    assert seen[0] == d0 and seen[31] == seen[59] and d0 <= seen[31] <= 27 and seen[21] <= 21 and seen[25] <= 25
+    assert seen[0] == d0 and seen[31] == seen[59] and d0 <= seen[31] <= 27 and seen[21] <= 21 and seen[25] <= 25    # (29 is not worth its 69 GB here)
     assert seen[31] >= 25, seen           # 5e7 symbols, 2e6 distinct 27-mers: deep enough for the wide layout to pay
     b.set_sparse_table(19)
     b.set_query_length(31)

@@ -515,11 +515,17 @@ def test_automatic_sparse_depth_follows_the_distinct_counts():
     # a declared k moves the limit of the automatic depth (msbwt_rle_set_query_length): 31-mers get depth 27 -- 12 entries of 10 bytes per
     # bucket at the same 64 % load: 16.6 bytes per distinct 27-mer --, 21-mers depth 21, and k unknown stays at 23
     rule = _lib.lib().msbwt_auto_sparse_max_depth
-    assert [rule(k) for k in (0, 12, 16, 21, 23, 25, 27, 31, 59)] == [23, 16, 16, 21, 23, 25, 27, 27, 27]
+    assert [rule(k) for k in (0, 12, 16, 21, 23, 25, 27, 28, 31, 59)] == [23, 16, 16, 21, 23, 25, 27, 28, 29, 29]
     human27 = dict(human)
-    human27.update({25: 2980128505, 27: 2980132285})
+    human27.update({25: 2980128505, 27: 2980132285, 29: 2980132543})
     depth, nbytes = choose(human27, 80 * GB, query_length=31)
+    assert depth == 29 and 68 * GB < nbytes < 69 * GB              # 2^29 buckets: the least depth 29 can have, 5.5 entries in each
+    depth, nbytes = choose(human27, 60 * GB, query_length=31)
     assert depth == 27 and 49 * GB < nbytes < 50 * GB
-    assert choose(human27, 80 * GB)[0] == 23 and choose(human27, 80 * GB, query_length=25)[0] == 25
-    assert choose(human27, 45 * GB, query_length=31)[0] == 23      # depth 27 does not fit: the deepest that does
+    assert choose(human27, 80 * GB)[0] == 23 and choose(human27, 80 * GB, query_length=25)[0] == 25 and choose(human27, 80 * GB, query_length=27)[0] == 27
+    assert choose(human27, 45 * GB, query_length=31)[0] == 23      # neither 29 nor 27 fits: the deepest that does
+    c4_deep = dict(c4)
+    c4_deep.update({25: 251000000, 27: 262000000, 29: 272000000})  # (reads with errors: every two symbols add singletons)
+    depth, nbytes = choose(c4_deep, 200 * GB, query_length=31)
+    assert depth == 27 and nbytes < 4.4 * GB                       # 69 GB for 2.7e8 entries is not worth two symbols
     assert choose(c2, 200 * GB, query_length=21)[0] == 21
