@@ -66,6 +66,7 @@ SIGNATURES = {
     "msbwt_rle_sparse_table_info": (_int, [_vp, _pu64]),
     "msbwt_sparse_hash": (_int, [_u64, _int, _u64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "msbwt_sparse_table_shape": (_int, [_int, _u64, _pu64, C.POINTER(C.c_int)]),
+    "msbwt_sparse_hash64": (_int, [_u64, _int, _u64, C.POINTER(C.c_uint32), _pu64]),
     "msbwt_auto_sparse_depth": (_int, [_pu64, _pu64, _int, _u64, _int, C.POINTER(C.c_int), _pu64]),
     "msbwt_rle_download_sparse_table": (_sz, [_vp, _vp, _sz, _vp, _sz]),
     "msbwt_rle_set_search_counters": (_int, [_vp, _int]),

@@ -2072,6 +2072,14 @@ int msbwt_sparse_hash(uint64_t key, int depth, uint64_t nbuckets, uint32_t *buck
     return MSBWT_OK;
 }
 
+int msbwt_sparse_hash64(uint64_t key, int depth, uint64_t nbuckets, uint32_t *bucket, uint64_t *tag) {
+    if (depth < kSparseMinDepth || depth > kSparseMaxDepth || nbuckets == 0 || nbuckets > 0xFFFFFFFFull || !bucket || !tag) return MSBWT_ERR_INVALID_ARG;
+    const uint64_t x = sparse_mix(key, uint32_t(2 * depth));
+    *bucket = sparse_bucket(x, uint32_t(2 * depth), uint32_t(nbuckets));
+    *tag = (uint64_t(sparse_tag_hi(x, uint32_t(depth))) << 32) | sparse_tag(x, uint32_t(depth));
+    return MSBWT_OK;
+}
+
 int msbwt_auto_sparse_depth(const uint64_t *distinct, const uint64_t *wide, int parent_depth, uint64_t avail_bytes, int query_length, int *depth, uint64_t *table_bytes) {
     if (!distinct || !wide || !depth || parent_depth < 0 || parent_depth > 16 || query_length < 0) return MSBWT_ERR_INVALID_ARG;
     const SparseChoice c = choose_sparse_depth(distinct, wide, parent_depth, sparse_auto_max_depth(query_length), avail_bytes, 0);

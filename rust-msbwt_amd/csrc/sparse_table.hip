@@ -35,7 +35,7 @@ constexpr int kAccEscape = 64;  // [64 .. 96): nodes 255 or more wide, per depth
 constexpr int kCurEscape = 96;  // [96 .. 128): the same for the chunk in hand
 constexpr int kOverflow = 128, kFailed = 129, kSideCursor = 130, kDisplaced = 131;
 constexpr int kCursorWords = 160;
-static_assert(kSparseMaxDepth + 2 < 32, "a cursor per depth the expansion can reach");
+static_assert(kSparseMaxDepth < 32, "a cursor per depth the expansion can reach");
 
 // this thread's first of `mine` consecutive slots behind *cursor: one atomic per workgroup.  Every thread of the block calls it.
 __device__ __forceinline__ uint64_t reserve(uint32_t mine, unsigned long long *cursor) {
@@ -150,8 +150,8 @@ __device__ __forceinline__ void sparse_insert(const FillEnv &env, uint64_t key, 
     const uint64_t x = sparse_mix(key, env.n);
     uint32_t b = sparse_bucket(x, env.n, env.nbuckets);
     const uint32_t depth = env.n >> 1;
-    const bool wide = sparse_wide(depth);  // launch-uniform: 12 entries with 32-bit tags (sparse_table.hpp)
-    const uint32_t tag = sparse_tag(x, depth), slots = sparse_slots(depth);
+    const bool wide = sparse_wide(depth), xwide = sparse_xwide(depth);  // launch-uniform: the layout follows the depth (sparse_table.hpp)
+    const uint32_t tag = sparse_tag(x, depth), tag_hi = sparse_tag_hi(x, depth), slots = sparse_slots(depth);
     uint64_t lval = nl;
     uint32_t wf = uint32_t(nh - nl);
     if (nh - nl >= kSparseEscapeWidth) {
@@ -164,7 +164,13 @@ __device__ __forceinline__ void sparse_insert(const FillEnv &env, uint64_t key, 
         const uint32_t slot = atomicAdd(env.counts + b, 1u);
         if (slot < slots) {
             uint32_t *line = reinterpret_cast<uint32_t *>(env.lines + uint64_t(b) * 8u);
-            if (wide) {
+            if (xwide) {
+                line[slot] = tag;
+                line[kSparseXL0Word + slot] = uint32_t(lval);
+                reinterpret_cast<uint8_t *>(line)[kSparseXTagHiByte + slot] = uint8_t(tag_hi);
+                reinterpret_cast<uint8_t *>(line)[kSparseXHiByte + slot] = uint8_t(lval >> 32);
+                reinterpret_cast<uint8_t *>(line)[kSparseXWidthByte + slot] = uint8_t(wf);
+            } else if (wide) {
                 line[slot] = tag;
                 line[kSparseWideL0Word + slot] = uint32_t(lval);
                 reinterpret_cast<uint8_t *>(line)[kSparseWideHiByte + slot] = uint8_t(lval >> 32);

@@ -1,4 +1,4 @@
-// Sparse suffix table: the ranges of the d-symbol suffixes that OCCUR, d up to 29 -- the reference's stubbed kmer_cache
+// Sparse suffix table: the ranges of the d-symbol suffixes that OCCUR, d up to 31 -- the reference's stubbed kmer_cache
 // (src/msbwt_core.rs:133-146, src/rle_bwt.rs:332-346) taken past what a direct-address table can hold.
 //
 // The direct table (kernels.hpp, TableView) has 4^d entries whatever the data: at d = 17 that is 73 GB of which at most
@@ -34,7 +34,18 @@
 //     bytes 126..127 header    (as above; > 12 = entries were displaced)
 // Uniqueness: (probe + 1) * W <= 2^32.  Depth 29 (a 58-bit key: one pair step left of a 31-mer) is the last this tag width reaches:
 // W <= 2^6 / 8 means 2^29 buckets at least -- 69 GB, which a human-scale index still has room for (5.5 entries per bucket) and a
-// small one has no use for: the automatic choice stops at 27, 29 is by request.
+// small one has no use for.
+//
+// Depths 30..31 ("xwide" layout: 40-bit tags, 11 entries of 11 bytes) -- at depth 31 the table's range IS the count of a 31-mer: one
+// line per query (23-mers on the depth-23 table: 3.4e10 q/s at human scale):
+//     words  0..10   tag_lo[i] = bits 0..31 of the mixed key
+//     words 11..21   l_lo[i]
+//     bytes  88..98  tag_hi[i] = bits 32..39 of the mixed key
+//     bytes  99..109 l_hi[i]
+//     bytes 110..120 width[i]
+//     bytes 126..127 header    (> 11 = entries were displaced)
+// Uniqueness: (probe + 1) * W <= 2^40 -- 2^25 buckets suffice again, and 7 entries per bucket (the same 64 %) make 18.3 bytes per
+// distinct suffix: 54.5 GB for the 2.98e9 distinct 31-mers of the error-free human-scale index.
 #pragma once
 #include <cstdint>
 
@@ -52,15 +63,19 @@ constexpr uint32_t kSparseTagBits = 24;
 constexpr uint32_t kSparseWideSlots = 12;    // ... and of the wide layout (depths 25..29): 32-bit tags
 constexpr uint32_t kSparseWideL0Word = 12, kSparseWideHiByte = 96, kSparseWideWidthByte = 108;
 constexpr int kSparseWideFrom = 25;
+constexpr uint32_t kSparseXSlots = 11;       // ... and of the xwide layout (depths 30..31): 40-bit tags
+constexpr uint32_t kSparseXL0Word = 11, kSparseXTagHiByte = 88, kSparseXHiByte = 99, kSparseXWidthByte = 110;
+constexpr int kSparseXFrom = 30;
 constexpr uint32_t kSparseEscapeWidth = 255;  // width field of an entry whose range lives in the side array
 constexpr uint32_t kSparseMaxProbe = 15;      // a key lives at most this many buckets behind its own
-constexpr int kSparseMinDepth = 16, kSparseMaxDepth = 29;
-constexpr int kSparseAutoDepth = 23;          // the automatic choice never goes deeper (msbwt_rle_set_sparse_table takes 16..29)
+constexpr int kSparseMinDepth = 16, kSparseMaxDepth = 31;
+constexpr int kSparseAutoDepth = 23;          // the automatic choice never goes deeper (msbwt_rle_set_sparse_table takes 16..31)
 constexpr double kSparseLoad = 9.0;           // entries per bucket the builder aims for (64 % of the slots: 0.9 % of the entries displaced)
 
-MSBWT_HD bool sparse_wide(uint32_t depth) { return depth >= uint32_t(kSparseWideFrom); }
-MSBWT_HD uint32_t sparse_slots(uint32_t depth) { return sparse_wide(depth) ? kSparseWideSlots : kSparseSlots; }
-MSBWT_HD uint32_t sparse_tag_bits(uint32_t depth) { return sparse_wide(depth) ? 32u : kSparseTagBits; }
+MSBWT_HD bool sparse_wide(uint32_t depth) { return depth >= uint32_t(kSparseWideFrom); }   // (xwide included: the tag's low word is whole)
+MSBWT_HD bool sparse_xwide(uint32_t depth) { return depth >= uint32_t(kSparseXFrom); }
+MSBWT_HD uint32_t sparse_slots(uint32_t depth) { return sparse_xwide(depth) ? kSparseXSlots : sparse_wide(depth) ? kSparseWideSlots : kSparseSlots; }
+MSBWT_HD uint32_t sparse_tag_bits(uint32_t depth) { return sparse_xwide(depth) ? 40u : sparse_wide(depth) ? 32u : kSparseTagBits; }
 inline double sparse_load(int depth) { return kSparseLoad * double(sparse_slots(uint32_t(depth))) / double(kSparseSlots); }  // the same 64 % of the slots
 constexpr uint32_t kSparseL0Word = 14, kSparseHiByte = 112, kSparseHeaderByte = 126;
 
@@ -72,7 +87,7 @@ struct SparseView {
     const void *side = nullptr;    // 16-byte {l, h} entries of the ESCAPE entries
 };
 
-// the bijection of n-bit words (n = 2 depth, 32 <= n <= 58)
+// the bijection of n-bit words (n = 2 depth, 32 <= n <= 62)
 MSBWT_HD uint64_t sparse_mix(uint64_t key, uint32_t n) {
     const uint64_t mask = (uint64_t(1) << n) - 1u;
     uint64_t x = key & mask;
@@ -90,6 +105,8 @@ MSBWT_HD uint32_t sparse_bucket(uint64_t mixed, uint32_t n, uint32_t nbuckets) {
 }
 
 MSBWT_HD uint32_t sparse_tag(uint64_t mixed, uint32_t depth) { return sparse_wide(depth) ? uint32_t(mixed) : uint32_t(mixed) & ((1u << kSparseTagBits) - 1u); }
+// bits 32..39 of the tag (xwide layout; 0 otherwise)
+MSBWT_HD uint32_t sparse_tag_hi(uint64_t mixed, uint32_t depth) { return sparse_xwide(depth) ? uint32_t(mixed >> 32) & 0xFFu : 0u; }
 
 // How far a lookup may probe with `nbuckets` buckets at depth d so that tags stay unambiguous: (probe + 1) * W <= 2^tagbits,
 // W = 2^(n-32) * ceil(2^32 / nbuckets).  Negative: this many buckets are too few for the depth.

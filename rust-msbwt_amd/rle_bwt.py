@@ -305,7 +305,7 @@ class RleBWT(BWT):
 
     # ---- sparse suffix table (include/msbwt_hip.h, msbwt_rle_set_sparse_table) ----
     def set_sparse_table(self, depth):
-        """-1 = automatic (default), 0 = off, 16..29 = exactly that depth (29: at least 2^29 buckets, 69 GB)."""
+        """-1 = automatic (default), 0 = off, 16..31 = exactly that depth (29: at least 2^29 buckets, 69 GB)."""
         rc = _lib.lib().msbwt_rle_set_sparse_table(self._h, int(depth))
         if rc:
             _raise(rc, self._h)
@@ -332,8 +332,8 @@ class RleBWT(BWT):
             _raise(rc, self._h)
         info = {"depth": int(out[0]), "entries": int(out[1]), "buckets": int(out[2]), "bytes": int(out[3]), "side_entries": int(out[4]),
                 "side_bytes": int(out[5]), "displaced": int(out[6]), "parent_depth": int(out[7]), "probe": int(out[9])}
-        info["distinct"] = {d: int(out[10 + d]) for d in range(30) if out[10 + d]}
-        info["wide"] = {d: int(out[45 + d]) for d in range(30) if out[10 + d]}
+        info["distinct"] = {d: int(out[10 + d]) for d in range(32) if out[10 + d]}
+        info["wide"] = {d: int(out[45 + d]) for d in range(32) if out[10 + d]}
         return info
 
     def download_sparse_table(self):

@@ -63,7 +63,7 @@ extern "C" {
                                     out_counts: *mut c_void, count_bits: c_int) -> c_int;
     // HBM the index may hold (0 = no budget): the space / time knob, as bin_power is the reference's
     fn msbwt_rle_set_memory_budget(bwt: *mut MsbwtRle, bytes: u64) -> c_int;
-    // sparse suffix table (round 5): ranges of the suffixes that occur, depth 16..28 (-1 = automatic, 0 = off); info = 80 u64 words
+    // sparse suffix table (round 5): ranges of the suffixes that occur, depth 16..31 (-1 = automatic, 0 = off); info = 80 u64 words
     fn msbwt_rle_set_sparse_table(bwt: *mut MsbwtRle, depth: c_int) -> c_int;
     fn msbwt_rle_get_sparse_table(bwt: *const MsbwtRle) -> c_int;
     // the k the index will mostly be asked about (0 = unknown): the automatic sparse table then reaches min(k, 27) instead of 23
@@ -180,7 +180,7 @@ impl GpuRleBWT {
         if rc != MSBWT_OK { panic!("set_memory_budget: {}", self.last_error()); }
     }
 
-    /// Sparse suffix table: -1 = automatic (default), 0 = off, 16..=28 = exactly that depth.  Results never change.
+    /// Sparse suffix table: -1 = automatic (default), 0 = off, 16..=31 = exactly that depth.  Results never change.
     pub fn set_sparse_table(&mut self, depth: i32) {
         let rc = unsafe { msbwt_rle_set_sparse_table(self.raw, depth) };
         if rc != MSBWT_OK { panic!("set_sparse_table: {}", self.last_error()); }

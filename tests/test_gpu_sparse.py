@@ -76,17 +76,21 @@ def table_key(kmers):
 
 def host_lookup(lines, side, info, key):
     """What the kernel does with one key, on the downloaded table: -> (l, h) or None."""
-    b, tag = C.c_uint32(), C.c_uint32()
-    assert _lib.lib().msbwt_sparse_hash(int(key), info["depth"], info["buckets"], C.byref(b), C.byref(tag)) == 0
+    b, tag = C.c_uint32(), C.c_uint64()
+    assert _lib.lib().msbwt_sparse_hash64(int(key), info["depth"], info["buckets"], C.byref(b), C.byref(tag)) == 0
     bucket = b.value
     wide = info["depth"] >= 25           # sparse_table.hpp: 12 entries with 32-bit tags and a width byte of their own
-    nslots = 12 if wide else 14
+    xwide = info["depth"] >= 30          # ... 11 entries with 40-bit tags
+    nslots = 11 if xwide else 12 if wide else 14
     for dist in range(info["probe"] + 1):
         line = lines[bucket + dist]
         raw = line.view(np.uint8)
         for slot in range(nslots):
             t = int(line[slot])
-            if wide:
+            if xwide:
+                width, hit = int(raw[110 + slot]), (t | (int(raw[88 + slot]) << 32)) == tag.value
+                lo = int(line[11 + slot]) | (int(raw[99 + slot]) << 32)
+            elif wide:
                 width, hit = int(raw[108 + slot]), t == tag.value
                 lo = int(line[12 + slot]) | (int(raw[96 + slot]) << 32)
             else:
@@ -103,12 +107,14 @@ def host_lookup(lines, side, info, key):
 
 
 def slots_in_use(lines, info):
+    if info["depth"] >= 30:
+        return int((lines.view(np.uint8).reshape(len(lines), 128)[:, 110:121] != 0).sum())
     if info["depth"] >= 25:
         return int((lines.view(np.uint8).reshape(len(lines), 128)[:, 108:120] != 0).sum())
     return int(((lines[:, :14] >> 24) != 0).sum())
 
 
-@pytest.mark.parametrize("depth", [16, 17, 20, 25, 27, 28])
+@pytest.mark.parametrize("depth", [16, 17, 20, 25, 27, 28, 30, 31])
 def test_every_entry_of_the_table_is_the_oracles_range(depth, monkeypatch):
     reads = read_set(11, 3000, 700, 60, repeats=4, err=0.01)
     b, ref = load_pair(bwt_of(reads), monkeypatch, depth)
@@ -152,7 +158,7 @@ def test_the_automatic_depth_follows_the_declared_query_length(monkeypatch):
         seen[hint] = b.get_sparse_table()
         for k, q in windows.items():
             assert np.array_equal(b.count_kmers(q), exp[k]), (hint, k)
-    assert seen[0] == d0 and seen[31] == seen[59] and d0 <= seen[31] <= 27 and seen[21] <= 21 and seen[25] <= 25    # (29 is not worth its 69 GB here)
+    assert seen[0] == d0 and seen[31] == seen[59] and d0 <= seen[31] <= 31 and seen[21] <= 21 and seen[25] <= 25
     assert seen[31] >= 25, seen           # 5e7 symbols, 2e6 distinct 27-mers: deep enough for the wide layout to pay
     b.set_sparse_table(19)
     b.set_query_length(31)
@@ -161,7 +167,7 @@ def test_the_automatic_depth_follows_the_declared_query_length(monkeypatch):
 
 
 @pytest.mark.parametrize("stride", [96, 128])
-@pytest.mark.parametrize("depth", [16, 19, 23, 24, 25, 26, 27, 28, 29])
+@pytest.mark.parametrize("depth", [16, 19, 23, 24, 25, 26, 27, 28, 29, 30, 31])
 def test_counts_with_the_sparse_table_equal_the_oracle(depth, stride, monkeypatch):
     if depth == 29:   # the last depth 32-bit tags reach needs 2^29 buckets whatever the index: 69 GB (+ 2 GB of slot counters while it is built)
         import torch

@@ -14,3 +14,10 @@ done
 timeout -k 10 200 python -m pytest tests/test_gpu_sparse.py -x -q -m gpu -k "counts_with and 29" 2>&1 | tail -2
 timeout -k 10 400 python bench.py --sparse-depth 29 --no-c4 --no-c5 --no-sorted --no-live-pmc --no-cpu-baseline --counters --parity-sample 2000000 > $out/human_depth29.json 2> $out/human_depth29.log
 python -c "import json;r=json.loads(open('$out/human_depth29.json').read().strip().splitlines()[-1]);print('depth 29:', r['value'], r['ms_per_step'], r['search_counters']['lines_per_query'], r['parity'], r['config']['index_bytes'])"
+# depths 30 / 31 (the xwide layout) have never run on a GPU either
+timeout -k 10 300 python -m pytest tests/test_gpu_sparse.py -x -q -m gpu -k "30 or 31" 2>&1 | tail -2
+for d in 31 -2; do   # explicit depth 31, then the default (bench declares its k: the automatic depth should come out as 31)
+  extra=""; [ $d -gt 0 ] && extra="--sparse-depth $d"
+  timeout -k 10 400 python bench.py $extra --no-c4 --no-c5 --no-sorted --no-live-pmc --no-cpu-baseline --counters --parity-sample 2000000 > $out/human_depth$d.json 2> $out/human_depth$d.log
+  python -c "import json;r=json.loads(open('$out/human_depth$d.json').read().strip().splitlines()[-1]);print('sparse depth', r['config']['sparse_table_depth'], r['value'], r['ms_per_step'], r['search_counters']['lines_per_query'], r['parity'], r['config']['index_bytes'])"
+done
