@@ -132,6 +132,9 @@ def parse_args(argv=None):
     ap.add_argument("--query-kind", default="", choices=["", "random", "reads", "walk"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the index (tests)")
     ap.add_argument("--table-depth", type=int, default=-2, help="-2 = library default")
+    ap.add_argument("--query-length-hint", type=int, default=-1, help="msbwt_rle_set_query_length before the load: the k the index is built for (default: this run's k; 0 = "
+                                                                      "unknown, i.e. the automatic sparse table stops at depth 23 whatever k is)")
+    ap.add_argument("--sparse-depth", type=int, default=-2, help="msbwt_rle_set_sparse_table before the load: 0 = off, 16..28 = that depth (default: the library's automatic choice)")
     ap.add_argument("--blocks", default="planes", choices=["planes", "runs"],
                     help="index block format: planes (default) or the memory-lean run blocks (no pair index)")
     ap.add_argument("--fused", action="store_true",
@@ -512,6 +515,11 @@ def main():
     bwt.set_block_format(args.blocks)
     if args.table_depth > -2:
         bwt.set_table_depth(args.table_depth)
+    if args.sparse_depth > -2:
+        bwt.set_sparse_table(args.sparse_depth)
+    # the index is built for the k it will be asked about (a deployment knows its k; results never depend on it): the automatic sparse
+    # table then reaches min(k, 27) -- a table of d-mers serves k >= d only
+    bwt.set_query_length(k if args.query_length_hint < 0 else args.query_length_hint)
     if args.no_table_side:
         bwt.set_table_side(0)
     t0 = time.time()
@@ -986,7 +994,7 @@ def main():
             "workload": wl, "k": k, "queries_per_step": job_queries, "queries_per_gpu": mine_n if strong else nq,
             "bwt_symbols": total, "index_bytes": bwt.device_bytes(),
             "table_depth": lookup_depth(bwt, k), "direct_table_depth": bwt.get_table_depth(), "sparse_table_depth": bwt.get_sparse_table(),
-            "sparse_table": {kk: vv for kk, vv in bwt.sparse_table_info().items() if kk != "wide"},
+            "sparse_table": {kk: vv for kk, vv in bwt.sparse_table_info().items() if kk != "wide"}, "query_length_hint": bwt.get_query_length(),
             "pair_index": bwt.get_pair_index(), "pair_stride": bwt.get_pair_stride(),
             "typical_range_width": bwt.get_typical_range_width(), "block_format": bwt.get_block_format(),
             "parallelism": ("index replicated x%d; %s; per step one %s all_gather of all counts (%s payload, widened to u64 on "
@@ -1140,6 +1148,7 @@ def main():
             log("%s: real MSBWT %s ready after %.1fs of waiting" % (key, os.path.basename(npy4), time.time() - t0))
             t0 = time.time()
             bwt4 = msbwt.RleBWT(device=local_rank)
+            bwt4.set_query_length(31 if args.query_length_hint < 0 else args.query_length_hint)
             bwt4.load_numpy_file(npy4)
             total4 = bwt4.get_total_size()
             n4 = max(1000, int(args.c4_queries * min(1.0, c4_scale * 4))) if c4_scale < 1.0 else args.c4_queries
@@ -1292,6 +1301,8 @@ def main():
         torch.cuda.empty_cache()
         t0 = time.time()
         child_args = ((["--k", str(args.k)] if args.k else []) + (["--table-depth", str(args.table_depth)] if args.table_depth > -2 else []) +
+                      (["--sparse-depth", str(args.sparse_depth)] if args.sparse_depth > -2 else []) +
+                      (["--query-length-hint", str(args.query_length_hint)] if args.query_length_hint >= 0 else []) +
                       (["--genome", args.genome] if args.genome != "random" else []))
         if args.genome == "repeats":   # (a lab line whose index takes longer to build: the read pass only, the writes are the counts)
             per_q, detail = live_pmc_traffic(child_args, 100_000_000, counters=("FETCH_SIZE",), patience=900)

@@ -258,8 +258,8 @@ int msbwt_rle_table_info(const msbwt_rle *bwt, uint64_t *lines, uint64_t *escape
 int msbwt_auto_table_depths(uint64_t total_symbols, uint64_t free_hbm_bytes, int pair_index, int *flat_depth, int *packed_depth);
 int msbwt_rle_get_table_packed(const msbwt_rle *bwt);
 /* Sparse suffix table (the reference's stubbed kmer_cache, src/msbwt_core.rs:133-146 / src/rle_bwt.rs:332-346, taken past what a
- * direct-address table can hold): the ranges of the `depth`-symbol suffixes that OCCUR in the BWT, 16 <= depth <= 24, as a hashed
- * table of 128-byte buckets of 14 entries (layout and hash: rust-msbwt_amd/csrc/sparse_table.hpp).  The direct table above has 4^depth
+ * direct-address table can hold): the ranges of the `depth`-symbol suffixes that OCCUR in the BWT, 16 <= depth <= 31, as a hashed
+ * table of 128-byte buckets of 14 entries (12 with 32-bit tags from depth 25 on, 11 with 40-bit tags from depth 30 on; layout and hash: rust-msbwt_amd/csrc/sparse_table.hpp).  The direct table above has 4^depth
  * entries whatever the data -- 73 GB at depth 17, of which a 30x human read set can fill 17 % and a chr20-sized one 0.4 % -- while a
  * table of the present suffixes reaches depth 23 in about 14 bytes per distinct 23-mer: every present 31-mer is three pair steps
  * (of seven) shorter.  One lookup = one random 128-byte line, fetched like any search step's; the table is complete, so a miss is
@@ -269,28 +269,40 @@ int msbwt_rle_get_table_packed(const msbwt_rle *bwt);
  * index; the one-query-per-lane kernel uses it for every batch with k >= depth, shorter k-mers (and k-mers with '$' / 'N' among
  * their last `depth` symbols) use the direct table, which then stays small (packed depth 15 at most when automatic).
  * depth: -1 = automatic (default: the deepest depth <= 23 whose table fits HBM -- and a memory budget, if one is set -- with an
- * eighth of the device left free; none if no depth fits, e.g. a read set whose error k-mers outnumber everything), 0 = off, 16..24 =
- * exactly that depth (an error if it cannot be built).  MSBWT_SPARSE_TABLE=<depth>|auto|0 in the environment sets the initial mode.
+ * eighth of the device left free; none if no depth fits, e.g. a read set whose error k-mers outnumber everything), 0 = off, 16..31 =
+ * exactly that depth (an error if it cannot be built; a table serves k >= its depth: a caller that counts 31-mers gains two pair
+ * steps per query from depth 27 -- 3 index lines instead of 5 -- and loses the table for k = 23..26).  MSBWT_SPARSE_TABLE=<depth>|auto|0 in the environment sets the initial mode.
  * Takes effect immediately if an index is loaded.  Results never change.
  * msbwt_rle_get_sparse_table: depth of the table in HBM, 0 = none.
  * msbwt_rle_sparse_table_info: out[MSBWT_SPARSE_INFO_WORDS] = [0] depth, [1] entries, [2] buckets, [3] bytes of the bucket lines,
  * [4] entries in the side array, [5] its bytes, [6] entries displaced to a later bucket, [7] depth of the direct table the build
- * started from, [9] buckets a lookup may go beyond its own, [10 + d] DISTINCT d-symbol suffixes that occur (d = 0..24; 0 where the
- * build did not pass: it advances two symbols at a time), [35 + d] of which 255 or more wide.  The counts are kept even when no
+ * started from, [9] buckets a lookup may go beyond its own, [10 + d] DISTINCT d-symbol suffixes that occur (d = 0..31; 0 where the
+ * build did not pass: it advances two symbols at a time), [45 + d] of which 255 or more wide.  The counts are kept even when no
  * table was built.
  * msbwt_sparse_hash / msbwt_sparse_table_shape: the table's hash and sizing as pure functions (no device needed).
  * msbwt_rle_download_sparse_table: copies the bucket lines (and the side array) to the host; returns the bytes of the lines,
  * SIZE_MAX without a table or on error (tests check every entry against the oracle). */
-#define MSBWT_SPARSE_INFO_WORDS 64
+#define MSBWT_SPARSE_INFO_WORDS 80
 int msbwt_rle_set_sparse_table(msbwt_rle *bwt, int depth);
 int msbwt_rle_get_sparse_table(const msbwt_rle *bwt);
 int msbwt_rle_sparse_table_info(const msbwt_rle *bwt, uint64_t *out);
 int msbwt_sparse_hash(uint64_t key, int depth, uint64_t nbuckets, uint32_t *bucket, uint32_t *tag);
+int msbwt_sparse_hash64(uint64_t key, int depth, uint64_t nbuckets, uint32_t *bucket, uint64_t *tag); /* the whole tag: 24, 32 or 40 bits by depth */
 int msbwt_sparse_table_shape(int depth, uint64_t entries, uint64_t *nbuckets, int *probe);
-/* The automatic depth as a pure function (no device needed; rust-msbwt_amd/csrc/sparse_policy.hpp): distinct[d] / wide[d] for d = 0..24
- * as msbwt_rle_sparse_table_info reports them ([10 + d], [35 + d]), the depth of the direct table the count started from, and the bytes
+/* The automatic depth as a pure function (no device needed; rust-msbwt_amd/csrc/sparse_policy.hpp): distinct[d] / wide[d] for d = 0..31
+ * as msbwt_rle_sparse_table_info reports them ([10 + d], [45 + d]), the depth of the direct table the count started from, and the bytes
  * the table and its build scratch may take -> the depth the loader would build (0 = none fits) and the bytes of that table. */
-int msbwt_auto_sparse_depth(const uint64_t *distinct, const uint64_t *wide, int parent_depth, uint64_t avail_bytes, int *depth, uint64_t *table_bytes);
+int msbwt_auto_sparse_depth(const uint64_t *distinct, const uint64_t *wide, int parent_depth, uint64_t avail_bytes, int query_length, int *depth, uint64_t *table_bytes);
+/* The k the index will mostly be asked about (0 = unknown, the default; MSBWT_QUERY_K in the environment sets the initial value).  The
+ * reference's count_kmer takes any k per call and so does this library -- results never depend on the hint -- but a hashed table of
+ * d-mers serves k >= d only, and every two symbols of depth save a present k-mer one index line: with k unknown the automatic sparse
+ * table stops at depth 23 (every k >= 23 is served: 5 lines for a present 31-mer); a caller that declares k = 31 gets depth 31 -- the table's range IS the count, one line per query
+ * (depth 29: 2 lines, 1.92e10 present 31-mers/s at 30x-human scale; depth 27: 3 lines, 1.34e10; k unknown: 5 lines, 8.4e9) -- and k = 21 gets depth 21.  Shorter k-mers than the table's depth use the
+ * direct table as before.  Only the AUTOMATIC depth follows the hint (msbwt_rle_set_sparse_table(-1)); it takes effect immediately if an
+ * index is loaded (the tables are rebuilt).  msbwt_auto_sparse_max_depth: the rule as a pure function. */
+int msbwt_rle_set_query_length(msbwt_rle *bwt, int k);
+int msbwt_rle_get_query_length(const msbwt_rle *bwt);
+int msbwt_auto_sparse_max_depth(int query_length);
 size_t msbwt_rle_download_sparse_table(const msbwt_rle *bwt, void *out_lines, size_t cap_bytes, void *out_side, size_t cap_side_bytes);
 /* Presence filter: one bit per ACGT suffix of length min(12, table depth), set when some table
  * entry with that suffix is a non-empty range; at most 2 MiB, so it lives in L2 and decides

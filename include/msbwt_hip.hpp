@@ -174,8 +174,11 @@ class RleBWT final : public BWT {
     void set_memory_budget(std::uint64_t bytes) { check(msbwt_rle_set_memory_budget(raw_, bytes)); }
     /// 1 = the library orders every batch it can before counting it; 0 and -1 (the default) = never: a switch, there is no automatic mode
     void set_batch_order(int mode) { check(msbwt_rle_set_batch_order(raw_, mode)); }
-    /// sparse suffix table (the suffixes that occur, one hashed 128-byte bucket per lookup): -1 = automatic (default), 0 = off, 16..24 = that depth
+    /// sparse suffix table (the suffixes that occur, one hashed 128-byte bucket per lookup): -1 = automatic (default), 0 = off, 16..31 = that depth
     void set_sparse_table(int depth) { check(msbwt_rle_set_sparse_table(raw_, depth)); }
+    /// the k this index will mostly be asked about (0 = unknown): the automatic sparse table reaches min(k, 27) instead of 23
+    void set_query_length(int k) { check(msbwt_rle_set_query_length(raw_, k)); }
+    int get_query_length() const { return msbwt_rle_get_query_length(raw_); }
     int get_sparse_table() const { return msbwt_rle_get_sparse_table(raw_); }
     void set_table_side(int mode) { check(msbwt_rle_set_table_side(raw_, mode)); }
     std::uint64_t device_bytes() const { return msbwt_rle_device_bytes(raw_); }

@@ -66,7 +66,8 @@ SIGNATURES = {
     "msbwt_rle_sparse_table_info": (_int, [_vp, _pu64]),
     "msbwt_sparse_hash": (_int, [_u64, _int, _u64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "msbwt_sparse_table_shape": (_int, [_int, _u64, _pu64, C.POINTER(C.c_int)]),
-    "msbwt_auto_sparse_depth": (_int, [_pu64, _pu64, _int, _u64, C.POINTER(C.c_int), _pu64]),
+    "msbwt_sparse_hash64": (_int, [_u64, _int, _u64, C.POINTER(C.c_uint32), _pu64]),
+    "msbwt_auto_sparse_depth": (_int, [_pu64, _pu64, _int, _u64, _int, C.POINTER(C.c_int), _pu64]),
     "msbwt_rle_download_sparse_table": (_sz, [_vp, _vp, _sz, _vp, _sz]),
     "msbwt_rle_set_search_counters": (_int, [_vp, _int]),
     "msbwt_rle_search_counters": (_int, [_vp, _vp, _vp]),
@@ -84,6 +85,9 @@ SIGNATURES = {
     "msbwt_rle_get_pair_stride": (_int, [_vp]),
     "msbwt_rle_get_typical_range_width": (C.c_double, [_vp]),
     "msbwt_auto_pair_stride": (_int, [_u64, _u64, _u64, C.c_double, C.POINTER(C.c_int)]),
+    "msbwt_rle_set_query_length": (_int, [_vp, _int]),
+    "msbwt_rle_get_query_length": (_int, [_vp]),
+    "msbwt_auto_sparse_max_depth": (_int, [_int]),
     "msbwt_rle_set_line_streaming": (_int, [_vp, _int]),
     "msbwt_rle_get_line_streaming": (_int, [_vp]),
     "msbwt_rle_probe_line_rate": (_int, [_vp, _int, C.POINTER(C.c_double)]),

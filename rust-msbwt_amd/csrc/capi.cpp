@@ -65,7 +65,8 @@ struct msbwt_rle {
     uint32_t sparse_nbuckets = 0, sparse_probe = 0;
     int sparse_depth = 0;
     int wanted_streaming = -1;       // index lines fetched non-temporally: -1 = when the random-access arrays dwarf the caches, 0 = never, 1 = always
-    int wanted_sparse = -1;          // -1 = automatic (beside a pair index, as deep as the data and HBM allow, at most 23), 0 = off, 16..24 = that depth
+    int wanted_sparse = -1;          // -1 = automatic (beside a pair index, as deep as the data and HBM allow, at most 23 -- or what query_length says), 0 = off, 16..28 = that depth
+    int query_length = 0;            // the k the index will mostly be asked about (msbwt_rle_set_query_length), 0 = unknown
     SparseBuildReport sparse_report{};
     bool counting = false;           // search counters wanted (msbwt_rle_set_search_counters)
     int wanted_table_packed = -1; // -1 = pack when the data warrants it and it fits, 0 = never, 1 = whenever a pair index exists
@@ -125,6 +126,7 @@ constexpr uint64_t kStreamLinesFrom = uint64_t(4) << 30;  // random-access array
 constexpr size_t kStatusBytes = 1024;  // flag words, debug record (bytes 64..128), search counters (bytes 128..256)
 constexpr size_t kCountersOffset = 128;
 static_assert(MSBWT_SEARCH_COUNTERS == kSearchCounters, "the header's counter block is the kernels'");
+static_assert(10 + kSparseMaxDepth + 1 <= 45 && 45 + kSparseMaxDepth + 1 <= MSBWT_SPARSE_INFO_WORDS, "msbwt_rle_sparse_table_info: [10 + d] distinct, [45 + d] wide");
 constexpr size_t kPackScratchOffset = 256;  // two u64 of the table packer (escape-line count, side-array cursor)
 constexpr size_t kMaxTimedEvents = 256;  // start/stop pairs kept before timed_launch folds them into the running sum
 constexpr int kHostFlags = 0, kDeviceFlags = 1;  // words of the status block
@@ -393,7 +395,7 @@ int build_sparse(msbwt_rle *h, uint64_t keep_free, uint64_t allowance) {
     const bool explicit_depth = h->wanted_sparse > 0;
     const void *flat = (h->d_table && !h->table_packed) ? h->d_table : nullptr;
     const int flat_depth = flat ? h->table_depth : 0;
-    const int max_depth = explicit_depth ? h->wanted_sparse : kSparseAutoDepth;
+    const int max_depth = explicit_depth ? h->wanted_sparse : sparse_auto_max_depth(h->query_length);
     if (max_depth <= flat_depth || max_depth < kSparseMinDepth) return explicit_depth ? fail(h, MSBWT_ERR_INVALID_ARG, "sparse table depth must exceed the direct table's") : MSBWT_OK;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return MSBWT_OK;
@@ -1090,6 +1092,7 @@ msbwt_rle *msbwt_rle_new_on_device(uint8_t bin_power, int device) {
     if (const char *env = std::getenv("MSBWT_TABLE_PACKED")) h->wanted_table_packed = std::atoi(env) ? 1 : 0;
     if (const char *env = std::getenv("MSBWT_TABLE_SIDE")) h->wanted_table_side = std::atoi(env) ? 1 : 0;
     if (const char *env = std::getenv("MSBWT_STREAM_LINES")) h->wanted_streaming = std::strcmp(env, "auto") == 0 ? -1 : (std::atoi(env) ? 1 : 0);
+    if (const char *env = std::getenv("MSBWT_QUERY_K")) h->query_length = std::max(0, std::atoi(env));
     if (const char *env = std::getenv("MSBWT_SPARSE_TABLE")) {
         const int d = std::strcmp(env, "auto") == 0 ? -1 : std::atoi(env);
         h->wanted_sparse = (d == 0 || d == -1 || (d >= kSparseMinDepth && d <= kSparseMaxDepth)) ? d : -1;
@@ -1566,6 +1569,7 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
     h->wanted_table_packed = src->wanted_table_packed;
     h->wanted_table_side = src->wanted_table_side;
     h->wanted_sparse = src->wanted_sparse;
+    h->query_length = src->query_length;
     h->wanted_streaming = src->wanted_streaming;
     h->wanted_block_format = src->wanted_block_format;
     h->block_format = src->block_format;
@@ -2021,6 +2025,21 @@ int msbwt_rle_set_sparse_table(msbwt_rle *h, int depth) {
 
 int msbwt_rle_get_sparse_table(const msbwt_rle *h) { return (h && h->d_sparse && h->d_pair_blocks) ? h->sparse_depth : 0; }
 
+int msbwt_rle_set_query_length(msbwt_rle *h, int k) {
+    if (!h || k < 0) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    const bool changes = sparse_auto_max_depth(k) != sparse_auto_max_depth(h->query_length);
+    h->query_length = k;
+    if (!h->loaded || !changes || h->wanted_sparse >= 0) return MSBWT_OK;  // (an explicit depth, or none at all, does not follow the hint)
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    return rebuild_table(h);
+}
+
+int msbwt_rle_get_query_length(const msbwt_rle *h) { return h ? h->query_length : 0; }
+
+int msbwt_auto_sparse_max_depth(int query_length) { return sparse_auto_max_depth(query_length); }
+
 int msbwt_rle_sparse_table_info(const msbwt_rle *ch, uint64_t *out) {
     msbwt_rle *h = const_cast<msbwt_rle *>(ch);
     if (!h || !out) return MSBWT_ERR_INVALID_ARG;
@@ -2040,7 +2059,7 @@ int msbwt_rle_sparse_table_info(const msbwt_rle *ch, uint64_t *out) {
     out[7] = uint64_t(r.parent_depth);
     for (int d = 0; d <= kSparseMaxDepth; ++d) {
         out[10 + d] = r.distinct[d];
-        out[10 + kSparseMaxDepth + 1 + d] = r.escapes[d];
+        out[45 + d] = r.escapes[d];
     }
     return MSBWT_OK;
 }
@@ -2049,13 +2068,21 @@ int msbwt_sparse_hash(uint64_t key, int depth, uint64_t nbuckets, uint32_t *buck
     if (depth < kSparseMinDepth || depth > kSparseMaxDepth || nbuckets == 0 || nbuckets > 0xFFFFFFFFull || !bucket || !tag) return MSBWT_ERR_INVALID_ARG;
     const uint64_t x = sparse_mix(key, uint32_t(2 * depth));
     *bucket = sparse_bucket(x, uint32_t(2 * depth), uint32_t(nbuckets));
-    *tag = sparse_tag(x);
+    *tag = sparse_tag(x, uint32_t(depth));
     return MSBWT_OK;
 }
 
-int msbwt_auto_sparse_depth(const uint64_t *distinct, const uint64_t *wide, int parent_depth, uint64_t avail_bytes, int *depth, uint64_t *table_bytes) {
-    if (!distinct || !wide || !depth || parent_depth < 0 || parent_depth > 16) return MSBWT_ERR_INVALID_ARG;
-    const SparseChoice c = choose_sparse_depth(distinct, wide, parent_depth, kSparseAutoDepth, avail_bytes, 0);
+int msbwt_sparse_hash64(uint64_t key, int depth, uint64_t nbuckets, uint32_t *bucket, uint64_t *tag) {
+    if (depth < kSparseMinDepth || depth > kSparseMaxDepth || nbuckets == 0 || nbuckets > 0xFFFFFFFFull || !bucket || !tag) return MSBWT_ERR_INVALID_ARG;
+    const uint64_t x = sparse_mix(key, uint32_t(2 * depth));
+    *bucket = sparse_bucket(x, uint32_t(2 * depth), uint32_t(nbuckets));
+    *tag = (uint64_t(sparse_tag_hi(x, uint32_t(depth))) << 32) | sparse_tag(x, uint32_t(depth));
+    return MSBWT_OK;
+}
+
+int msbwt_auto_sparse_depth(const uint64_t *distinct, const uint64_t *wide, int parent_depth, uint64_t avail_bytes, int query_length, int *depth, uint64_t *table_bytes) {
+    if (!distinct || !wide || !depth || parent_depth < 0 || parent_depth > 16 || query_length < 0) return MSBWT_ERR_INVALID_ARG;
+    const SparseChoice c = choose_sparse_depth(distinct, wide, parent_depth, sparse_auto_max_depth(query_length), avail_bytes, 0);
     *depth = c.depth;
     if (table_bytes) *table_bytes = c.bytes;
     return MSBWT_OK;

@@ -318,6 +318,72 @@ __device__ __forceinline__ bool sparse_scan(const uint4 *lines, uint32_t slot, u
     return true;
 }
 
+// The WIDE layout of depths 25..28 (sparse_table.hpp): 12 entries, the tag is the whole word, the width a byte of its own.
+__device__ __forceinline__ bool sparse_scan_wide(const uint4 *lines, uint32_t slot, uint32_t want, uint64_t &l, uint32_t &width, uint32_t &header) {
+    const uint32_t base = line_base(slot), g = slot & 7u;
+    const uint4 c0 = lines[base + (0u ^ g)], c1 = lines[base + (1u ^ g)], c2 = lines[base + (2u ^ g)];
+    const uint32_t tags[kSparseWideSlots] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w};
+    uint32_t hit = kSparseWideSlots;
+#pragma unroll
+    for (int i = int(kSparseWideSlots) - 1; i >= 0; --i) hit = tags[i] == want ? uint32_t(i) : hit;  // the lowest matching slot: an entry beats an empty slot
+    header = lines[base + (7u ^ g)].w >> 16;
+    width = 0;
+    if (hit >= kSparseWideSlots) return false;
+    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(lines);
+    const uint32_t wb = kSparseWideWidthByte + hit, hb = kSparseWideHiByte + hit;
+    width = bytes[(base + ((wb >> 4) ^ g)) * 16u + (wb & 15u)];
+    if (width == 0u) return false;  // an empty slot (a key whose tag is 0 matches it)
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(lines);
+    const uint32_t word = kSparseWideL0Word + hit;
+    const uint32_t lo = words[(base + ((word >> 2) ^ g)) * 4u + (word & 3u)];
+    const uint32_t hi = bytes[(base + ((hb >> 4) ^ g)) * 16u + (hb & 15u)];
+    l = (uint64_t(hi) << 32) | lo;
+    return true;
+}
+
+// The XWIDE layout of depths 30..31: 11 entries, 40-bit tags (a low word and a byte).  The low words alone nearly always decide; the
+// candidate's high byte is checked, and should it differ the scan goes on behind it (two keys of one probe window may share their low
+// 32 bits -- never all 40).
+__device__ __forceinline__ bool sparse_scan_xwide(const uint4 *lines, uint32_t slot, uint64_t want, uint64_t &l, uint32_t &width, uint32_t &header) {
+    const uint32_t base = line_base(slot), g = slot & 7u;
+    const uint4 c0 = lines[base + (0u ^ g)], c1 = lines[base + (1u ^ g)], c2 = lines[base + (2u ^ g)];
+    const uint32_t tags[kSparseXSlots] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z};
+    const uint32_t want_lo = uint32_t(want), want_hi = uint32_t(want >> 32) & 0xFFu;
+    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(lines);
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(lines);
+    auto byte_at = [&](uint32_t b) -> uint32_t { return bytes[(base + ((b >> 4) ^ g)) * 16u + (b & 15u)]; };
+    header = lines[base + (7u ^ g)].w >> 16;
+    width = 0;
+    uint32_t cand = 0;  // bit i: slot i's low word matches (the words need not stay in registers beyond this)
+#pragma unroll
+    for (uint32_t i = 0; i < kSparseXSlots; ++i) cand |= (tags[i] == want_lo ? 1u : 0u) << i;
+    while (cand != 0u) {  // lowest candidate first: one round, but for low words shared by chance
+        const uint32_t hit = uint32_t(__builtin_ctz(cand));
+        const uint32_t w = byte_at(kSparseXWidthByte + hit);
+        if (w == 0u) return false;  // an empty slot whose zero low word matched: a bucket fills from slot 0 up, nothing lies behind it
+        if (byte_at(kSparseXTagHiByte + hit) == want_hi) {
+            width = w;
+            const uint32_t word = kSparseXL0Word + hit;
+            const uint32_t lo = words[(base + ((word >> 2) ^ g)) * 4u + (word & 3u)];
+            l = (uint64_t(byte_at(kSparseXHiByte + hit)) << 32) | lo;
+            return true;
+        }
+        cand &= cand - 1u;  // an entry that shares the low word only
+    }
+    return false;
+}
+
+// (the k > 32 instantiations sit at their register limit: they take the xwide scan as a call, not inlined)
+struct SparseScanOut {
+    uint64_t l;
+    uint32_t width, header, hit;
+};
+__device__ __attribute__((noinline)) SparseScanOut sparse_scan_xwide_call(const uint4 *lines, uint32_t slot, uint64_t want) {  // (results by value: no stack)
+    SparseScanOut o{0, 0, 0, 0};
+    o.hit = sparse_scan_xwide(lines, slot, want, o.l, o.width, o.header) ? 1u : 0u;
+    return o;
+}
+
 // kPacked (matrix mode only): the queries come as 2-bit words (QuerySource::packed), possibly with a place for each count.
 // A compile-time switch, not a launch-uniform branch: with both ways of fetching a tile in one kernel the compiler merged
 // their results through register copies, i.e. WAITED for the tile's bytes right after asking for them -- setup no longer
@@ -361,6 +427,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     // stream).  Round 5, human scale, alternating on one box: 38.4 ms (36.7-39.8) by default, 36.1 ms (35.6-36.6) streaming; C3 fused,
     // whose pair blocks half live in the Infinity Cache, 14.9 -> 19.8 ms -- hence a launch-uniform switch, not a constant.
     const bool stream_lines = (table_packed & 2u) != 0u;
+    // the sparse table's layout follows its depth (launch-uniform): 14 entries with 24-bit tags up to depth 24, 12 with 32-bit tags beyond
+    const bool sparse_wide_layout = kSparse && sparse_wide(depth);
+    const uint32_t sparse_nslots = sparse_slots(depth);
+    const bool sparse_xwide_layout = kSparse && sparse_xwide(depth);
+    auto scan_bucket = [&](uint32_t slot, uint64_t want, uint64_t &tl, uint32_t &tw, uint32_t &header) -> bool {  // want: the tag, up to 40 bits
+        if (sparse_xwide_layout) {
+            if constexpr (kWords == 6) {
+                const SparseScanOut o = sparse_scan_xwide_call(ws.lines, slot, want);
+                tl = o.hit ? o.l : tl;
+                tw = o.width;
+                header = o.header;
+                return o.hit != 0u;
+            } else {
+                return sparse_scan_xwide(ws.lines, slot, want, tl, tw, header);
+            }
+        }
+        return sparse_wide_layout ? sparse_scan_wide(ws.lines, slot, uint32_t(want), tl, tw, header) : sparse_scan(ws.lines, slot, uint32_t(want), tl, tw, header);
+    };
     // optional search counters (kernels.hpp, SearchCounter): wave sums kept in LDS, added to the caller's block at the end
     const bool counting = kCounting && counters != nullptr;
     if (counting && lane < uint32_t(kSearchCounters)) ws.cnt[lane] = 0u;
@@ -573,7 +657,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 it.l_lo = uint32_t(pl);
                 it.h_lo = uint32_t(ph);
                 it.meta = uint32_t(pl >> 32) | (uint32_t(ph >> 32) << 8) | (prep_rem << 16) | (lane << 24);  // l, h < 2^40; rem <= 64
-                if (kSparse && lookup) it.meta = prep_entry.z | (prep_rem << 16) | (lane << 24) | (1u << 23);  // (buckets gone beyond its own so far)
+                if (kSparse && lookup) it.meta = prep_entry.z | (prep_rem << 16) | (lane << 24) | (1u << 23);  // (z: buckets gone beyond its own so far, and the tag's high byte)
 #pragma unroll
                 for (int i = 0; i < kWords; ++i) it.w[i] = prep_w[i];
                 if constexpr (kPacked) it.out = prep_out;
@@ -601,7 +685,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 if (kSparse && tmode) {
                     tdist = it.meta & 0xFFu;
                     l = it.l_lo;
-                    h = it.h_lo;
+                    h = (uint64_t((it.meta >> 8) & 0xFFu) << 32) | it.h_lo;  // the tag (40 bits in the xwide layout)
                 }
                 qid = ring_tile * kTile + (it.meta >> 24);
                 if constexpr (kPacked) qid = place_of(qid, it.out);
@@ -698,8 +782,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                         if constexpr (kSparse) {  // nothing to fetch here: the bucket line is the query's first search step
                             const uint64_t x = sparse_mix(pq.tidx, 2u * depth);
                             prep_entry.x = sparse_bucket(x, 2u * depth, sparse_nbuckets);
-                            prep_entry.y = sparse_tag(x);
-                            prep_entry.z = 0u;  // buckets gone beyond its own
+                            prep_entry.y = sparse_tag(x, depth);
+                            prep_entry.z = sparse_tag_hi(x, depth) << 8;  // low byte: buckets gone beyond its own; next byte: bits 32..39 of the tag (xwide layout; else 0)
                             prep_kind = 3;
                         } else {
                             prep_entry = table_fetch(env, pq.tidx);  // stays in flight: consumed in step A of a later iteration
@@ -843,11 +927,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             if (riding) {
                 uint64_t tl = 0;
                 uint32_t tw = 0, header = 0;
-                if (sparse_scan(ws.lines, slot_ride, prep_entry.y, tl, tw, header)) {
+                if (scan_bucket(slot_ride, (uint64_t((prep_entry.z >> 8) & 0xFFu) << 32) | prep_entry.y, tl, tw, header)) {
                     prep_entry.x = uint32_t(tl);
                     prep_entry.y = uint32_t(tl >> 32) | (tw << 8);
                     prep_kind = 4;
-                } else if (header > kSparseSlots && prep_entry.z < sparse_probe) {  // entries of this bucket were displaced: the next one, next time
+                } else if (header > sparse_nslots && (prep_entry.z & 0xFFu) < sparse_probe) {  // entries of this bucket were displaced: the next one, next time
                     ++prep_entry.x;
                     ++prep_entry.z;
                 } else {  // a miss in a complete table: the suffix does not occur (msbwt_core.rs:151-153)
@@ -866,7 +950,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             if (kSparse && looking) {  // this step fetched the query's own bucket
                 uint64_t tl = 0;
                 uint32_t width = 0, header = 0;
-                const bool hit = sparse_scan(ws.lines, slot_l, uint32_t(h), tl, width, header);
+                const bool hit = scan_bucket(slot_l, h, tl, width, header);
                 nl = nh = 0;
                 step_done = false;
                 if (hit) {
@@ -882,7 +966,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                         store_count<kReads>(src, qid, h - l);
                         have = false;
                     }
-                } else if (header > kSparseSlots && tdist < sparse_probe) {  // entries of this bucket were displaced: the next one
+                } else if (header > sparse_nslots && tdist < sparse_probe) {  // entries of this bucket were displaced: the next one
                     ++l;
                     ++tdist;
                 } else {  // a miss in a complete table: the suffix does not occur (msbwt_core.rs:151-153)

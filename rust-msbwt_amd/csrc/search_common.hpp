@@ -248,7 +248,7 @@ __device__ __forceinline__ void pack_row_swar(uint32_t k, uint32_t depth, const 
         const uint32_t z = ((y >> 8) | (y << 3)) & 0x003F003Fu;
         const uint32_t g = ((z >> 16) | (z << 6)) & 0xFFFu;
         constexpr_shift_or12<kBits>(pq.bits, g, 12u * u);
-        if (u < 6u) {  // the tables reach at most 24 steps deep (sparse_table.hpp)
+        if (u < 8u) {  // the tables reach at most 29 steps deep (sparse_table.hpp): the block's last 32 symbols
             const uint32_t dm = tail_byte_mask(d, first_d);
             const uint32_t ys = (y & dm) | (0x01010101u & ~dm);
             const uint32_t low2 = ys & 0x03030303u;
@@ -258,7 +258,7 @@ __device__ __forceinline__ void pack_row_swar(uint32_t k, uint32_t depth, const 
             tidx |= uint64_t(((z2 >> 16) | (z2 << 4)) & 0xFFu) << (8u * u);
         }
     }
-    pq.tidx = tidx & ((1ull << (2u * min(depth, 24u))) - 1ull);
+    pq.tidx = tidx & ((1ull << (2u * min(depth, 31u))) - 1ull);
     pq.bad = bad != 0u;
     pq.acgt = nonacgt == 0u;
 }
@@ -372,7 +372,7 @@ template <int kWords>
 __device__ __forceinline__ void unpack_words(const PackedQuery<kWords> &pq, uint32_t skip, uint32_t (&w)[kWords]) {
     constexpr int kBits = PackedQuery<kWords>::kBits;
     uint64_t bits[kBits];
-    // 0, or 3..72 (the sparse table reaches 24 symbols deep): whole words first, then the bits (wave-uniform)
+    // 0, or 3..87 (the sparse table reaches 29 symbols deep): whole words first, then the bits (wave-uniform)
     const bool whole = 3u * skip >= 64u;
     const uint32_t sh = 3u * skip - (whole ? 64u : 0u);
 #pragma unroll

@@ -22,6 +22,16 @@ struct SparseChoice {
     uint64_t build_bytes = 0; // ... + the slot counters the fill pass needs beside them
 };
 
+// How deep the AUTOMATIC table may go, given the k the index will mostly be asked about (msbwt_rle_set_query_length; 0 = unknown).
+// A hashed table of d-mers serves k >= d only, and every two symbols of depth save a present k-mer one index line: unknown -> 23 (serves
+// every k >= 23; what round 5 shipped), a declared k -> that k, within what the format reaches (16..31: a present 31-mer behind depth 27
+// needs 3 lines instead of 5, behind depth 29 two -- 1.34e10 and 1.92e10 against 8.4e9 q/s at human scale --, behind depth 31 the one bucket).  Whether the deepest depths
+// are WORTH their memory is choose_sparse_depth's call: depth 29 needs 2^29 buckets (69 GB) whatever the index holds.
+inline int sparse_auto_max_depth(int query_length) {
+    if (query_length <= 0) return kSparseAutoDepth;
+    return std::max(kSparseMinDepth, std::min(query_length, kSparseMaxDepth));
+}
+
 // distinct[d] / wide[d]: non-empty ranges at depth d and how many of them are 255 or more wide (0 for depths the pass did not reach);
 // parent_depth: the direct table the pass started from; avail: bytes the table (and its build scratch) may take;
 // explicit_depth: 0 = automatic, else exactly that depth or nothing.
@@ -29,10 +39,14 @@ inline SparseChoice choose_sparse_depth(const uint64_t *distinct, const uint64_t
     SparseChoice none;
     for (int d = std::min(max_depth, kSparseMaxDepth); d >= kSparseMinDepth && d > parent_depth; --d) {
         if (explicit_depth ? d != explicit_depth : distinct[d] == 0) continue;  // not a level of the pass (the other parity), or nothing occurs
-        const uint64_t needed = uint64_t(double(distinct[d]) / kSparseLoad) + 1, nb = sparse_buckets_for(d, distinct[d]);
+        const uint64_t needed = uint64_t(double(distinct[d]) / sparse_load(d)) + 1, nb = sparse_buckets_for(d, distinct[d]);
         const uint64_t lines = nb + kSparseMaxProbe;
         if (lines > 0xFFFFFFFFull) continue;
-        if (!explicit_depth && sparse_min_buckets(d) > std::max<uint64_t>(16 * needed, 65536)) continue;
+        // a table that the tags force to be far larger than its entries need is not worth its depth: 16 x for the cheap depths (a toy index
+        // gets a toy table), 4 x for depth 29, whose least size is 69 GB (a human-scale index fills it to 72 % of the aimed load; a
+        // chr20-sized one would fill 7 % and takes depth 27 in 4.3 GB instead)
+        const uint64_t slack = d == 29 ? 4 : 16;
+        if (!explicit_depth && sparse_min_buckets(d) > std::max<uint64_t>(slack * needed, 65536)) continue;
         SparseChoice c;
         c.depth = d;
         c.nbuckets = nb;

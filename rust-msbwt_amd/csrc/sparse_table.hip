@@ -35,6 +35,7 @@ constexpr int kAccEscape = 64;  // [64 .. 96): nodes 255 or more wide, per depth
 constexpr int kCurEscape = 96;  // [96 .. 128): the same for the chunk in hand
 constexpr int kOverflow = 128, kFailed = 129, kSideCursor = 130, kDisplaced = 131;
 constexpr int kCursorWords = 160;
+static_assert(kSparseMaxDepth < 32, "a cursor per depth the expansion can reach");
 
 // this thread's first of `mine` consecutive slots behind *cursor: one atomic per workgroup.  Every thread of the block calls it.
 __device__ __forceinline__ uint64_t reserve(uint32_t mine, unsigned long long *cursor) {
@@ -148,7 +149,9 @@ struct FillEnv {
 __device__ __forceinline__ void sparse_insert(const FillEnv &env, uint64_t key, uint64_t nl, uint64_t nh, unsigned long long *cur) {
     const uint64_t x = sparse_mix(key, env.n);
     uint32_t b = sparse_bucket(x, env.n, env.nbuckets);
-    const uint32_t tag = sparse_tag(x);
+    const uint32_t depth = env.n >> 1;
+    const bool wide = sparse_wide(depth), xwide = sparse_xwide(depth);  // launch-uniform: the layout follows the depth (sparse_table.hpp)
+    const uint32_t tag = sparse_tag(x, depth), tag_hi = sparse_tag_hi(x, depth), slots = sparse_slots(depth);
     uint64_t lval = nl;
     uint32_t wf = uint32_t(nh - nl);
     if (nh - nl >= kSparseEscapeWidth) {
@@ -159,11 +162,24 @@ __device__ __forceinline__ void sparse_insert(const FillEnv &env, uint64_t key, 
     }
     for (uint32_t dist = 0; dist <= env.probe; ++dist, ++b) {
         const uint32_t slot = atomicAdd(env.counts + b, 1u);
-        if (slot < kSparseSlots) {
+        if (slot < slots) {
             uint32_t *line = reinterpret_cast<uint32_t *>(env.lines + uint64_t(b) * 8u);
-            line[slot] = tag | (wf << kSparseTagBits);
-            line[kSparseL0Word + slot] = uint32_t(lval);
-            reinterpret_cast<uint8_t *>(line)[kSparseHiByte + slot] = uint8_t(lval >> 32);
+            if (xwide) {
+                line[slot] = tag;
+                line[kSparseXL0Word + slot] = uint32_t(lval);
+                reinterpret_cast<uint8_t *>(line)[kSparseXTagHiByte + slot] = uint8_t(tag_hi);
+                reinterpret_cast<uint8_t *>(line)[kSparseXHiByte + slot] = uint8_t(lval >> 32);
+                reinterpret_cast<uint8_t *>(line)[kSparseXWidthByte + slot] = uint8_t(wf);
+            } else if (wide) {
+                line[slot] = tag;
+                line[kSparseWideL0Word + slot] = uint32_t(lval);
+                reinterpret_cast<uint8_t *>(line)[kSparseWideHiByte + slot] = uint8_t(lval >> 32);
+                reinterpret_cast<uint8_t *>(line)[kSparseWideWidthByte + slot] = uint8_t(wf);
+            } else {
+                line[slot] = tag | (wf << kSparseTagBits);
+                line[kSparseL0Word + slot] = uint32_t(lval);
+                reinterpret_cast<uint8_t *>(line)[kSparseHiByte + slot] = uint8_t(lval >> 32);
+            }
             if (dist != 0u) atomicAdd(cur + kDisplaced, 1ull);
             return;
         }
@@ -470,10 +486,7 @@ hipError_t sparse_fill(const IndexView &ix, const void *flat_entries, int flat_d
     report->nbuckets = nbuckets;
     report->nescapes = cur[kSideCursor];
     report->displaced = cur[kDisplaced];
-    uint64_t entries = 0;
-    for (uint64_t b = 0; b < 1; ++b) entries = 0;
     report->entries = report->distinct[depth];
-    (void)entries;
     return hipSuccess;
 }
 

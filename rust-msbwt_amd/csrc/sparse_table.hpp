@@ -1,4 +1,4 @@
-// Sparse suffix table: the ranges of the d-symbol suffixes that OCCUR, d up to 24 -- the reference's stubbed kmer_cache
+// Sparse suffix table: the ranges of the d-symbol suffixes that OCCUR, d up to 31 -- the reference's stubbed kmer_cache
 // (src/msbwt_core.rs:133-146, src/rle_bwt.rs:332-346) taken past what a direct-address table can hold.
 //
 // The direct table (kernels.hpp, TableView) has 4^d entries whatever the data: at d = 17 that is 73 GB of which at most
@@ -22,6 +22,30 @@
 // consecutive values no two share their low 24 bits, so a tag match IS a key match (no false positives, nothing to verify).
 // An entry whose range is 255 or more wide (a suffix of a high-copy repeat) names a flat {l, h} entry of 16 bytes in a side
 // array: one more line for that query, like the escape lines of the packed direct table.
+//
+// Depths 25..29 (round 6: a present 31-mer behind a depth-27 table needs 3 lines instead of 5 -- measured with 27-mers on the
+// depth-23 table: 1.46e10 q/s at human scale) -- a 50..56-bit key leaves 24-bit tags no room ((probe + 1) * W <= 2^24 with W =
+// 2^(n-32) * 13 fails from n = 50 on), so these depths keep the low 32 bits of the mixed key as the tag: 10 bytes per entry, 12 per
+// bucket ("wide" layout):
+//     words  0..11   tag[i]   = low 32 bits of the mixed key
+//     words 12..23   l_lo[i]
+//     bytes  96..107 l_hi[i]
+//     bytes 108..119 width[i]  (1..254; 255 = ESCAPE; 0 = empty slot)
+//     bytes 126..127 header    (as above; > 12 = entries were displaced)
+// Uniqueness: (probe + 1) * W <= 2^32.  Depth 29 (a 58-bit key: one pair step left of a 31-mer) is the last this tag width reaches:
+// W <= 2^6 / 8 means 2^29 buckets at least -- 69 GB, which a human-scale index still has room for (5.5 entries per bucket) and a
+// small one has no use for.
+//
+// Depths 30..31 ("xwide" layout: 40-bit tags, 11 entries of 11 bytes) -- at depth 31 the table's range IS the count of a 31-mer: one
+// line per query (23-mers on the depth-23 table: 3.4e10 q/s at human scale):
+//     words  0..10   tag_lo[i] = bits 0..31 of the mixed key
+//     words 11..21   l_lo[i]
+//     bytes  88..98  tag_hi[i] = bits 32..39 of the mixed key
+//     bytes  99..109 l_hi[i]
+//     bytes 110..120 width[i]
+//     bytes 126..127 header    (> 11 = entries were displaced)
+// Uniqueness: (probe + 1) * W <= 2^40 -- 2^25 buckets suffice again, and 7 entries per bucket (the same 64 %) make 18.3 bytes per
+// distinct suffix: 54.5 GB for the 2.98e9 distinct 31-mers of the error-free human-scale index.
 #pragma once
 #include <cstdint>
 
@@ -34,13 +58,25 @@
 
 namespace msbwt {
 
-constexpr uint32_t kSparseSlots = 14;        // entries per 128-byte bucket
+constexpr uint32_t kSparseSlots = 14;        // entries per 128-byte bucket (depths up to 24)
 constexpr uint32_t kSparseTagBits = 24;
+constexpr uint32_t kSparseWideSlots = 12;    // ... and of the wide layout (depths 25..29): 32-bit tags
+constexpr uint32_t kSparseWideL0Word = 12, kSparseWideHiByte = 96, kSparseWideWidthByte = 108;
+constexpr int kSparseWideFrom = 25;
+constexpr uint32_t kSparseXSlots = 11;       // ... and of the xwide layout (depths 30..31): 40-bit tags
+constexpr uint32_t kSparseXL0Word = 11, kSparseXTagHiByte = 88, kSparseXHiByte = 99, kSparseXWidthByte = 110;
+constexpr int kSparseXFrom = 30;
 constexpr uint32_t kSparseEscapeWidth = 255;  // width field of an entry whose range lives in the side array
 constexpr uint32_t kSparseMaxProbe = 15;      // a key lives at most this many buckets behind its own
-constexpr int kSparseMinDepth = 16, kSparseMaxDepth = 24;
-constexpr int kSparseAutoDepth = 23;          // the automatic choice never goes deeper (msbwt_rle_set_sparse_table takes 16..24)
+constexpr int kSparseMinDepth = 16, kSparseMaxDepth = 31;
+constexpr int kSparseAutoDepth = 23;          // the automatic choice never goes deeper (msbwt_rle_set_sparse_table takes 16..31)
 constexpr double kSparseLoad = 9.0;           // entries per bucket the builder aims for (64 % of the slots: 0.9 % of the entries displaced)
+
+MSBWT_HD bool sparse_wide(uint32_t depth) { return depth >= uint32_t(kSparseWideFrom); }   // (xwide included: the tag's low word is whole)
+MSBWT_HD bool sparse_xwide(uint32_t depth) { return depth >= uint32_t(kSparseXFrom); }
+MSBWT_HD uint32_t sparse_slots(uint32_t depth) { return sparse_xwide(depth) ? kSparseXSlots : sparse_wide(depth) ? kSparseWideSlots : kSparseSlots; }
+MSBWT_HD uint32_t sparse_tag_bits(uint32_t depth) { return sparse_xwide(depth) ? 40u : sparse_wide(depth) ? 32u : kSparseTagBits; }
+inline double sparse_load(int depth) { return kSparseLoad * double(sparse_slots(uint32_t(depth))) / double(kSparseSlots); }  // the same 64 % of the slots
 constexpr uint32_t kSparseL0Word = 14, kSparseHiByte = 112, kSparseHeaderByte = 126;
 
 struct SparseView {
@@ -51,7 +87,7 @@ struct SparseView {
     const void *side = nullptr;    // 16-byte {l, h} entries of the ESCAPE entries
 };
 
-// the bijection of n-bit words (n = 2 depth, 32 <= n <= 48)
+// the bijection of n-bit words (n = 2 depth, 32 <= n <= 62)
 MSBWT_HD uint64_t sparse_mix(uint64_t key, uint32_t n) {
     const uint64_t mask = (uint64_t(1) << n) - 1u;
     uint64_t x = key & mask;
@@ -68,15 +104,17 @@ MSBWT_HD uint32_t sparse_bucket(uint64_t mixed, uint32_t n, uint32_t nbuckets) {
     return uint32_t((uint64_t(top) * nbuckets) >> 32);
 }
 
-MSBWT_HD uint32_t sparse_tag(uint64_t mixed) { return uint32_t(mixed) & ((1u << kSparseTagBits) - 1u); }
+MSBWT_HD uint32_t sparse_tag(uint64_t mixed, uint32_t depth) { return sparse_wide(depth) ? uint32_t(mixed) : uint32_t(mixed) & ((1u << kSparseTagBits) - 1u); }
+// bits 32..39 of the tag (xwide layout; 0 otherwise)
+MSBWT_HD uint32_t sparse_tag_hi(uint64_t mixed, uint32_t depth) { return sparse_xwide(depth) ? uint32_t(mixed >> 32) & 0xFFu : 0u; }
 
-// How far a lookup may probe with `nbuckets` buckets at depth d so that tags stay unambiguous: (probe + 1) * W <= 2^24,
+// How far a lookup may probe with `nbuckets` buckets at depth d so that tags stay unambiguous: (probe + 1) * W <= 2^tagbits,
 // W = 2^(n-32) * ceil(2^32 / nbuckets).  Negative: this many buckets are too few for the depth.
 inline int sparse_probe_limit(int depth, uint64_t nbuckets) {
     if (depth < kSparseMinDepth || depth > kSparseMaxDepth || nbuckets == 0 || nbuckets > 0xFFFFFFFFull) return -1;
     const uint64_t per_top = ((uint64_t(1) << 32) + nbuckets - 1) / nbuckets;
     const uint64_t window = per_top << (2 * depth - 32);
-    const uint64_t fit = (uint64_t(1) << kSparseTagBits) / window;  // windows that fit the tag space
+    const uint64_t fit = (uint64_t(1) << sparse_tag_bits(uint32_t(depth))) / window;  // windows that fit the tag space
     if (fit < 2) return -1;
     return int(fit - 1 < kSparseMaxProbe ? fit - 1 : kSparseMaxProbe);
 }
@@ -85,15 +123,17 @@ inline int sparse_probe_limit(int depth, uint64_t nbuckets) {
 // entry is displaced beyond it (with 4 -- what 9 entries per bucket leave a chr20-sized index at depth 23 -- about one entry in
 // 10^5 found no slot and the whole table was filled a second time with more buckets: round 5's first C4 builds)
 inline uint64_t sparse_min_buckets(int depth) {
-    const int shift = 2 * depth - 32 + 3;  // W <= 2^21  <=>  ceil(2^32 / nb) <= 2^(21 - (n - 32))
-    if (shift >= int(kSparseTagBits)) return ~uint64_t(0);
-    const uint64_t per_top = uint64_t(1) << (kSparseTagBits - shift);  // allowed ceil(2^32 / nb)
+    const int bits = int(sparse_tag_bits(uint32_t(depth)));
+    const int shift = 2 * depth - 32 + 3;  // 8 W <= 2^bits  <=>  ceil(2^32 / nb) <= 2^(bits - 3 - (n - 32))
+    if (shift >= bits) return ~uint64_t(0);
+    if (bits - shift >= 32) return 1;     // (shallow depths with wide tags: any bucket count will do)
+    const uint64_t per_top = uint64_t(1) << (bits - shift);  // allowed ceil(2^32 / nb)
     return ((uint64_t(1) << 32) + per_top - 1) / per_top;
 }
 
 // buckets for `entries` entries at depth d (the load the builder aims for, within what the tags allow)
-inline uint64_t sparse_buckets_for(int depth, uint64_t entries, double load = kSparseLoad) {
-    const uint64_t want = uint64_t(double(entries) / load) + 1;
+inline uint64_t sparse_buckets_for(int depth, uint64_t entries, double load = 0.0) {
+    const uint64_t want = uint64_t(double(entries) / (load > 0.0 ? load : sparse_load(depth))) + 1;
     const uint64_t least = sparse_min_buckets(depth);
     return want > least ? want : least;
 }

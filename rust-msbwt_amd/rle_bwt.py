@@ -305,10 +305,20 @@ class RleBWT(BWT):
 
     # ---- sparse suffix table (include/msbwt_hip.h, msbwt_rle_set_sparse_table) ----
     def set_sparse_table(self, depth):
-        """-1 = automatic (default), 0 = off, 16..24 = exactly that depth."""
+        """-1 = automatic (default), 0 = off, 16..31 = exactly that depth (29: at least 2^29 buckets, 69 GB)."""
         rc = _lib.lib().msbwt_rle_set_sparse_table(self._h, int(depth))
         if rc:
             _raise(rc, self._h)
+
+    def set_query_length(self, k):
+        """The k this index will mostly be asked about (0 = unknown): the AUTOMATIC sparse table goes as deep as min(k, 27) instead of 23
+        -- a table of d-mers serves k >= d only.  Results never depend on it."""
+        rc = _lib.lib().msbwt_rle_set_query_length(self._h, int(k))
+        if rc:
+            _raise(rc, self._h)
+
+    def get_query_length(self):
+        return int(_lib.lib().msbwt_rle_get_query_length(self._h))
 
     def get_sparse_table(self):
         """Depth of the sparse suffix table in HBM, 0 = none."""
@@ -316,14 +326,14 @@ class RleBWT(BWT):
 
     def sparse_table_info(self):
         """What msbwt_rle_sparse_table_info reports, by name; "distinct" / "wide": {depth: count} for the depths the build passed."""
-        out = (C.c_uint64 * 64)()
+        out = (C.c_uint64 * 80)()
         rc = _lib.lib().msbwt_rle_sparse_table_info(self._h, out)
         if rc:
             _raise(rc, self._h)
         info = {"depth": int(out[0]), "entries": int(out[1]), "buckets": int(out[2]), "bytes": int(out[3]), "side_entries": int(out[4]),
                 "side_bytes": int(out[5]), "displaced": int(out[6]), "parent_depth": int(out[7]), "probe": int(out[9])}
-        info["distinct"] = {d: int(out[10 + d]) for d in range(25) if out[10 + d]}
-        info["wide"] = {d: int(out[35 + d]) for d in range(25) if out[10 + d]}
+        info["distinct"] = {d: int(out[10 + d]) for d in range(32) if out[10 + d]}
+        info["wide"] = {d: int(out[45 + d]) for d in range(32) if out[10 + d]}
         return info
 
     def download_sparse_table(self):

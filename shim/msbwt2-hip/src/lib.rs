@@ -63,9 +63,13 @@ extern "C" {
                                     out_counts: *mut c_void, count_bits: c_int) -> c_int;
     // HBM the index may hold (0 = no budget): the space / time knob, as bin_power is the reference's
     fn msbwt_rle_set_memory_budget(bwt: *mut MsbwtRle, bytes: u64) -> c_int;
-    // sparse suffix table (round 5): ranges of the suffixes that occur, depth 16..24 (-1 = automatic, 0 = off); info = 64 u64 words
+    // sparse suffix table (round 5): ranges of the suffixes that occur, depth 16..31 (-1 = automatic, 0 = off); info = 80 u64 words
     fn msbwt_rle_set_sparse_table(bwt: *mut MsbwtRle, depth: c_int) -> c_int;
     fn msbwt_rle_get_sparse_table(bwt: *const MsbwtRle) -> c_int;
+    // the k the index will mostly be asked about (0 = unknown): the automatic sparse table then reaches min(k, 27) instead of 23
+    fn msbwt_rle_set_query_length(bwt: *mut MsbwtRle, k: c_int) -> c_int;
+    fn msbwt_rle_get_query_length(bwt: *const MsbwtRle) -> c_int;
+    fn msbwt_auto_sparse_max_depth(query_length: c_int) -> c_int;
     fn msbwt_rle_sparse_table_info(bwt: *const MsbwtRle, out: *mut u64) -> c_int;
     // one batch counted and gathered as a pipeline (pieces searched while earlier pieces' counts travel over RCCL)
     fn msbwt_rle_count_kmers_allgather_device(bwt: *const MsbwtRle, comm: *mut c_void, d_kmers: *const c_void, k: usize, n_mine: usize,
@@ -176,15 +180,23 @@ impl GpuRleBWT {
         if rc != MSBWT_OK { panic!("set_memory_budget: {}", self.last_error()); }
     }
 
-    /// Sparse suffix table: -1 = automatic (default), 0 = off, 16..=24 = exactly that depth.  Results never change.
+    /// Sparse suffix table: -1 = automatic (default), 0 = off, 16..=31 = exactly that depth.  Results never change.
     pub fn set_sparse_table(&mut self, depth: i32) {
         let rc = unsafe { msbwt_rle_set_sparse_table(self.raw, depth) };
         if rc != MSBWT_OK { panic!("set_sparse_table: {}", self.last_error()); }
     }
 
+    /// The k this index will mostly be asked about (0 = unknown): the automatic sparse table follows it (a table of d-mers serves k >= d).
+    pub fn set_query_length(&mut self, k: i32) {
+        let rc = unsafe { msbwt_rle_set_query_length(self.raw, k) };
+        if rc != MSBWT_OK { panic!("set_query_length: {}", self.last_error()); }
+    }
+
+    pub fn query_length(&self) -> i32 { unsafe { msbwt_rle_get_query_length(self.raw) } }
+
     /// Depth of the sparse suffix table in HBM (0 = none) and how many distinct suffixes of that length occur.
     pub fn sparse_table(&self) -> (i32, u64) {
-        let mut info = [0u64; 64];
+        let mut info = [0u64; 80];
         let rc = unsafe { msbwt_rle_sparse_table_info(self.raw, info.as_mut_ptr()) };
         if rc != MSBWT_OK { panic!("sparse_table_info: {}", self.last_error()); }
         (unsafe { msbwt_rle_get_sparse_table(self.raw) }, info[1])

@@ -36,6 +36,12 @@ def bwt_of(reads):
     return orc.convert_to_vec(orc.naive_bwt(text))
 
 
+def synth_bwt(reads):
+    """the same by the suffix-sorting builder (read sets too large for the naive one)"""
+    import synth
+    return synth.rle_encode(synth.build_msbwt_symbols(reads))
+
+
 def load_pair(rle, monkeypatch, depth, **env):
     monkeypatch.setenv("MSBWT_SEARCH", "lanes")
     monkeypatch.setenv("MSBWT_SPARSE_TABLE", str(depth))
@@ -70,27 +76,45 @@ def table_key(kmers):
 
 def host_lookup(lines, side, info, key):
     """What the kernel does with one key, on the downloaded table: -> (l, h) or None."""
-    b, tag = C.c_uint32(), C.c_uint32()
-    assert _lib.lib().msbwt_sparse_hash(int(key), info["depth"], info["buckets"], C.byref(b), C.byref(tag)) == 0
+    b, tag = C.c_uint32(), C.c_uint64()
+    assert _lib.lib().msbwt_sparse_hash64(int(key), info["depth"], info["buckets"], C.byref(b), C.byref(tag)) == 0
     bucket = b.value
+    wide = info["depth"] >= 25           # sparse_table.hpp: 12 entries with 32-bit tags and a width byte of their own
+    xwide = info["depth"] >= 30          # ... 11 entries with 40-bit tags
+    nslots = 11 if xwide else 12 if wide else 14
     for dist in range(info["probe"] + 1):
         line = lines[bucket + dist]
         raw = line.view(np.uint8)
-        for slot in range(14):
+        for slot in range(nslots):
             t = int(line[slot])
-            if (t >> 24) != 0 and (t & 0xFFFFFF) == tag.value:
+            if xwide:
+                width, hit = int(raw[110 + slot]), (t | (int(raw[88 + slot]) << 32)) == tag.value
+                lo = int(line[11 + slot]) | (int(raw[99 + slot]) << 32)
+            elif wide:
+                width, hit = int(raw[108 + slot]), t == tag.value
+                lo = int(line[12 + slot]) | (int(raw[96 + slot]) << 32)
+            else:
+                width, hit = t >> 24, (t & 0xFFFFFF) == tag.value
                 lo = int(line[14 + slot]) | (int(raw[112 + slot]) << 32)
-                width = t >> 24
+            if width != 0 and hit:
                 if width == 255:
                     return int(side[lo][0]), int(side[lo][1])
                 return lo, lo + width
         header = int(raw[126]) | (int(raw[127]) << 8)
-        if header <= 14:
+        if header <= nslots:
             return None
     return None
 
 
-@pytest.mark.parametrize("depth", [16, 17, 20])
+def slots_in_use(lines, info):
+    if info["depth"] >= 30:
+        return int((lines.view(np.uint8).reshape(len(lines), 128)[:, 110:121] != 0).sum())
+    if info["depth"] >= 25:
+        return int((lines.view(np.uint8).reshape(len(lines), 128)[:, 108:120] != 0).sum())
+    return int(((lines[:, :14] >> 24) != 0).sum())
+
+
+@pytest.mark.parametrize("depth", [16, 17, 20, 25, 27, 28, 30, 31])
 def test_every_entry_of_the_table_is_the_oracles_range(depth, monkeypatch):
     reads = read_set(11, 3000, 700, 60, repeats=4, err=0.01)
     b, ref = load_pair(bwt_of(reads), monkeypatch, depth)
@@ -110,16 +134,45 @@ def test_every_entry_of_the_table_is_the_oracles_range(depth, monkeypatch):
     for key, el, eh in zip(table_key(absent), al, ah):
         got = host_lookup(lines, side, info, key)
         assert got == ((int(el), int(eh)) if eh > el else None)
-    assert int(((lines[:, :14] >> 24) != 0).sum()) == info["entries"]
+    assert slots_in_use(lines, info) == info["entries"]
     # distinct counts of the shallower levels the build passed through
     for d, n in info["distinct"].items():
         if 4 <= d <= depth:
             assert n == len(np.unique(np.lib.stride_tricks.sliding_window_view(reads, d, axis=1).reshape(-1, d), axis=0)), d
 
 
+def test_the_automatic_depth_follows_the_declared_query_length(monkeypatch):
+    """msbwt_rle_set_query_length: a table of d-mers serves k >= d only, so the AUTOMATIC depth stops at 23 while k is unknown and reaches
+    min(k, 27) for a declared k; an explicit depth does not follow the hint; counts never change."""
+    reads = read_set(77, 2_000_000, 500_000, 100, repeats=30, err=0.002)
+    rle = synth_bwt(reads)
+    b, ref = load_pair(rle, monkeypatch, "auto")
+    d0 = b.get_sparse_table()
+    assert b.get_query_length() == 0 and 16 <= d0 <= 23
+    windows = {k: np.ascontiguousarray(np.lib.stride_tricks.sliding_window_view(reads[:300], k, axis=1).reshape(-1, k)) for k in (21, 25, 31, 59)}
+    exp = {k: ref.count_kmers(q) for k, q in windows.items()}
+    seen = {}
+    for hint in (31, 21, 25, 59, 0):
+        b.set_query_length(hint)
+        assert b.get_query_length() == hint
+        seen[hint] = b.get_sparse_table()
+        for k, q in windows.items():
+            assert np.array_equal(b.count_kmers(q), exp[k]), (hint, k)
+    assert seen[0] == d0 and seen[31] == seen[59] and d0 <= seen[31] <= 31 and seen[21] <= 21 and seen[25] <= 25
+    assert seen[31] >= 25, seen           # 5e7 symbols, 2e6 distinct 27-mers: deep enough for the wide layout to pay
+    b.set_sparse_table(19)
+    b.set_query_length(31)
+    assert b.get_sparse_table() == 19
+    assert np.array_equal(b.count_kmers(windows[31]), exp[31])
+
+
 @pytest.mark.parametrize("stride", [96, 128])
-@pytest.mark.parametrize("depth", [16, 19, 23, 24])
+@pytest.mark.parametrize("depth", [16, 19, 23, 24, 25, 26, 27, 28, 29, 30, 31])
 def test_counts_with_the_sparse_table_equal_the_oracle(depth, stride, monkeypatch):
+    if depth == 29:   # the last depth 32-bit tags reach needs 2^29 buckets whatever the index: 69 GB (+ 2 GB of slot counters while it is built)
+        import torch
+        if torch.cuda.mem_get_info(0)[0] < 90 * 10**9:
+            pytest.skip("needs 90 GB of free HBM")
     reads = read_set(21 + depth, 5000, 900, 80, repeats=6, err=0.005)
     b, ref = load_pair(bwt_of(reads), monkeypatch, depth, MSBWT_PAIR_STRIDE=stride)
     assert b.get_sparse_table() == depth and b.get_pair_stride() == stride

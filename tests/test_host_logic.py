@@ -431,23 +431,26 @@ def test_sparse_table_hash_and_shape_are_pure_functions():
     shape the builder picks leaves every lookup a probe limit of 7 buckets or more with tags unambiguous."""
     L = _lib.lib()
     rng = np.random.default_rng(1)
-    for depth in (16, 19, 23, 24):
+    for depth in (16, 19, 23, 24, 25, 27, 28, 29, 30, 31):
         n = 2 * depth
+        tag_bits = 24 if depth <= 24 else 32 if depth <= 29 else 40   # the wide layout (12 entries, 32-bit tags) and the xwide one (11 entries, 40-bit tags)
+        slots = 14 if depth <= 24 else 12 if depth <= 29 else 11
         for entries in (0, 1000, 3 * 10 ** 7, 3 * 10 ** 9):
             nb, probe = C.c_uint64(), C.c_int()
             assert L.msbwt_sparse_table_shape(depth, entries, C.byref(nb), C.byref(probe)) == 0
-            assert nb.value >= entries / 9.0 and 7 <= probe.value <= 15 and nb.value + probe.value < 2 ** 32
+            assert nb.value >= entries / (9.0 * slots / 14) - 1 and 7 <= probe.value <= 15 and nb.value + probe.value < 2 ** 32
             window = (-(-2 ** 32 // nb.value)) << (n - 32)        # widest range of mixed keys one bucket takes
-            assert (probe.value + 1) * window <= 2 ** 24            # ... so that the 24-bit tags of one probe sequence never collide
+            assert (probe.value + 1) * window <= 2 ** tag_bits      # ... so that the tags of one probe sequence never collide
         # the mix loses nothing: with (nearly) 2^32 buckets the bucket is the mixed key's top 32 bits and the tag its low 24 -- together
         # every bit of a key of at most 48 bits -- so distinct keys must give distinct pairs
         keys = np.unique(rng.integers(0, 2 ** n, size=5000, dtype=np.uint64))
-        b, t = C.c_uint32(), C.c_uint32()
+        b, t, t64 = C.c_uint32(), C.c_uint32(), C.c_uint64()
         mixes = set()
         for key in keys.tolist():
             assert L.msbwt_sparse_hash(key, depth, 2 ** 32 - 1, C.byref(b), C.byref(t)) == 0
-            assert t.value < 2 ** 24
-            mixes.add((b.value, t.value))
+            assert L.msbwt_sparse_hash64(key, depth, 2 ** 32 - 1, C.byref(b), C.byref(t64)) == 0
+            assert t64.value < 2 ** tag_bits and (t64.value & 0xFFFFFFFF) == t.value
+            mixes.add((b.value, t64.value))
         assert len(mixes) >= len(keys) - 1   # (the scaling by 2^32 - 1 folds the two lowest top values together)
         # and it spreads structured keys: consecutive keys (one symbol apart in the first position searched) over 1000 buckets
         hits = np.zeros(1000, dtype=np.int64)
@@ -457,7 +460,7 @@ def test_sparse_table_hash_and_shape_are_pure_functions():
         assert hits.max() <= 60 and hits.min() >= 2, (hits.min(), hits.max())
     assert L.msbwt_sparse_hash(0, 15, 10, C.byref(b), C.byref(t)) == _lib.ERR_INVALID_ARG
     nb, probe = C.c_uint64(), C.c_int()
-    assert L.msbwt_sparse_table_shape(25, 10, C.byref(nb), C.byref(probe)) == _lib.ERR_INVALID_ARG
+    assert L.msbwt_sparse_table_shape(32, 10, C.byref(nb), C.byref(probe)) == _lib.ERR_INVALID_ARG
 
 
 def test_run_block_device_build_decision():
@@ -477,14 +480,14 @@ def test_automatic_sparse_depth_follows_the_distinct_counts():
     """csrc/sparse_policy.hpp through msbwt_auto_sparse_depth (no device): the depth of the sparse suffix table is the deepest one the
     sizing pass reached whose table fits -- with the distinct counts the device builder measured on this repo's indexes (DESIGN.md 2,
     profiles/r05_lab/sparse_table.log), and with what a 30x human read set WITH errors would count (about 1.3e10 distinct 23-mers)."""
-    def choose(distinct, avail, parent=13, wide=None):
-        d, w = (C.c_uint64 * 25)(), (C.c_uint64 * 25)()
+    def choose(distinct, avail, parent=13, wide=None, query_length=0):
+        d, w = (C.c_uint64 * 32)(), (C.c_uint64 * 32)()
         for k, v in distinct.items():
             d[k] = v
         for k, v in (wide or {}).items():
             w[k] = v
         depth, nbytes = C.c_int(), C.c_uint64()
-        assert _lib.lib().msbwt_auto_sparse_depth(d, w, parent, avail, C.byref(depth), C.byref(nbytes)) == 0
+        assert _lib.lib().msbwt_auto_sparse_depth(d, w, parent, avail, query_length, C.byref(depth), C.byref(nbytes)) == 0
         return depth.value, nbytes.value
 
     GB = 10 ** 9
@@ -511,3 +514,22 @@ def test_automatic_sparse_depth_follows_the_distinct_counts():
     noisy = {k: int(v) for k, v in noisy.items()}
     assert choose(noisy, 100 * GB)[0] == 0 and choose(noisy, 200 * GB)[0] == 23
     assert choose({}, 200 * GB)[0] == 0
+    # a declared k moves the limit of the automatic depth (msbwt_rle_set_query_length): 31-mers get depth 27 -- 12 entries of 10 bytes per
+    # bucket at the same 64 % load: 16.6 bytes per distinct 27-mer --, 21-mers depth 21, and k unknown stays at 23
+    rule = _lib.lib().msbwt_auto_sparse_max_depth
+    assert [rule(k) for k in (0, 12, 16, 21, 23, 25, 27, 28, 29, 31, 59)] == [23, 16, 16, 21, 23, 25, 27, 28, 29, 31, 31]
+    human27 = dict(human)
+    human27.update({25: 2980128505, 27: 2980132285, 29: 2980132543, 31: 2980132600})
+    depth, nbytes = choose(human27, 80 * GB, query_length=31)
+    assert depth == 31 and 53.5 * GB < nbytes < 54.5 * GB          # 40-bit tags: 11 entries of 11 bytes, 7 per bucket on average (18.1 bytes per distinct 31-mer)
+    depth, nbytes = choose(human27, 80 * GB, query_length=29)
+    assert depth == 29 and 68 * GB < nbytes < 69 * GB              # 32-bit tags at their limit: 2^29 buckets at least, 5.5 entries in each
+    depth, nbytes = choose(human27, 52 * GB, query_length=31)
+    assert depth == 27 and 49 * GB < nbytes < 50 * GB
+    assert choose(human27, 80 * GB)[0] == 23 and choose(human27, 80 * GB, query_length=25)[0] == 25 and choose(human27, 80 * GB, query_length=27)[0] == 27
+    assert choose(human27, 45 * GB, query_length=31)[0] == 23      # neither 29 nor 27 fits: the deepest that does
+    c4_deep = dict(c4)
+    c4_deep.update({25: 251000000, 27: 262000000, 29: 272000000})  # (reads with errors: every two symbols add singletons)
+    depth, nbytes = choose(c4_deep, 200 * GB, query_length=29)
+    assert depth == 27 and nbytes < 4.4 * GB                       # 69 GB for 2.7e8 entries is not worth two symbols
+    assert choose(c2, 200 * GB, query_length=21)[0] == 21

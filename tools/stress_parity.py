@@ -61,7 +61,7 @@ def main():
             b.set_search_kernel(str(rng.choice(["auto", "groups", "lanes", "lanes"])))
             b.set_table_side(int(rng.integers(0, 2)))              # round 4: escape lines from the side array, or restarted
             b.set_batch_order(int(rng.choice([-1, 0, 1, 1])))      # ... the library's own ordering pass forced on half the time
-            b.set_sparse_table(int(rng.choice([-1, -1, 0, 16, 17, 18, 19, 20, 23])))   # round 5: sparse suffix table: automatic, off, or a depth
+            b.set_sparse_table(int(rng.choice([-1, -1, 0, 16, 17, 18, 19, 20, 23, 25, 27, 28, 30, 31])))   # round 5: sparse suffix table: automatic, off, or a depth
             b.set_line_streaming(int(rng.choice([-1, 0, 1, 1])))   # ... kernel revision 3: the non-temporal line loads forced on half the time
             if rng.random() < 0.15:                                # ... and a memory budget now and then (rebuilds the optional structures)
                 b.set_memory_budget(int(b.device_bytes() * float(rng.choice([0.2, 0.5, 0.9]))) + 1)
