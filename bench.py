@@ -164,6 +164,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-c4-random", action="store_true", help="default workload: only the repeat-bearing C4 line (c4_repeats), not the random-genome one (c4_real_reads)")
     ap.add_argument("--c4-scale", type=float, default=0.0, help="tests: run the extra C4 line on a shrunk C4 (0 = full size, only with --scale 1)")
     ap.add_argument("--c4-queries", type=int, default=100_000_000)
+    ap.add_argument("--c4-lab", action="store_true", help="the C4 lines' lab extras: `library_ordered` (the library's batch-ordering pass forced on) and "
+                                                          "`copy_number_bins` (cost by copy number, repeat-bearing line) -- round 4/5 material, off by default")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="default workload, N = 1, full scale: do NOT re-measure the kernel's HBM traffic in this run (two rocprofv3 --pmc child "
                          "passes of a shortened copy of the run, after the GPU has been handed back); roofline.traffic then comes from the committed "
@@ -178,6 +180,11 @@ def parse_args(argv=None):
                     help="one extra, untimed pass with the library's search counters on (msbwt_rle_set_search_counters): steps, second lines, "
                          "escape lines per query -> `search_counters` in the JSON line")
     ap.add_argument("--no-table-side", action="store_true", help="packed table without its side array: queries of escape lines search from scratch (round 3)")
+    ap.add_argument("--extras-file", default=os.path.join(ROOT, "bench_extras.json"),
+                    help="where the FULL record goes (notes, telemetry, counters, sub-lines); stdout carries one compact line (< 8 KB)")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="default workload: skip the extra lines on the same index rebuilt with k undeclared (`undeclared_k`), without the sparse "
+                         "table (`headline_sparse_off`) and their short-k timings (`short_k`)")
     ap.add_argument("--parity-sample", type=int, default=2_000_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     return ap.parse_args(argv)
@@ -271,7 +278,13 @@ def device_random_kmers(torch, dev, lo, hi, k, seed, chunk=50_000_000):
     return d_q
 
 
-def lookup_traffic(workload, k, bwt, kind, total, fused, full_size):
+def index_shape(bwt, k, fused, n):
+    """what decides the kernel and the bytes of a launch on this index, read NOW (later table rebuilds do not change a record made of it)"""
+    return {"lookup_depth": lookup_depth(bwt, k), "kernel": kernel_label(bwt, k, fused), "pair_index": bwt.get_pair_index(), "pair_stride": bwt.get_pair_stride(),
+            "ordered": (not fused) and bwt.batch_order_for(k, n), "sparse_depth": bwt.get_sparse_table()}
+
+
+def lookup_traffic(workload, k, shape, kind, total, fused, full_size):
     """HBM traffic per query of one launch of this configuration: PMC counters from separate rocprofv3 passes
     (FETCH_SIZE x2 on gfx950, WRITE_SIZE), committed under profiles/ and keyed by configuration AND kernel sources.
     Returns (bytes per query | None, source, note, stamp)."""
@@ -279,8 +292,8 @@ def lookup_traffic(workload, k, bwt, kind, total, fused, full_size):
     stamp = kernel_stamp()
     try:
         for ent in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["entries"]:
-            same = (ent["workload"] == workload and ent["k"] == k and ent["table_depth"] == lookup_depth(bwt, k)
-                    and ent.get("pair_index", False) == bwt.get_pair_index() and ent.get("pair_stride", bwt.get_pair_stride()) == bwt.get_pair_stride()
+            same = (ent["workload"] == workload and ent["k"] == k and ent["table_depth"] == shape["lookup_depth"]
+                    and ent.get("pair_index", False) == shape["pair_index"] and ent.get("pair_stride", shape["pair_stride"]) == shape["pair_stride"]
                     and ent.get("query_kind") == kind and ent.get("bwt_symbols", total) == total and full_size
                     and bool(ent.get("fused", False)) == bool(fused))
             if same and ent.get("kernel_stamp") != stamp:
@@ -393,6 +406,91 @@ def roofline_block(orc, ref, queries, k, ncpu, per_launch_q, kern_s, kernel_ms, 
                                                               "too, so such a line can come close to 1"},
     }
 
+COMPACT_LIMIT = 8192  # bytes of the stdout line (the driver's parser lost round 5's 25 KB line)
+
+
+def compact_record(full, extras_path):
+    """The ONE stdout line: the contract's keys, the roofline and CPU-baseline objects cut to their figures, parity, and scalar
+    figures of the extra lines.  Everything else -- notes, telemetry, counters, sub-lines -- is in the extras file (and on stderr)."""
+    def pick(d, keys):
+        return {kk: d[kk] for kk in keys if isinstance(d, dict) and kk in d}
+
+    def short(text, n):
+        text = str(text)
+        return text if len(text) <= n else text[:n - 3] + "..."
+
+    out = pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    cfg = full.get("config", {})
+    out["config"] = pick(cfg, ("k", "queries_per_step", "queries_per_gpu", "bwt_symbols", "index_bytes", "table_depth", "direct_table_depth", "sparse_table_depth",
+                               "sparse_table_tiers", "query_length_hint", "pair_index", "pair_stride", "block_format"))
+    out["config"]["workload"] = short(str(cfg.get("workload", "")).split(".  ")[0], 420)
+    if "parallelism" in cfg:
+        out["config"]["parallelism"] = short(cfg["parallelism"], 200)
+    roof = full.get("roofline")
+    if isinstance(roof, dict):
+        r = pick(roof, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "kernel_launches", "kernel_stamp"))
+        if roof.get("traffic_source") is not None:
+            r["traffic_source"] = short(roof["traffic_source"], 160)
+        lay, refalg, lines = roof.get("layout_algorithmic") or {}, roof.get("reference_algorithm") or {}, roof.get("random_lines") or {}
+        r.update({"layout_bytes_per_query": lay.get("bytes_per_query"), "layout_lines_per_query": lay.get("lines_per_query"),
+                  "frac_layout_algorithmic": lay.get("frac_algorithmic"), "traffic_over_layout": lay.get("traffic_over_algorithmic"),
+                  "reference_bytes_per_query": refalg.get("bytes_per_query"), "random_lines_frac": lines.get("frac")})
+        out["roofline"] = r
+    cpu = full.get("cpu_baseline")
+    if isinstance(cpu, dict):
+        c = pick(cpu, ("value", "unit", "cores", "kind", "nproc", "cpu_model"))
+        c["sample"] = short(cpu.get("sample", ""), 200)
+        c["all_cores_value"] = (cpu.get("all_cores") or {}).get("value")
+        out["cpu_baseline"] = c
+    if isinstance(full.get("parity"), dict):
+        out["parity"] = pick(full["parity"], ("checked", "mismatches"))
+    extras = {}
+    for key in ("c5_random_1e9", "c4_repeats", "c4_real_reads", "c4_budgeted", "undeclared_k", "headline_sparse_off", "sorted_batch", "weak_scaling", "native_gather"):
+        line = full.get(key)
+        if not isinstance(line, dict):
+            continue
+        if "error" in line and "value" not in line:
+            extras[key + "_error"] = short(line["error"], 120)
+            continue
+        extras[key + "_qps"] = line.get("value")
+        if isinstance(line.get("roofline"), dict) and "frac" in line["roofline"]:
+            extras[key + "_frac"] = line["roofline"]["frac"]
+        if isinstance(line.get("parity"), dict):
+            extras[key + "_mismatches"] = line["parity"].get("mismatches")
+        for flag in ("counts_equal_headline", "counts_equal_unordered_run", "equals_torch_path"):
+            if flag in line:
+                extras[key + "_" + flag] = line[flag]
+        for num in ("sparse_table_depth", "direct_table_depth", "lines_per_query"):
+            if num in line:
+                extras[key + "_" + num] = line[num]
+    if isinstance(full.get("c4_budgeted"), dict):
+        for mode, rec in (full["c4_budgeted"].get("modes") or {}).items():
+            if isinstance(rec, dict):
+                extras["c4_budgeted_%s_qps" % mode] = rec.get("value")
+                extras["c4_budgeted_%s_lines_per_query" % mode] = rec.get("lines_per_query")
+    if isinstance(full.get("short_k"), dict):
+        extras["short_k_worst_ratio_to_sparse_off"] = full["short_k"].get("worst_ratio_to_sparse_off")
+    if isinstance(full.get("host_api"), dict):
+        for kk in ("bytes_qps", "packed_u64_qps", "packed_u32_qps", "pcie_both_ways_GBps"):
+            if kk in full["host_api"]:
+                extras["host_api_" + kk] = full["host_api"][kk]
+    if isinstance(full.get("ranks"), dict):
+        extras.update({"ranks_kernel_ms_min": full["ranks"].get("kernel_ms_min"), "ranks_kernel_ms_max": full["ranks"].get("kernel_ms_max"),
+                       "ranks_exchange_ms_alone": full["ranks"].get("exchange_ms_alone")})
+    if isinstance(full.get("native_gather"), dict):
+        for kk in ("single_batch_latency_ms", "single_batch_pipelined_ms", "single_batch_pipelined_narrow_destination_ms"):
+            if kk in full["native_gather"]:
+                extras["native_gather_" + kk] = full["native_gather"][kk]
+    if full.get("consistency_errors"):
+        extras["consistency_errors"] = len(full["consistency_errors"])
+    out["extras"] = extras
+    out["extras_file"] = os.path.basename(extras_path) if extras_path else None
+    line = json.dumps(out)
+    if len(line) >= COMPACT_LIMIT:  # (cannot happen with the fields above; the contract's keys always survive)
+        out["extras"] = {kk: vv for kk, vv in extras.items() if kk.endswith("_qps")}
+        out["config"]["workload"] = short(out["config"]["workload"], 160)
+    return out
+
 
 def main():
     args = parse_args()
@@ -405,7 +503,17 @@ def main():
     os.dup2(2, 1)
 
     def emit(obj):
-        os.write(result_fd, (json.dumps(obj) + "\n").encode())
+        """the full record to the extras file and stderr; ONE compact line (compact_record, < 8 KB) to stdout"""
+        blob = json.dumps(obj)
+        try:
+            with open(args.extras_file, "w") as f:
+                f.write(blob + "\n")
+        except OSError as e:
+            log("could not write %s: %r" % (args.extras_file, e))
+        log("full record: " + blob)
+        line = json.dumps(compact_record(obj, args.extras_file))
+        assert len(line) < COMPACT_LIMIT, "compact line of %d bytes" % len(line)
+        os.write(result_fd, (line + "\n").encode())
 
     import gc
 
@@ -816,6 +924,8 @@ def main():
         counters = counted_pass(bwt, main_batch, lo, hi, cap)
     job_queries = nq if (strong or not multi) else nq * world
     value = job_queries * args.steps / elapsed
+    # what the index looked like when the headline ran (the variant lines further down rebuild its tables)
+    headline_shape = index_shape(bwt, k, fused, mine_n if strong else nq)
     d_counts = stitch(d_all, d_out, nq, cap)
     # the repeat-genome lab line: what a k-mer costs by copy number AT THIS SIZE (human copy numbers: 10^5 and more occurrences)
     main_bins = None
@@ -1045,6 +1155,11 @@ def main():
         else:
             queries = d_q[torch.from_numpy(sample_ids).to(dev)].cpu().numpy()
         got = d_counts[torch.from_numpy(sample_ids).to(dev)].cpu().numpy().astype(np.uint64)
+    # the variant lines (same index, tables rebuilt) need the batch and its counts again after the 1e9-query line: parked on the host meanwhile
+    want_variants = human and not multi and not args.no_variants and not fused and d_q is not None and rank == 0 and not args.sort_queries
+    h_q = h_counts = None
+    if want_variants:
+        h_q, h_counts = d_q.cpu(), d_counts.cpu()
     del d_counts, d_out, d_all, d_q, main_batch
     torch.cuda.empty_cache()
 
@@ -1071,6 +1186,87 @@ def main():
         del d_q5, o5, all5, b5
         torch.cuda.empty_cache()
         log("c5 line: %d random %d-mers in %.1f ms per pass (%.1fs incl. generation)" % (n5, k, dt5 * 1e3, time.time() - t0))
+
+    # ---- the same index with its tables rebuilt: what the headline owes to the declared k and to the sparse table --------------------
+    #   undeclared_k         msbwt_rle_set_query_length(0): the automatic sparse table stops at depth 23 (serves every k >= 23);
+    #   headline_sparse_off  msbwt_rle_set_sparse_table(0): no sparse table, the deep direct table of round 4 -- what a read set whose error
+    #                        k-mers outgrow HBM gets when not even the two-tier table fits;
+    #   short_k              present k-mers of k = 17, 19, 21 (shorter than the sparse table's entries: the direct table serves them, and it is
+    #                        shallower beside a sparse table) on both, the last k symbols of the headline's own queries.
+    short_k_samples = {}
+    if want_variants:
+        t0 = time.time()
+        d_q, d_counts = h_q.to(dev), h_counts.to(dev)
+        del h_q, h_counts
+
+        def variant_line():
+            vb = Batch(bwt, d_q, 0)
+            saved = args.steps
+            args.steps = min(args.steps, 10)
+            try:
+                o, _, el, kms, _, _ = measure(vb, 0, nq, nq)
+                cp = counted_pass(bwt, vb, 0, nq, nq)
+                line = {"value": nq * args.steps / el, "unit": "queries/s", "ms_per_step": el / args.steps * 1e3, "kernel_ms": kms, "steps": args.steps,
+                        "counts_equal_headline": bool(torch.equal(o, d_counts)), "sparse_table_depth": bwt.get_sparse_table(),
+                        "direct_table_depth": bwt.get_table_depth(), "index_bytes": bwt.device_bytes(), "kernel": kernel_label(bwt, k, False),
+                        "lines_per_query": cp["lines_per_query"], "second_line_rate": cp["second_line_rate"]}
+            finally:
+                args.steps = saved
+            del o
+            return line
+
+        def short_k_lines(which, into):
+            ns = min(nq, 100_000_000)
+            saved = args.steps
+            args.steps = min(args.steps, 5)
+            try:
+                for kk in (17, 19, 21):
+                    if kk >= k:
+                        continue
+                    d_s = d_q[:ns, k - kk:].contiguous()
+                    o, _, el, kms, _, _ = measure(Batch(bwt, d_s, 0, None, kk), 0, ns, ns)
+                    rec = into.setdefault("k%d" % kk, {"queries": ns})
+                    rec[which + "_qps"] = ns * args.steps / el
+                    rec[which + "_kernel_ms"] = kms
+                    rec[which + "_kernel"] = kernel_label(bwt, kk, False)
+                    if kk not in short_k_samples:  # the oracle checks a sample of the first variant's counts; the second must equal the first everywhere
+                        ids = torch.from_numpy(np.sort(np.random.default_rng(kk).choice(ns, size=min(ns, 100_000), replace=False))).to(dev)
+                        short_k_samples[kk] = (d_s[ids].cpu().numpy(), o[ids].cpu().numpy().astype(np.uint64), o)
+                    else:
+                        rec["counts_equal"] = bool(torch.equal(o, short_k_samples[kk][2]))
+                        short_k_samples[kk] = short_k_samples[kk][:2]
+                    del d_s
+            finally:
+                args.steps = saved
+
+        short_k = {}
+        try:
+            if bwt.get_query_length() != 0:
+                bwt.set_query_length(0)
+            result["undeclared_k"] = dict(variant_line(), note="the same index after msbwt_rle_set_query_length(0): the automatic sparse table stops at depth 23")
+            short_k_lines("default", short_k)
+            bwt.set_sparse_table(0)
+            result["headline_sparse_off"] = dict(variant_line(), note="the same index after msbwt_rle_set_sparse_table(0): no sparse table, the deep direct table")
+            short_k_lines("sparse_off", short_k)
+            ratios = [rec["default_qps"] / rec["sparse_off_qps"] for rec in short_k.values() if "default_qps" in rec and "sparse_off_qps" in rec]
+            short_k["worst_ratio_to_sparse_off"] = min(ratios) if ratios else None
+            short_k["note"] = ("present k-mers shorter than the sparse table's entries (the last k symbols of the headline's queries, 1e8 of them): the default index "
+                               "(sparse table + shallow direct table) against the same index without the sparse table (deep direct table)")
+            result["short_k"] = short_k
+            for key in ("undeclared_k", "headline_sparse_off"):
+                if not result[key]["counts_equal_headline"]:
+                    log("PARITY FAILURE: %s counts differ from the headline's" % key)
+                    result["value"] = None
+            if any(rec.get("counts_equal") is False for rec in short_k.values() if isinstance(rec, dict)):
+                log("PARITY FAILURE: short-k counts differ between the two indexes")
+                result["value"] = None
+        except msbwt.MsbwtError as e:  # (a variant that cannot be built -- no room for the deep direct table -- is recorded, not fatal)
+            result.setdefault("undeclared_k", {"error": repr(e)})
+            result.setdefault("headline_sparse_off", {"error": repr(e)})
+        short_k_samples = {kk: vv[:2] for kk, vv in short_k_samples.items()}
+        del d_q, d_counts
+        torch.cuda.empty_cache()
+        log("variant lines (undeclared k, sparse table off, short k) in %.1fs" % (time.time() - t0))
 
     rc = 0
     ncpu = host_threads
@@ -1103,16 +1299,24 @@ def main():
             mism += m5
             del c5["_q"], c5["_got"]
             result["c5_random_1e9"] = c5
+        if short_k_samples and "short_k" in result:
+            checked = bad = 0
+            for kk, (qs_k, got_k) in short_k_samples.items():
+                exp_k = ref.count_kmers(qs_k, nthreads=ncpu)
+                checked += len(exp_k)
+                bad += int((exp_k != got_k).sum())
+            result["short_k"]["parity"] = {"checked": checked, "mismatches": bad}
+            mism += bad
         if mism:
             log("PARITY FAILURE: %d sampled counts differ from the oracle" % mism)
             result["value"] = None
             rc = 1
         per_launch_q = mine_n if strong else nq
         kern_s = kernel_ms / 1e3 if launches else elapsed / args.steps
-        tq, tsrc, tnote, stamp = lookup_traffic(args.workload + ("+repeats" if args.genome == "repeats" else ""), k, bwt, kind, total, fused, args.scale == 1.0)
+        tq, tsrc, tnote, stamp = lookup_traffic(args.workload + ("+repeats" if args.genome == "repeats" else ""), k, headline_shape, kind, total, fused, args.scale == 1.0)
         result["roofline"] = roofline_block(orc, ref, queries, k, ncpu, per_launch_q, kern_s, kernel_ms, launches, tq, tsrc, tnote, stamp,
-                                            kernel_label(bwt, k, fused), args.stats_sample, lookup_depth(bwt, k), bwt.get_pair_index(),
-                                            (not fused) and bwt.batch_order_for(k, per_launch_q), sparse=lookup_depth(bwt, k) == bwt.get_sparse_table() != 0)
+                                            headline_shape["kernel"], args.stats_sample, headline_shape["lookup_depth"], headline_shape["pair_index"],
+                                            headline_shape["ordered"], sparse=headline_shape["lookup_depth"] == headline_shape["sparse_depth"] != 0)
         if world == 1 and not args.no_cpu_baseline:
             ncs = min(len(queries), args.cpu_sample)
             t0 = time.time()
@@ -1170,7 +1374,8 @@ def main():
             log("%s: %d symbols on the GPU (%.1f MB, table depth %d, pair stride %d, typical range width %.1f), %d read-derived 31-mers in HBM in %.1fs"
                 % (key, total4, bwt4.device_bytes() / 1e6, bwt4.get_table_depth(), bwt4.get_pair_stride(), bwt4.get_typical_range_width(), n4, time.time() - t0))
             b4 = Batch(bwt4, d_q4, 0, None, 31)
-            ordered = bwt4.batch_order_for(31, n4)
+            shape4 = index_shape(bwt4, 31, False, n4)
+            ordered = shape4["ordered"]
             o4, _, el4, kms4, launches4, _ = measure(b4, 0, n4, n4)
             sampled4 = dict(last_sampled)
             line = {"value": n4 * args.steps / el4, "unit": "queries/s", "ms_per_step": el4 / args.steps * 1e3, "steps": args.steps,
@@ -1187,7 +1392,7 @@ def main():
             line["search_counters"] = counted_pass(bwt4, b4, 0, n4, n4)
             # the same launch with the library's own batch-ordering pass forced on (msbwt_rle_set_batch_order(1); automatic = off, on
             # these very numbers): pack + two bucket passes + ordered search + counts back to the caller's order, all timed
-            if not ordered:
+            if not ordered and args.c4_lab:
                 bwt4.set_batch_order(1)
                 if bwt4.batch_order_for(31, n4):
                     saved = args.steps
@@ -1207,7 +1412,7 @@ def main():
             # What a k-mer costs by COPY NUMBER (the repeat-bearing line only): the batch's own counts pick sub-batches of read-derived 31-mers
             # that occur 1-99, 100-999, 1 000-9 999 and >= 10 000 times in the read set (a young-SINE or satellite 31-mer occurs tens of
             # thousands of times here; at human scale copy numbers are another ~50 x higher), each timed and counted on its own.
-            if cfg4.get("repeats"):
+            if cfg4.get("repeats") and args.c4_lab:
                 line["copy_number_bins"], bins_ok = copy_number_bins(bwt4, d_q4, o4, 31, ((1, 100), (100, 1000), (1000, 10_000), (10_000, 1 << 62)))
                 if not bins_ok:
                     log("PARITY FAILURE on %s: a copy-number sub-batch counts differently from the main run" % key)
@@ -1250,7 +1455,7 @@ def main():
                     log("PARITY FAILURE on %s: %d sampled counts differ from the oracle" % (key, m4))
                     result["value"] = None
                     rc = 1
-                tq, tsrc, tnote, stamp = lookup_traffic(name, 31, bwt4, "reads", total4, False, c4_scale == 1.0)
+                tq, tsrc, tnote, stamp = lookup_traffic(name, 31, shape4, "reads", total4, False, c4_scale == 1.0)
                 live4 = None
                 if c4_scale == 1.0 and not args.no_live_pmc:
                     # this line's HBM-side read traffic measured NOW, like the headline's: one rocprofv3 --pmc FETCH_SIZE child pass over the same
@@ -1267,11 +1472,9 @@ def main():
                         live4 = dict(detail4, bytes_per_query=per_q4, committed_bytes_per_query=tq, seconds=time.time() - t_live)
                         tq, tsrc, tnote = per_q4, "live: rocprofv3 --pmc FETCH_SIZE, one child pass of this run (same index, %d read-derived 31-mers per launch)" % detail4["queries_per_launch"], None
                     log("%s: live PMC traffic: %s" % (key, live4))
-                    bwt4 = msbwt.RleBWT(device=local_rank)   # (only asked for its shape below)
-                    bwt4.load_numpy_file(npy4)
                 line["roofline"] = roofline_block(orc, ref4, qs4, 31, ncpu, n4, kms4 / 1e3 if launches4 else el4 / args.steps, kms4, launches4, tq, tsrc,
-                                                  tnote, stamp, kernel_label(bwt4, 31, False), args.stats_sample, lookup_depth(bwt4, 31), bwt4.get_pair_index(), ordered,
-                                                  sparse=lookup_depth(bwt4, 31) == bwt4.get_sparse_table() != 0)
+                                                  tnote, stamp, shape4["kernel"], args.stats_sample, shape4["lookup_depth"], shape4["pair_index"], ordered,
+                                                  sparse=shape4["lookup_depth"] == shape4["sparse_depth"] != 0)
                 if live4 is not None:
                     line["roofline"]["traffic_live"] = live4
                 if not args.no_cpu_baseline:

@@ -196,6 +196,9 @@ int msbwt_rle_allgather_counts(const msbwt_rle *bwt, void *comm, const void *d_m
  * msbwt_rle_device_status return MSBWT_ERR_OVERFLOW.  Calls on one handle must be ordered by the caller (they share scratch). */
 int msbwt_rle_count_kmers_allgather_device(const msbwt_rle *bwt, void *comm, const void *d_kmers, size_t k, size_t n_mine, void *d_mine_counts,
                                            void *d_all, int wire_bits, int out_bits, int pieces, void *hip_stream);
+/* How that call cuts a shard (a pure function, no device needed): queries per piece -- whole 16-query units, at most `pieces` pieces
+ * for any n_mine, the last one takes what is left. */
+size_t msbwt_allgather_piece_queries(size_t n_mine, int pieces);
 
 /* ---- batch order (no reference counterpart) ----
  * The order in which a batch is handed over does not change a single count, but it changes how fast they come: a batch whose

@@ -69,6 +69,7 @@ SIGNATURES = {
     "msbwt_sparse_hash64": (_int, [_u64, _int, _u64, C.POINTER(C.c_uint32), _pu64]),
     "msbwt_auto_sparse_depth": (_int, [_pu64, _pu64, _int, _u64, _int, C.POINTER(C.c_int), _pu64]),
     "msbwt_rle_download_sparse_table": (_sz, [_vp, _vp, _sz, _vp, _sz]),
+    "msbwt_allgather_piece_queries": (_sz, [_sz, _int]),
     "msbwt_rle_set_search_counters": (_int, [_vp, _int]),
     "msbwt_rle_search_counters": (_int, [_vp, _vp, _vp]),
     "msbwt_rle_set_presence_filter": (_int, [_vp, _int]),

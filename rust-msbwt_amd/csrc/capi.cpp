@@ -417,6 +417,9 @@ int build_sparse(msbwt_rle *h, uint64_t keep_free, uint64_t allowance) {
     };
     hipError_t e = hipMalloc(&tmp.work, work_bytes);
     if (e != hipSuccess) return optional(e, "scratch");
+    // (the frontiers start out as zeros, not as whatever the allocation held: a node {0, 0, 0} is harmless wherever it is read)
+    e = hipMemsetAsync(tmp.work, 0, work_bytes, h->stream);
+    if (e != hipSuccess) return optional(e, "scratch");
     SparseBuildReport rep;
     e = sparse_count_levels(view_of(h), flat, flat_depth, max_depth, tmp.work, work_bytes, &rep, h->stream);
     if (e != hipSuccess) return optional(e, "sizing pass");
@@ -452,7 +455,7 @@ int build_sparse(msbwt_rle *h, uint64_t keep_free, uint64_t allowance) {
         e = hipMalloc(&tmp.lines, lines * 128);
         if (e == hipSuccess) e = hipMalloc(&tmp.counts, lines * sizeof(uint32_t));
         if (e != hipSuccess) return optional(e, "bucket lines");
-        e = sparse_fill(view_of(h), flat, flat_depth, chosen, tmp.lines, nbuckets, uint32_t(probe), tmp.side, tmp.counts, tmp.work, work_bytes, &rep, h->stream);
+        e = sparse_fill(view_of(h), flat, flat_depth, chosen, tmp.lines, nbuckets, uint32_t(probe), tmp.side, nside, tmp.counts, tmp.work, work_bytes, &rep, h->stream);
         if (e == hipSuccess) {
             h->sparse_probe = uint32_t(probe);
             h->sparse_bytes = lines * 128;
@@ -463,6 +466,9 @@ int build_sparse(msbwt_rle *h, uint64_t keep_free, uint64_t allowance) {
         (void)hipFree(tmp.counts);
         tmp.lines = tmp.counts = nullptr;
         nbuckets += nbuckets / 4;
+        // the larger table must still fit what the first one was chosen within (the budget, the eighth of HBM left to the caller) and the format
+        const uint64_t again = nbuckets + kSparseMaxProbe;
+        if (again > 0xFFFFFFFFull || again * 128 + again * sizeof(uint32_t) + nside * 16 > avail) return optional(hipErrorOutOfMemory, "fill pass (no room for more buckets)");
     }
     h->d_sparse = tmp.lines;
     h->d_sparse_side = tmp.side;
@@ -1844,26 +1850,45 @@ int msbwt_rle_count_kmers_allgather_device(const msbwt_rle *ch, void *comm, cons
     }
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     // pieces of whole 16-query units (rows of any k then start 16-byte aligned: the fast kernels), the last one takes what is left
-    const size_t unit = 16, per = std::max<size_t>(unit, (n_mine / size_t(pieces) + unit - 1) / unit * unit);
+    const size_t per = allgather_piece_queries(n_mine, pieces);  // (gather.hpp: at most `pieces` pieces, whatever n_mine)
     // the gather stream starts behind everything the caller has queued so far (its buffers may still be in use there)
     HIP_TRY(h, hipEventRecord(h->piece_events[size_t(pieces)], stream));
     HIP_TRY(h, hipStreamWaitEvent(h->gather_stream, h->piece_events[size_t(pieces)], 0));
     size_t piece = 0;
     for (size_t off = 0; off < n_mine; off += per, ++piece) {
         const size_t len = std::min(per, n_mine - off);
+        if (piece >= size_t(pieces)) {  // (cannot happen: allgather_piece_queries cuts at most `pieces` pieces)
+            rc = fail(h, MSBWT_ERR_INTERNAL, "count_kmers_allgather: more pieces than events");
+            break;
+        }
         rc = launch_count(h, static_cast<const uint8_t *>(d_kmers) + off * k, k, len, static_cast<uint64_t *>(d_mine_counts) + off, stream, kDeviceFlags);
-        if (rc) return rc;
-        HIP_TRY(h, hipEventRecord(h->piece_events[piece], stream));
-        HIP_TRY(h, hipStreamWaitEvent(h->gather_stream, h->piece_events[piece], 0));
-        const hipError_t e = allgather_piece(comm, nranks, static_cast<const uint64_t *>(d_mine_counts), n_mine, off, len, d_all, wire_bits, out_bits, h->d_gather,
-                                             h->d_flags + kDeviceFlags, h->gather_stream, &why);
-        if (e != hipSuccess) return why.empty() ? hip_fail(h, e, "all-gather of a piece of the counts") : fail(h, MSBWT_ERR_RCCL, why);
+        if (rc) break;
+        hipError_t e = hipEventRecord(h->piece_events[piece], stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(h->gather_stream, h->piece_events[piece], 0);
+        if (e != hipSuccess) {
+            rc = hip_fail(h, e, "piece event");
+            break;
+        }
+        e = allgather_piece(comm, nranks, static_cast<const uint64_t *>(d_mine_counts), n_mine, off, len, d_all, wire_bits, out_bits, h->d_gather,
+                            h->d_flags + kDeviceFlags, h->gather_stream, &why);
+        if (e != hipSuccess) {
+            rc = why.empty() ? hip_fail(h, e, "all-gather of a piece of the counts") : fail(h, MSBWT_ERR_RCCL, why);
+            break;
+        }
     }
-    // the caller's stream continues once the last piece has arrived
-    HIP_TRY(h, hipEventRecord(h->piece_events[size_t(pieces)], h->gather_stream));
-    HIP_TRY(h, hipStreamWaitEvent(stream, h->piece_events[size_t(pieces)], 0));
-    return MSBWT_OK;
+    // The caller's stream continues once the last piece has arrived -- also after an error in the middle: pieces already queued on the
+    // gather stream still write d_gather and d_all, so the caller's stream must not run ahead of them (after an RCCL error the
+    // communicator is unusable and other ranks may be left inside ncclAllGather: the caller tears the job down).
+    const hipError_t j1 = hipEventRecord(h->piece_events[size_t(pieces)], h->gather_stream);
+    const hipError_t j2 = j1 == hipSuccess ? hipStreamWaitEvent(stream, h->piece_events[size_t(pieces)], 0) : j1;
+    if (j2 != hipSuccess) {
+        (void)hipStreamSynchronize(h->gather_stream);
+        if (!rc) rc = hip_fail(h, j2, "join of the gather stream");
+    }
+    return rc;
 }
+
+size_t msbwt_allgather_piece_queries(size_t n_mine, int pieces) { return allgather_piece_queries(n_mine, pieces); }
 
 // ---- batch order keys (order.hip): sort a batch by them and it walks the index in ascending order -----------------------
 int msbwt_kmer_order_keys(const uint8_t *kmers, size_t k, size_t n, uint64_t *out_keys) {

@@ -27,6 +27,14 @@ size_t allgather_scratch_bytes(size_t n_mine, int nranks, int wire_bits);
 hipError_t allgather_piece(void *comm, int nranks, const uint64_t *d_mine, size_t n_mine, size_t off, size_t len, void *d_all, int wire_bits, int out_bits,
                            void *d_scratch, uint32_t *flags, hipStream_t stream, std::string *why);
 size_t allgather_pieces_scratch_bytes(size_t n_mine, int nranks, int wire_bits);
+// Queries per piece when a shard of n_mine queries is cut into at most `pieces` pieces of whole 16-query units (rows of any k then start
+// 16-byte aligned: the fast kernels); the last piece takes what is left.  ceil, not floor: n_mine = 1087, pieces = 64 -> 32 per piece,
+// 34 pieces (floor gave 16 per piece and 68 pieces for 65 events).  Pinned by a CPU test through msbwt_allgather_piece_queries.
+inline size_t allgather_piece_queries(size_t n_mine, int pieces) {
+    const size_t unit = 16, p = pieces < 1 ? 1 : size_t(pieces);
+    const size_t per = ((n_mine + p - 1) / p + unit - 1) / unit * unit;
+    return per < unit ? unit : per;
+}
 // d_out[i] = d_in[i] as u32; a count that does not fit sets kFlagNarrowOverflow in *flags (the 32-bit count outputs of the
 // packed host entry point)
 hipError_t launch_narrow_counts32(const uint64_t *d_in, uint32_t *d_out, uint64_t n, uint32_t *flags, hipStream_t stream);

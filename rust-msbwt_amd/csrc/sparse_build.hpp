@@ -27,10 +27,10 @@ size_t sparse_work_bytes(uint64_t free_bytes);
 // [0, total), depth 0) level by level up to max_depth and reports the distinct counts on the way.  Synchronises the stream.
 hipError_t sparse_count_levels(const IndexView &ix, const void *flat_entries, int flat_depth, int max_depth, void *d_work, size_t work_bytes,
                                SparseBuildReport *report, hipStream_t stream);
-// Fill pass at `depth` (same parity rules as the sizing pass): `lines` (nbuckets x 128 bytes, zeroed here) and `side`
-// (report->escapes[depth] x 16 bytes, may be nullptr when 0) are written; d_counts: nbuckets x u32 of scratch.
+// Fill pass at `depth` (any depth the sizing pass reached or passed): `lines` (nbuckets x 128 bytes, zeroed here) and `side`
+// (nside = report->escapes[depth] entries of 16 bytes, may be nullptr when 0) are written; d_counts: nbuckets x u32 of scratch.
 // hipErrorInvalidValue when some entry found no slot within `probe` buckets (the caller retries with more buckets).
 hipError_t sparse_fill(const IndexView &ix, const void *flat_entries, int flat_depth, int depth, void *lines, uint64_t nbuckets, uint32_t probe,
-                       void *side, void *d_counts, void *d_work, size_t work_bytes, SparseBuildReport *report, hipStream_t stream);
+                       void *side, uint64_t nside, void *d_counts, void *d_work, size_t work_bytes, SparseBuildReport *report, hipStream_t stream);
 
 }  // namespace msbwt

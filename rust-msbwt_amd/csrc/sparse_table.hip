@@ -143,6 +143,7 @@ struct FillEnv {
     uint32_t *counts;    // slot counter per bucket
     uint4 *side;
     uint32_t nbuckets, probe, n;  // n = 2 depth
+    uint64_t nside;      // entries the side array holds
 };
 
 // puts the entry of (key, [nl, nh)) into its bucket; `cur`: the cursor block (side cursor, displaced, failed)
@@ -156,6 +157,10 @@ __device__ __forceinline__ void sparse_insert(const FillEnv &env, uint64_t key, 
     uint32_t wf = uint32_t(nh - nl);
     if (nh - nl >= kSparseEscapeWidth) {
         const uint64_t idx = atomicAdd(cur + kSideCursor, 1ull);
+        if (idx >= env.nside) {  // (more wide ranges than the sizing pass counted: never on a consistent build -- refuse rather than write outside)
+            atomicOr(cur + kFailed, 2ull);
+            return;
+        }
         env.side[idx] = make_uint4(uint32_t(nl), uint32_t(nl >> 32), uint32_t(nh), uint32_t(nh >> 32));
         lval = idx;
         wf = kSparseEscapeWidth;
@@ -194,6 +199,10 @@ __global__ __launch_bounds__(kThreads) void k_sparse_expand_pair(const Node *__r
                                                                  const uint4 *__restrict__ pair_blocks, const uint64_t *__restrict__ pair_super,
                                                                  uint32_t stride96, Node *__restrict__ out, uint64_t cap,
                                                                  unsigned long long *__restrict__ cur, FillEnv env) {
+    // An earlier level of this chunk overflowed its frontier: the slots of the thread whose reservation straddled the end were never
+    // written, so this level must not read them (raw allocation contents would become wild line addresses).  The host takes the whole
+    // chunk again at half the size.
+    if (cur[kOverflow] != 0ull) return;
     const uint64_t n = min(uint64_t(cur[kCurLevel + depth]), in_cap);
     const bool s96 = stride96 != 0u;
     for (uint64_t base = uint64_t(blockIdx.x) * kThreads; base < n; base += uint64_t(gridDim.x) * kThreads) {
@@ -278,6 +287,7 @@ __device__ __forceinline__ void plane_line_four(const uint4 *__restrict__ blk, u
 
 __global__ __launch_bounds__(kThreads) void k_sparse_expand_plane(const Node *__restrict__ in, uint64_t in_cap, uint32_t depth,
                                                                   const uint4 *__restrict__ blocks, unsigned long long *__restrict__ cur, FillEnv env) {
+    if (cur[kOverflow] != 0ull) return;  // (as in k_sparse_expand_pair)
     const uint64_t n = min(uint64_t(cur[kCurLevel + depth]), in_cap);
     for (uint64_t base = uint64_t(blockIdx.x) * kThreads; base < n; base += uint64_t(gridDim.x) * kThreads) {
         const uint64_t i = base + threadIdx.x;
@@ -404,7 +414,7 @@ hipError_t sparse_count_levels(const IndexView &ix, const void *flat_entries, in
     if (w.cap < 1024) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(w.cur, 0, kCursorWords * sizeof(unsigned long long), stream);
     if (e != hipSuccess) return e;
-    const FillEnv none{nullptr, nullptr, nullptr, 0, 0, uint32_t(2 * max_depth)};
+    const FillEnv none{nullptr, nullptr, nullptr, 0, 0, uint32_t(2 * max_depth), 0};
     const uint64_t parents = flat_entries ? (uint64_t(1) << (2 * flat_depth)) : 1;
     g_plan = ChunkPlan{flat_entries, flat_depth, max_depth, w.cap, {}};
     // Chunks of parents: the first is small, the following ones are sized by what the last one's largest frontier was, aiming at a
@@ -447,7 +457,7 @@ hipError_t sparse_count_levels(const IndexView &ix, const void *flat_entries, in
 }
 
 hipError_t sparse_fill(const IndexView &ix, const void *flat_entries, int flat_depth, int depth, void *lines, uint64_t nbuckets, uint32_t probe, void *side,
-                       void *d_counts, void *d_work, size_t work_bytes, SparseBuildReport *report, hipStream_t stream) {
+                       uint64_t nside, void *d_counts, void *d_work, size_t work_bytes, SparseBuildReport *report, hipStream_t stream) {
     if (flat_entries == nullptr) flat_depth = 0;
     if (!ix.pair_blocks || !lines || !d_counts || depth < kSparseMinDepth || depth > kSparseMaxDepth || flat_depth >= depth || nbuckets == 0 ||
         nbuckets + probe > 0xFFFFFFFFull || int(probe) > sparse_probe_limit(depth, nbuckets))
@@ -458,11 +468,13 @@ hipError_t sparse_fill(const IndexView &ix, const void *flat_entries, int flat_d
     if (e == hipSuccess) e = hipMemsetAsync(lines, 0, nlines * 128, stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_counts, 0, nlines * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    const FillEnv env{static_cast<uint4 *>(lines), static_cast<uint32_t *>(d_counts), static_cast<uint4 *>(side), uint32_t(nbuckets), probe, uint32_t(2 * depth)};
-    // The chunking of the sizing pass holds for every depth up to the one it was made for (shallower frontiers are no larger
-    // than the ones it saw).  Without one (a fill that was not preceded by its sizing pass): small chunks.
+    const FillEnv env{static_cast<uint4 *>(lines), static_cast<uint32_t *>(d_counts), static_cast<uint4 *>(side), uint32_t(nbuckets), probe, uint32_t(2 * depth),
+                      side ? nside : 0};
+    // The chunking of the sizing pass holds for every depth up to the one it was made for, of either parity: the pair levels are the
+    // same ones (a frontier at depth d does not depend on where the expansion ends), and the last level is never materialised.  Without
+    // one (a fill that was not preceded by its sizing pass): small chunks.
     std::vector<Chunk> chunks;
-    if (g_plan.flat == flat_entries && g_plan.flat_depth == flat_depth && g_plan.depth >= depth && g_plan.cap == w.cap && (g_plan.depth - depth) % 2 == 0) {
+    if (g_plan.flat == flat_entries && g_plan.flat_depth == flat_depth && g_plan.depth >= depth && g_plan.cap == w.cap) {
         chunks = g_plan.chunks;
     } else {
         const uint64_t parents = flat_entries ? (uint64_t(1) << (2 * flat_depth)) : 1;

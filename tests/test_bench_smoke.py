@@ -11,13 +11,44 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _run(args):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+COMPACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config")
+
+
+def check_compact_line(stdout, extras_path):
+    """stdout carries ONE line: json.loads-able, under 8 KB (round 5's 25 KB line could not be parsed by the driver), with the contract's
+    keys; the full record is in the extras file.  -> (compact, full)"""
+    lines = [l for l in stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "bench.py must print exactly one JSON line: %r" % stdout[:500]
+    assert len(lines[0].encode()) < 8192, "the stdout line has %d bytes" % len(lines[0].encode())
+    compact = json.loads(lines[-1])
+    for key in COMPACT_KEYS:
+        assert key in compact, key
+    assert "workload" in compact["config"] and "model" not in compact["config"] and len(compact["config"]["workload"]) <= 420
+    assert compact["extras_file"] == os.path.basename(extras_path)
+    full = json.load(open(extras_path))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling"):
+        assert compact[key] == full[key], key
+    if "roofline" in full and "frac" in full["roofline"]:
+        assert "frac" in compact["roofline"] and compact["roofline"]["frac"] == full["roofline"]["frac"]
+        assert compact["roofline"]["kernel_ms"] == full["roofline"]["kernel_ms"] and "layout_bytes_per_query" in compact["roofline"]
+    if "cpu_baseline" in full:
+        assert compact["cpu_baseline"]["value"] == full["cpu_baseline"]["value"] and compact["cpu_baseline"]["cores"] == 1
+    if "parity" in full:
+        assert compact["parity"]["mismatches"] == full["parity"]["mismatches"]
+    return compact, full
+
+
+def _run(args, tmp=[0]):
+    tmp[0] += 1
+    extras = os.path.join(ROOT, "gpurun_out", "bench_extras_test_%d_%d.json" % (os.getpid(), tmp[0]))
+    os.makedirs(os.path.dirname(extras), exist_ok=True)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--extras-file", extras] + args, capture_output=True, text=True,
                          timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, "bench.py must print exactly one JSON line"
-    return json.loads(lines[0])
+    compact, full = check_compact_line(out.stdout, extras)
+    os.remove(extras)
+    full["_compact"] = compact
+    return full
 
 
 @pytest.mark.parametrize("extra", [["--scale", "0.00003"],  # the default workload (human-scale stand-in), shrunk
@@ -43,7 +74,16 @@ def test_bench_contract(extra):
 def test_bench_default_run_carries_the_real_msbwt_line():
     """The default run's extra key c4_real_reads (the REAL MSBWT of config C4, read-derived 31-mers), here on a
     shrunk C4 beside a shrunk human-scale index: own value, roofline, parity."""
-    r = _run(["--scale", "0.00003", "--c4-scale", "0.002", "--steps", "2", "--warmup", "1", "--cpu-sample", "2000", "--parity-sample", "5000"])
+    r = _run(["--scale", "0.00003", "--c4-scale", "0.002", "--c4-lab", "--steps", "2", "--warmup", "1", "--cpu-sample", "2000", "--parity-sample", "5000"])
+    compact = r["_compact"]
+    assert compact["roofline"]["kernel_ms"] > 0 and compact["cpu_baseline"]["value"] > 0 and compact["parity"]["mismatches"] == 0
+    for key in ("c4_real_reads_qps", "c4_repeats_qps", "undeclared_k_qps", "headline_sparse_off_qps"):
+        assert compact["extras"][key] > 0, key
+    assert compact["extras"]["c4_real_reads_mismatches"] == 0 and compact["extras"]["undeclared_k_counts_equal_headline"] is True
+    assert compact["extras"]["headline_sparse_off_counts_equal_headline"] is True and compact["extras"]["headline_sparse_off_sparse_table_depth"] == 0
+    for rec in (r["short_k"]["k17"], r["short_k"]["k19"], r["short_k"]["k21"]):
+        assert rec["default_qps"] > 0 and rec["sparse_off_qps"] > 0 and rec["counts_equal"] is True
+    assert r["short_k"]["parity"]["mismatches"] == 0 and r["short_k"]["parity"]["checked"] > 0
     c4 = r["c4_real_reads"]
     assert c4["value"] > 0 and c4["parity"]["mismatches"] == 0 and c4["parity"]["checked"] > 0
     assert c4["parity"]["mean_count_in_sample"] > 5      # a real 30x read set: present k-mers occur ~ coverage times
@@ -114,11 +154,13 @@ def test_bench_two_ranks_rehearsal(payload):
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
            "--workload", "c2", "--scale", "0.003", "--steps", "3", "--warmup", "1", "--parity-sample", "5000", "--payload", payload,
            "--scaling", "weak"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    extras = os.path.join(ROOT, "gpurun_out", "bench_extras_test_ranks_%d_%s.json" % (os.getpid(), payload))
+    os.makedirs(os.path.dirname(extras), exist_ok=True)
+    out = subprocess.run(cmd + ["--extras-file", extras], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    r = json.loads(lines[0])
+    compact, r = check_compact_line(out.stdout, extras)
+    os.remove(extras)
+    assert "ranks_kernel_ms_max" in compact["extras"] and compact["n_gpus"] == 2
     assert r["n_gpus"] == 2 and r["steps"] == 3 and r["scaling"] == "weak" and r["parity"]["mismatches"] == 0
     assert "cpu_baseline" not in r            # reported at N=1 only
     assert r["value"] > 0 and "x2" in r["config"]["parallelism"]
@@ -137,13 +179,16 @@ def test_bench_rccl_calls_on_one_rank(payload):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    extras = os.path.join(ROOT, "gpurun_out", "bench_extras_test_rccl_%d_%s.json" % (os.getpid(), payload))
+    os.makedirs(os.path.dirname(extras), exist_ok=True)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--dist-backend", "nccl", "--scale", "0.00003",
-                          "--steps", "4", "--warmup", "1", "--parity-sample", "5000", "--payload", payload, "--no-c5"],
+                          "--steps", "4", "--warmup", "1", "--parity-sample", "5000", "--payload", payload, "--no-c5", "--extras-file", extras],
                          capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, "stdout must carry the JSON line only (RCCL's banner belongs on stderr): %r" % out.stdout[:500]
-    r = json.loads(lines[0])
+    compact, r = check_compact_line(out.stdout, extras)   # (stdout carries the JSON line only: RCCL's banner belongs on stderr)
+    os.remove(extras)
+    for key in ("native_gather_qps", "weak_scaling_qps", "native_gather_single_batch_latency_ms", "native_gather_single_batch_pipelined_ms", "ranks_kernel_ms_max"):
+        assert compact["extras"][key] > 0, key
     assert r["n_gpus"] == 1 and r["scaling"] == "strong" and r["parity"]["mismatches"] == 0 and r["value"] > 0
     assert "RCCL" in r["config"]["parallelism"] and ("int16" if payload == "auto" else "int64") in r["config"]["parallelism"]
     assert r["weak_scaling"]["value"] > 0

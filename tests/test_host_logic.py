@@ -332,6 +332,45 @@ def test_gather_entry_points_reject_bad_arguments_without_touching_a_device():
     assert L.msbwt_auto_pair_stride(10**9, 10**11, 3 * 10**11, 30.0, C.byref(stride)) == 0 and stride.value in (96, 128)
 
 
+def test_bench_stdout_line_is_compact():
+    """bench.py prints ONE line the driver must parse: round 5's had grown to 25 KB and was lost.  compact_record cuts a full record
+    (here round 5's own, as committed) to the contract's keys + roofline + cpu_baseline + parity + scalar extras, well under 8 KB."""
+    import json
+    import bench
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r05_lab", "bench_default_full_2.json")).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 20000
+    c = bench.compact_record(full, os.path.join(ROOT, "bench_extras.json"))
+    line = json.dumps(c)
+    assert len(line) < 4096 < bench.COMPACT_LIMIT
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline", "parity", "extras", "extras_file"):
+        assert key in c, key
+    assert c["value"] == full["value"] and c["roofline"]["frac"] == full["roofline"]["frac"] and c["roofline"]["traffic"] == full["roofline"]["traffic"]
+    assert c["cpu_baseline"]["value"] == full["cpu_baseline"]["value"] and c["cpu_baseline"]["cores"] == 1 and c["parity"] == {"checked": 2000000, "mismatches": 0}
+    assert c["extras"]["c4_real_reads_qps"] == full["c4_real_reads"]["value"] and c["extras"]["c5_random_1e9_mismatches"] == 0
+    assert "note" not in line and "telemetry" not in line and c["extras_file"] == "bench_extras.json"
+    # a record with absurdly long strings still fits
+    full["config"]["workload"] = "x" * 100000
+    full["roofline"]["traffic_source"] = "y" * 100000
+    assert len(json.dumps(bench.compact_record(full, "e.json"))) < 4096
+
+
+def test_pipelined_gather_cuts_a_shard_into_at_most_the_pieces_asked_for():
+    """msbwt_rle_count_kmers_allgather_device holds pieces + 1 events: its cut (csrc/gather.hpp, allgather_piece_queries) never makes more
+    pieces than that for any shard size -- round 5's floor-based cut made 68 of n_mine = 1087, pieces = 64 -- and every piece but the
+    last is a whole number of 16-query units, like the Python twin's (sharded.count_kmers_pipelined)."""
+    L = _lib.lib()
+    for pieces in range(1, 65):
+        for n in list(range(1, 2200)) + [1087, 543, 2111, 10**6 + 7, 3 * 10**8, 2**40 + 5]:
+            per = L.msbwt_allgather_piece_queries(n, pieces)
+            assert per >= 16 and per % 16 == 0
+            made = -(-n // per)
+            assert 1 <= made <= pieces, (n, pieces, per, made)
+            assert per == max(16, -(-(-(-n // pieces)) // 16) * 16)
+    assert L.msbwt_allgather_piece_queries(1087, 64) == 32 and L.msbwt_allgather_piece_queries(543, 32) == 32
+    assert L.msbwt_allgather_piece_queries(0, 4) == 16 and L.msbwt_allgather_piece_queries(5, 0) == 16
+
+
 def test_missing_rccl_is_an_error_code_not_a_crash():
     """A host without RCCL: the communicator entry points return MSBWT_ERR_RCCL (include/msbwt_hip.h) -- in a fresh process,
     with MSBWT_RCCL_LIB naming a library that does not exist (an explicit name is taken literally: no search beside it)."""
