@@ -280,14 +280,27 @@ int msbwt_rle_get_table_packed(const msbwt_rle *bwt);
  * msbwt_rle_sparse_table_info: out[MSBWT_SPARSE_INFO_WORDS] = [0] depth, [1] entries, [2] buckets, [3] bytes of the bucket lines,
  * [4] entries in the side array, [5] its bytes, [6] entries displaced to a later bucket, [7] depth of the direct table the build
  * started from, [9] buckets a lookup may go beyond its own, [10 + d] DISTINCT d-symbol suffixes that occur (d = 0..31; 0 where the
- * build did not pass: it advances two symbols at a time), [45 + d] of which 255 or more wide.  The counts are kept even when no
- * table was built.
+ * build did not pass: it advances two symbols at a time), [45 + d] of which 255 or more wide, [80 + d] of which exactly 1 wide (suffixes
+ * that occur once: on reads with errors, mostly error k-mers), [8] 1 = the table is of the two-tier form, [42] suffixes in its filters.
+ * The counts are kept even when no table was built.
+ * TWO-TIER form (msbwt_rle_set_sparse_tiers; rust-msbwt_amd/csrc/sparse_table.hpp): the complete table's size follows the distinct
+ * suffixes, and on reads WITH errors most of those occur once (a 30x human read set with 0.5 % substitutions: 1.3e10 distinct 23-mers,
+ * 185 GB, of which about 3e9 -- the genome's -- occur more than once).  The two-tier table keeps entries only for the suffixes whose
+ * range is at least 2 wide and sets, for each of the others, four bits of a filter inside its own bucket line (no false negatives):
+ * a lookup that finds its tag is served as before, one that finds neither tag nor filter bits is count 0, and one whose filter bits are
+ * set continues through the direct table and the search -- the reference's own path (src/rle_bwt.rs:202-287) -- so every count stays
+ * exact whatever the filter says.  mode: -1 = automatic (default: the two-tier form of a depth where its complete table does not fit
+ * HBM or the memory budget -- tried before the next shallower depth), 0 = complete tables only, 1 = two-tier only (tests, measurements).
+ * MSBWT_SPARSE_TIERS=auto|0|1 sets the initial mode.  Takes effect immediately if an index is loaded.  Results never change.
+ * msbwt_rle_get_sparse_tiers: 1 when the table in HBM is of the two-tier form, else 0.
  * msbwt_sparse_hash / msbwt_sparse_table_shape: the table's hash and sizing as pure functions (no device needed).
  * msbwt_rle_download_sparse_table: copies the bucket lines (and the side array) to the host; returns the bytes of the lines,
  * SIZE_MAX without a table or on error (tests check every entry against the oracle). */
-#define MSBWT_SPARSE_INFO_WORDS 80
+#define MSBWT_SPARSE_INFO_WORDS 120
 int msbwt_rle_set_sparse_table(msbwt_rle *bwt, int depth);
 int msbwt_rle_get_sparse_table(const msbwt_rle *bwt);
+int msbwt_rle_set_sparse_tiers(msbwt_rle *bwt, int mode);
+int msbwt_rle_get_sparse_tiers(const msbwt_rle *bwt);
 int msbwt_rle_sparse_table_info(const msbwt_rle *bwt, uint64_t *out);
 int msbwt_sparse_hash(uint64_t key, int depth, uint64_t nbuckets, uint32_t *bucket, uint32_t *tag);
 int msbwt_sparse_hash64(uint64_t key, int depth, uint64_t nbuckets, uint32_t *bucket, uint64_t *tag); /* the whole tag: 24, 32 or 40 bits by depth */
@@ -296,6 +309,11 @@ int msbwt_sparse_table_shape(int depth, uint64_t entries, uint64_t *nbuckets, in
  * as msbwt_rle_sparse_table_info reports them ([10 + d], [45 + d]), the depth of the direct table the count started from, and the bytes
  * the table and its build scratch may take -> the depth the loader would build (0 = none fits) and the bytes of that table. */
 int msbwt_auto_sparse_depth(const uint64_t *distinct, const uint64_t *wide, int parent_depth, uint64_t avail_bytes, int query_length, int *depth, uint64_t *table_bytes);
+/* ... with the two-tier form in the choice: singles[d] as [80 + d] above, tiers as msbwt_rle_set_sparse_tiers -> also *two_tier (0 / 1). */
+int msbwt_auto_sparse_choice(const uint64_t *distinct, const uint64_t *wide, const uint64_t *singles, int parent_depth, uint64_t avail_bytes, int query_length,
+                             int tiers, int *depth, int *two_tier, uint64_t *table_bytes);
+/* The two-tier filter as a pure function: the filter word (0..7, i.e. word 23 + that of the bucket line) and the four bits of a key with this tag. */
+int msbwt_sparse_filter_bits(uint64_t tag, uint32_t *word, uint32_t *mask);
 /* The k the index will mostly be asked about (0 = unknown, the default; MSBWT_QUERY_K in the environment sets the initial value).  The
  * reference's count_kmer takes any k per call and so does this library -- results never depend on the hint -- but a hashed table of
  * d-mers serves k >= d only, and every two symbols of depth save a present k-mer one index line: with k unknown the automatic sparse

@@ -179,6 +179,10 @@ class RleBWT final : public BWT {
     /// the k this index will mostly be asked about (0 = unknown): the automatic sparse table reaches min(k, 27) instead of 23
     void set_query_length(int k) { check(msbwt_rle_set_query_length(raw_, k)); }
     int get_query_length() const { return msbwt_rle_get_query_length(raw_); }
+    /// two-tier form of the sparse table (entries for the suffixes that occur at least twice, filter bits for the rest: read sets with errors):
+    /// -1 = where the complete table of a depth does not fit (default), 0 = never, 1 = always
+    void set_sparse_tiers(int mode) { check(msbwt_rle_set_sparse_tiers(raw_, mode)); }
+    bool get_sparse_tiers() const { return msbwt_rle_get_sparse_tiers(raw_) != 0; }
     int get_sparse_table() const { return msbwt_rle_get_sparse_table(raw_); }
     void set_table_side(int mode) { check(msbwt_rle_set_table_side(raw_, mode)); }
     std::uint64_t device_bytes() const { return msbwt_rle_device_bytes(raw_); }

@@ -11,6 +11,7 @@ ERR_IO, ERR_UNEXPECTED_EOF, ERR_BAD_HEADER, ERR_INVALID_SYMBOL = -1, -2, -3, -4
 ERR_INVALID_RANGE, ERR_HIP, ERR_NOT_LOADED, ERR_TOO_LARGE, ERR_INVALID_ARG, ERR_INTERNAL = -5, -6, -7, -8, -9, -10
 ERR_OVERFLOW, ERR_RCCL = -11, -12
 COMM_ID_BYTES = 128
+SPARSE_INFO_WORDS = 120  # MSBWT_SPARSE_INFO_WORDS
 
 SIZE_MAX = C.c_size_t(-1).value
 
@@ -86,6 +87,10 @@ SIGNATURES = {
     "msbwt_rle_get_pair_stride": (_int, [_vp]),
     "msbwt_rle_get_typical_range_width": (C.c_double, [_vp]),
     "msbwt_auto_pair_stride": (_int, [_u64, _u64, _u64, C.c_double, C.POINTER(C.c_int)]),
+    "msbwt_rle_set_sparse_tiers": (_int, [_vp, _int]),
+    "msbwt_rle_get_sparse_tiers": (_int, [_vp]),
+    "msbwt_auto_sparse_choice": (_int, [_pu64, _pu64, _pu64, _int, _u64, _int, _int, C.POINTER(C.c_int), C.POINTER(C.c_int), _pu64]),
+    "msbwt_sparse_filter_bits": (_int, [_u64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "msbwt_rle_set_query_length": (_int, [_vp, _int]),
     "msbwt_rle_get_query_length": (_int, [_vp]),
     "msbwt_auto_sparse_max_depth": (_int, [_int]),

@@ -64,6 +64,8 @@ struct msbwt_rle {
     uint64_t sparse_bytes = 0, sparse_side_bytes = 0;
     uint32_t sparse_nbuckets = 0, sparse_probe = 0;
     int sparse_depth = 0;
+    bool sparse_tier = false;        // the table in HBM is of the two-tier form (entries for the suffixes at least 2 wide, filter bits for the rest)
+    int wanted_tiers = -1;           // -1 = two-tier where the complete table of a depth does not fit, 0 = complete tables only, 1 = two-tier only
     int wanted_streaming = -1;       // index lines fetched non-temporally: -1 = when the random-access arrays dwarf the caches, 0 = never, 1 = always
     int wanted_sparse = -1;          // -1 = automatic (beside a pair index, as deep as the data and HBM allow, at most 23 -- or what query_length says), 0 = off, 16..28 = that depth
     int query_length = 0;            // the k the index will mostly be asked about (msbwt_rle_set_query_length), 0 = unknown
@@ -126,7 +128,8 @@ constexpr uint64_t kStreamLinesFrom = uint64_t(4) << 30;  // random-access array
 constexpr size_t kStatusBytes = 1024;  // flag words, debug record (bytes 64..128), search counters (bytes 128..256)
 constexpr size_t kCountersOffset = 128;
 static_assert(MSBWT_SEARCH_COUNTERS == kSearchCounters, "the header's counter block is the kernels'");
-static_assert(10 + kSparseMaxDepth + 1 <= 45 && 45 + kSparseMaxDepth + 1 <= MSBWT_SPARSE_INFO_WORDS, "msbwt_rle_sparse_table_info: [10 + d] distinct, [45 + d] wide");
+static_assert(10 + kSparseMaxDepth + 1 <= 42 && 45 + kSparseMaxDepth + 1 <= 80 && 80 + kSparseMaxDepth + 1 <= MSBWT_SPARSE_INFO_WORDS,
+              "msbwt_rle_sparse_table_info: [10 + d] distinct, [42] filtered, [45 + d] wide, [80 + d] once");
 constexpr size_t kPackScratchOffset = 256;  // two u64 of the table packer (escape-line count, side-array cursor)
 constexpr size_t kMaxTimedEvents = 256;  // start/stop pairs kept before timed_launch folds them into the running sum
 constexpr int kHostFlags = 0, kDeviceFlags = 1;  // words of the status block
@@ -201,6 +204,7 @@ void release_sparse(msbwt_rle *h) {
     h->sparse_bytes = h->sparse_side_bytes = 0;
     h->sparse_nbuckets = h->sparse_probe = 0;
     h->sparse_depth = 0;
+    h->sparse_tier = false;
     h->sparse_report = SparseBuildReport{};
 }
 
@@ -253,12 +257,13 @@ IndexView view_of(msbwt_rle *h) {
         const uint64_t hot = h->d_pair_blocks ? h->pair_bytes : h->nblocks * kBlockBytes;
         v.stream_lines = h->wanted_streaming > 0 || (h->wanted_streaming < 0 && hot >= kStreamLinesFrom);
     }
-    if (h->d_sparse && h->d_pair_blocks) {
+    if (h->d_sparse && (h->d_pair_blocks || h->block_format == kBlocksRuns)) {  // (run blocks: built from pair blocks that are gone again)
         v.sparse.lines = h->d_sparse;
         v.sparse.nbuckets = h->sparse_nbuckets;
         v.sparse.depth = uint32_t(h->sparse_depth);
         v.sparse.probe = h->sparse_probe;
         v.sparse.side = h->d_sparse_side;
+        v.sparse.tier = h->sparse_tier ? 1u : 0u;
     }
     v.debug = h->d_flags ? reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(h->d_flags) + 64) : nullptr;
     return v;  // tile_counter: with_tickets()
@@ -426,7 +431,7 @@ int build_sparse(msbwt_rle *h, uint64_t keep_free, uint64_t allowance) {
     if (verbose) {
         std::fprintf(stderr, "[msbwt] sparse table: distinct suffixes by length:");
         for (int d = flat_depth; d <= max_depth; ++d)
-            if (rep.distinct[d]) std::fprintf(stderr, " %d: %llu (%llu wide)", d, (unsigned long long)rep.distinct[d], (unsigned long long)rep.escapes[d]);
+            if (rep.distinct[d]) std::fprintf(stderr, " %d: %llu (%llu wide, %llu once)", d, (unsigned long long)rep.distinct[d], (unsigned long long)rep.escapes[d], (unsigned long long)rep.singles[d]);
         std::fprintf(stderr, "\n");
     }
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return MSBWT_OK;
@@ -434,7 +439,9 @@ int build_sparse(msbwt_rle *h, uint64_t keep_free, uint64_t allowance) {
     // (an explicit depth wins over a memory budget, like the other explicit settings: only the HBM itself limits it)
     const uint64_t avail = std::min<uint64_t>(explicit_depth ? kNoBudget : allowance, uint64_t(free_b) > spare ? uint64_t(free_b) - spare : 0);
     // the depth: a pure function of the counts and the bytes (sparse_policy.hpp, pinned by a CPU test through msbwt_auto_sparse_depth)
-    const SparseChoice choice = choose_sparse_depth(rep.distinct, rep.escapes, flat_depth, max_depth, avail, explicit_depth ? max_depth : 0);
+    // (the two-tier form sends the suffixes that occur once down the direct table's path: it needs that table's side array for escape lines)
+    const int tiers = h->wanted_table_side == 0 ? 0 : h->wanted_tiers;
+    const SparseChoice choice = choose_sparse_depth(rep.distinct, rep.escapes, flat_depth, max_depth, avail, explicit_depth ? max_depth : 0, rep.singles, tiers);
     const int chosen = choice.depth;
     uint64_t nbuckets = choice.nbuckets;
     if (!chosen && explicit_depth) return fail(h, MSBWT_ERR_HIP, "the sparse table of the requested depth does not fit in HBM");
@@ -455,7 +462,7 @@ int build_sparse(msbwt_rle *h, uint64_t keep_free, uint64_t allowance) {
         e = hipMalloc(&tmp.lines, lines * 128);
         if (e == hipSuccess) e = hipMalloc(&tmp.counts, lines * sizeof(uint32_t));
         if (e != hipSuccess) return optional(e, "bucket lines");
-        e = sparse_fill(view_of(h), flat, flat_depth, chosen, tmp.lines, nbuckets, uint32_t(probe), tmp.side, nside, tmp.counts, tmp.work, work_bytes, &rep, h->stream);
+        e = sparse_fill(view_of(h), flat, flat_depth, chosen, choice.tier, tmp.lines, nbuckets, uint32_t(probe), tmp.side, nside, tmp.counts, tmp.work, work_bytes, &rep, h->stream);
         if (e == hipSuccess) {
             h->sparse_probe = uint32_t(probe);
             h->sparse_bytes = lines * 128;
@@ -476,11 +483,12 @@ int build_sparse(msbwt_rle *h, uint64_t keep_free, uint64_t allowance) {
     h->sparse_side_bytes = nside * 16;
     h->sparse_nbuckets = uint32_t(nbuckets);
     h->sparse_depth = chosen;
+    h->sparse_tier = choice.tier;
     h->sparse_report = rep;
     if (verbose)
-        std::fprintf(stderr, "[msbwt] sparse table: depth %d, %llu entries in %u buckets (%.2f per bucket, %llu displaced, %llu in the side array), %.2f GB\n", chosen,
-                     (unsigned long long)rep.entries, h->sparse_nbuckets, double(rep.entries) / double(nbuckets), (unsigned long long)rep.displaced,
-                     (unsigned long long)rep.nescapes, double(h->sparse_bytes + h->sparse_side_bytes) / 1e9);
+        std::fprintf(stderr, "[msbwt] sparse table: depth %d%s, %llu entries in %u buckets (%.2f per bucket, %llu displaced, %llu in the side array, %llu in the filters), %.2f GB\n", chosen,
+                     choice.tier ? " two-tier" : "", (unsigned long long)rep.entries, h->sparse_nbuckets, double(rep.entries) / double(nbuckets), (unsigned long long)rep.displaced,
+                     (unsigned long long)rep.nescapes, (unsigned long long)rep.filtered, double(h->sparse_bytes + h->sparse_side_bytes) / 1e9);
     return MSBWT_OK;
 }
 
@@ -489,7 +497,9 @@ int build_sparse(msbwt_rle *h, uint64_t keep_free, uint64_t allowance) {
 constexpr int kDirectDepthBesideSparse = 13;  // levels of the flat table (the packed one: + 2)
 
 int rebuild_table(msbwt_rle *h, bool allow_sparse = true) {
-    release_sparse(h);
+    // (run blocks: their sparse table was built at load time from temporary plane and pair blocks -- build_sparse_for_runs -- and does
+    // not depend on the direct table rebuilt here; it goes with the index, or by msbwt_rle_set_sparse_table(0))
+    if (h->block_format == kBlocksPlanes) release_sparse(h);
     if (h->d_filter) (void)hipFree(h->d_filter);
     h->d_filter = nullptr;
     h->filter_depth = 0;
@@ -524,6 +534,7 @@ int rebuild_table(msbwt_rle *h, bool allow_sparse = true) {
     // again as if there were no such thing.
     const bool try_sparse = allow_sparse && h->wanted_sparse != 0 && h->d_pair_blocks != nullptr && h->block_format == kBlocksPlanes && h->totals.total > 0;
     bool capped = false;
+    const int uncapped_depth = depth;
     if (try_sparse && automatic && depth > kDirectDepthBesideSparse) {
         depth = kDirectDepthBesideSparse;
         capped = true;
@@ -562,6 +573,27 @@ int rebuild_table(msbwt_rle *h, bool allow_sparse = true) {
             const int again = rebuild_table(h, false);
             h->sparse_report = counted;
             return again;
+        }
+    }
+    // Beside a sparse table the direct table serves the queries SHORTER than that table's entries (and those with '$' / 'N' among their
+    // last symbols).  Capped at packed depth 15 those lose against the index without a sparse table (round 6, human scale, present
+    // k-mers: k = 17 2.5 x, k = 19 1.8 x, k = 21 1.5 x slower than behind the packed depth-17 table) -- so where HBM is plentiful (a
+    // chr20-sized index: 15 GB of 288) the deep direct table is kept AS WELL: nothing is lost for any k.  Not under a memory budget
+    // (the plan has sized the table), and not where it would take the eighth of the device left to the caller's batches.
+    if (capped && h->d_sparse && h->d_table && pack && !h->planned && uncapped_depth + 2 <= 18) {
+        size_t free_b = 0, total_b = 0;
+        const uint64_t flat_deep = (uint64_t(1) << (2 * uncapped_depth)) * 16, need = flat_deep + packed_table_bytes(uncapped_depth + 2) + packed_table_bytes(uncapped_depth + 2) / 8;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && uint64_t(free_b) + h->table_bytes >= need + uint64_t(total_b) / 8) {
+            if (h->d_filter) (void)hipFree(h->d_filter);
+            h->d_filter = nullptr;
+            h->filter_depth = 0;
+            (void)hipFree(h->d_table);
+            h->d_table = nullptr;
+            h->table_depth = 0;
+            h->table_bytes = 0;
+            depth = uncapped_depth;
+            rc = build_flat(depth);
+            if (rc) return rc;
         }
     }
     if (!h->d_table || !pack) return rc;
@@ -619,7 +651,97 @@ int rebuild_table(msbwt_rle *h, bool allow_sparse = true) {
     h->table_side_bytes = side ? uint64_t(escapes) * 512 : 0;
     h->table_lines = pbytes / 128;
     h->table_escape_lines = escapes;
+    if (h->d_sparse && h->sparse_tier && escapes > 0 && !side) {
+        // the two-tier table sends queries down this table's path, and an escape line without its side entry cannot be followed from
+        // there (the query's first symbols are gone): no room for the side array -> the index as if there were no sparse table
+        const SparseBuildReport counted = h->sparse_report;
+        const int again = rebuild_table(h, false);
+        h->sparse_report = counted;
+        return again;
+    }
     return MSBWT_OK;
+}
+
+int rebuild_pair_index(msbwt_rle *h);
+
+// Run blocks with a sparse table (round 6): the table is built while the PLANE blocks of the load are still in HBM -- temporary pair blocks
+// (stride 128) and a flat parent table beside them, then the usual sizing and fill passes -- and only the table stays: pair blocks and
+// parent are freed again before the planes become run blocks.  Optional: whatever does not fit leaves the index without a sparse table.
+// The caller has made the handle look like a plane-block index (d_blocks = planes, totals, nblocks).
+int build_sparse_for_runs(msbwt_rle *h) {
+    const bool verbose = std::getenv("MSBWT_VERBOSE") != nullptr;
+    if (h->wanted_sparse == 0 || h->totals.total == 0) return MSBWT_OK;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return MSBWT_OK;
+    const PairIndexSizes sz = pair_index_sizes(h->nblocks, 128);
+    const uint64_t run_bytes = run_block_count(h->totals.total) * kBlockBytes, run_peak = run_bytes + run_bytes / 8;  // (what the conversion will need beside the planes)
+    const int parent = std::min(kDirectDepthBesideSparse, std::max(0, auto_flat_table_depth(h->totals.total, h->nblocks * kBlockBytes)));
+    const uint64_t parent_bytes = parent > 0 ? (uint64_t(1) << (2 * parent)) * 16 : 0;
+    if (sz.pair_block_bytes + sz.super_bytes + sz.scratch_bytes + parent_bytes + run_peak > uint64_t(free_b) - uint64_t(free_b) / 32) {
+        if (verbose) std::fprintf(stderr, "[msbwt] run blocks: no room for the temporary pair blocks of a sparse-table build -- none built\n");
+        return h->wanted_sparse > 0 ? fail(h, MSBWT_ERR_HIP, "the sparse table of the requested depth cannot be built: no room for its temporary pair blocks") : MSBWT_OK;
+    }
+    const int saved_pair = h->wanted_pair, saved_stride = h->wanted_pair_stride;
+    const bool saved_planned = h->planned;
+    h->wanted_pair = 1;
+    h->wanted_pair_stride = 128;
+    h->planned = false;
+    int rc = rebuild_pair_index(h);
+    h->wanted_pair = saved_pair;
+    h->wanted_pair_stride = saved_stride;
+    h->planned = saved_planned;
+    auto drop_temps = [&]() {
+        if (h->d_table) (void)hipFree(h->d_table);
+        h->d_table = nullptr;
+        h->table_depth = 0;
+        h->table_bytes = 0;
+        h->table_packed = false;
+        if (h->d_filter) (void)hipFree(h->d_filter);
+        h->d_filter = nullptr;
+        h->filter_depth = 0;
+        if (h->d_pair_blocks) (void)hipFree(h->d_pair_blocks);
+        if (h->d_pair_super) (void)hipFree(h->d_pair_super);
+        h->d_pair_blocks = h->d_pair_super = nullptr;
+        h->pair_bytes = 0;
+        h->pair_overlap_bytes = 0;
+        h->pair_stride = 128;
+    };
+    if (rc || !h->d_pair_blocks) {
+        drop_temps();
+        (void)hipGetLastError();
+        if (h->wanted_sparse > 0) return rc ? rc : fail(h, MSBWT_ERR_HIP, "the sparse table of the requested depth cannot be built: no pair blocks");
+        h->err.clear();
+        return MSBWT_OK;
+    }
+    if (parent > 0) {
+        void *tab = nullptr;
+        hipError_t e = hipMalloc(&tab, parent_bytes);
+        if (e == hipSuccess) e = launch_build_table(view_of(h), parent, tab, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) {
+            if (tab) (void)hipFree(tab);
+            (void)hipGetLastError();
+            tab = nullptr;
+        }
+        h->d_table = tab;
+        h->table_depth = tab ? parent : 0;
+        h->table_bytes = tab ? parent_bytes : 0;
+        h->table_packed = false;
+    }
+    // what the budget leaves once the run blocks and their (flat) direct table are paid for; the conversion's peak stays free
+    uint64_t allowance = kNoBudget;
+    if (h->memory_budget) {
+        const uint64_t held = run_peak + parent_bytes;
+        allowance = h->memory_budget > held ? h->memory_budget - held : 0;
+    }
+    rc = build_sparse(h, run_peak, allowance);
+    drop_temps();
+    if (rc && h->wanted_sparse <= 0) {
+        release_sparse(h);
+        h->err.clear();
+        rc = MSBWT_OK;
+    }
+    return rc;
 }
 
 // A memory budget (msbwt_rle_set_memory_budget) turns the automatic choices into ONE plan, made once the plane blocks are in
@@ -804,6 +926,15 @@ int build_on_device(msbwt_rle *h, const uint8_t *rle, size_t n, Totals *t_out, b
 // built on the host and uploaded.
 int build_run_index(msbwt_rle *h, const uint8_t *rle, size_t n, Totals *t_out) {
     const char *mode = std::getenv("MSBWT_BUILD");
+    auto sparse_while_planes = [&]() -> int {  // (the planes are in h->d_blocks: the handle looks like a plane-block index for a moment)
+        if (h->wanted_sparse == 0) return MSBWT_OK;
+        h->block_format = kBlocksPlanes;
+        h->totals = *t_out;
+        h->nblocks = plane_block_count(t_out->total);
+        const int rc = build_sparse_for_runs(h);
+        h->block_format = kBlocksRuns;
+        return rc;
+    };
     // The device path holds the plane blocks (0.5 byte per symbol), the RLE bytes and its scratch for a moment, and then the run
     // blocks beside the planes: about 0.8 byte per symbol at its peak against 0.3 for the finished index.  An index whose planes do
     // not fit beside its runs is built on the host instead (as until round 3) -- decided beforehand from the free HBM where the totals
@@ -819,6 +950,8 @@ int build_run_index(msbwt_rle *h, const uint8_t *rle, size_t n, Totals *t_out) {
         }
     }
     if (on_device) {
+        const int rcs = sparse_while_planes();
+        if (rcs) return rcs;
         void *planes = h->d_blocks;
         h->d_blocks = nullptr;
         const uint64_t nplanes = plane_block_count(t_out->total), nruns = run_block_count(t_out->total);
@@ -1103,6 +1236,7 @@ msbwt_rle *msbwt_rle_new_on_device(uint8_t bin_power, int device) {
         const int d = std::strcmp(env, "auto") == 0 ? -1 : std::atoi(env);
         h->wanted_sparse = (d == 0 || d == -1 || (d >= kSparseMinDepth && d <= kSparseMaxDepth)) ? d : -1;
     }
+    if (const char *env = std::getenv("MSBWT_SPARSE_TIERS")) h->wanted_tiers = std::strcmp(env, "auto") == 0 ? -1 : (std::atoi(env) ? 1 : 0);
     if (const char *env = std::getenv("MSBWT_PAIR_INDEX")) h->wanted_pair = std::atoi(env) ? 1 : 0;
     if (const char *env = std::getenv("MSBWT_PAIR_STRIDE")) h->wanted_pair_stride = std::atoi(env);
     if (const char *env = std::getenv("MSBWT_FILTER")) h->wanted_filter = std::atoi(env) ? -1 : 0;
@@ -1575,6 +1709,7 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
     h->wanted_table_packed = src->wanted_table_packed;
     h->wanted_table_side = src->wanted_table_side;
     h->wanted_sparse = src->wanted_sparse;
+    h->wanted_tiers = src->wanted_tiers;
     h->query_length = src->query_length;
     h->wanted_streaming = src->wanted_streaming;
     h->wanted_block_format = src->wanted_block_format;
@@ -1643,6 +1778,7 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
     h->sparse_nbuckets = src->sparse_nbuckets;
     h->sparse_probe = src->sparse_probe;
     h->sparse_depth = src->sparse_depth;
+    h->sparse_tier = src->sparse_tier;
     h->sparse_report = src->sparse_report;
     h->typical_width = src->typical_width;
     h->pair_overlap_bytes = src->pair_overlap_bytes;
@@ -2045,17 +2181,34 @@ int msbwt_rle_set_sparse_table(msbwt_rle *h, int depth) {
     if (!h->loaded) return MSBWT_OK;
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    if (h->block_format != kBlocksPlanes) {  // run blocks: the table is built at load time only (from plane blocks that are gone); 0 drops it now
+        if (depth == 0) release_sparse(h);
+        return MSBWT_OK;
+    }
     return rebuild_table(h);
 }
 
-int msbwt_rle_get_sparse_table(const msbwt_rle *h) { return (h && h->d_sparse && h->d_pair_blocks) ? h->sparse_depth : 0; }
+int msbwt_rle_get_sparse_table(const msbwt_rle *h) { return (h && h->d_sparse) ? h->sparse_depth : 0; }
+
+int msbwt_rle_set_sparse_tiers(msbwt_rle *h, int mode) {
+    if (!h || mode < -1 || mode > 1) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    const bool changes = mode != h->wanted_tiers;
+    h->wanted_tiers = mode;
+    if (!h->loaded || !changes || h->wanted_sparse == 0 || h->block_format != kBlocksPlanes) return MSBWT_OK;  // (run blocks: at the next load)
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    return rebuild_table(h);
+}
+
+int msbwt_rle_get_sparse_tiers(const msbwt_rle *h) { return (h && h->d_sparse && h->sparse_tier) ? 1 : 0; }
 
 int msbwt_rle_set_query_length(msbwt_rle *h, int k) {
     if (!h || k < 0) return MSBWT_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
     const bool changes = sparse_auto_max_depth(k) != sparse_auto_max_depth(h->query_length);
     h->query_length = k;
-    if (!h->loaded || !changes || h->wanted_sparse >= 0) return MSBWT_OK;  // (an explicit depth, or none at all, does not follow the hint)
+    if (!h->loaded || !changes || h->wanted_sparse >= 0 || h->block_format != kBlocksPlanes) return MSBWT_OK;  // (an explicit depth, or none at all, does not follow the hint; run blocks: at the next load)
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
     return rebuild_table(h);
@@ -2079,12 +2232,15 @@ int msbwt_rle_sparse_table_info(const msbwt_rle *ch, uint64_t *out) {
         out[4] = r.nescapes;
         out[5] = h->sparse_side_bytes;
         out[6] = r.displaced;
+        out[8] = h->sparse_tier ? 1 : 0;
         out[9] = h->sparse_probe;
+        out[42] = r.filtered;
     }
     out[7] = uint64_t(r.parent_depth);
     for (int d = 0; d <= kSparseMaxDepth; ++d) {
         out[10 + d] = r.distinct[d];
         out[45 + d] = r.escapes[d];
+        out[80 + d] = r.singles[d];
     }
     return MSBWT_OK;
 }
@@ -2110,6 +2266,25 @@ int msbwt_auto_sparse_depth(const uint64_t *distinct, const uint64_t *wide, int 
     const SparseChoice c = choose_sparse_depth(distinct, wide, parent_depth, sparse_auto_max_depth(query_length), avail_bytes, 0);
     *depth = c.depth;
     if (table_bytes) *table_bytes = c.bytes;
+    return MSBWT_OK;
+}
+
+int msbwt_auto_sparse_choice(const uint64_t *distinct, const uint64_t *wide, const uint64_t *singles, int parent_depth, uint64_t avail_bytes, int query_length,
+                             int tiers, int *depth, int *two_tier, uint64_t *table_bytes) {
+    if (!distinct || !wide || !singles || !depth || !two_tier || parent_depth < 0 || parent_depth > 16 || query_length < 0 || tiers < -1 || tiers > 1)
+        return MSBWT_ERR_INVALID_ARG;
+    const SparseChoice c = choose_sparse_depth(distinct, wide, parent_depth, sparse_auto_max_depth(query_length), avail_bytes, 0, singles, tiers);
+    *depth = c.depth;
+    *two_tier = c.tier ? 1 : 0;
+    if (table_bytes) *table_bytes = c.bytes;
+    return MSBWT_OK;
+}
+
+int msbwt_sparse_filter_bits(uint64_t tag, uint32_t *word, uint32_t *mask) {
+    if (!word || !mask) return MSBWT_ERR_INVALID_ARG;
+    const uint32_t f = sparse_filter_hash(uint32_t(tag));
+    *word = sparse_filter_word(f);
+    *mask = sparse_filter_mask(f);
     return MSBWT_OK;
 }
 

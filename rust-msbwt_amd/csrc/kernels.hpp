@@ -71,7 +71,8 @@ struct IndexView {
 };
 
 inline bool sparse_serves(const IndexView &ix, uint32_t k) {
-    return ix.sparse.lines != nullptr && ix.pair_blocks != nullptr && ix.block_format == kBlocksPlanes && k >= ix.sparse.depth;
+    // (beside a pair index, or -- round 6 -- on run blocks, whose table was built from pair blocks that are gone again)
+    return ix.sparse.lines != nullptr && (ix.pair_blocks != nullptr || ix.block_format == kBlocksRuns) && k >= ix.sparse.depth;
 }
 
 // indices into IndexView::counters
@@ -90,6 +91,7 @@ enum SearchCounter {
     kCntTableDisplaced,    // ... of which did not find the key in a bucket that had displaced entries (the lookup went on)
     kCntTableRides,        // ... of which rode along with the search of the tile before (no search step of their own)
     kCntWavesWorked,       // waves of the persistent kernel that were dealt at least one tile (a workgroup that became resident late finds none)
+    kCntTierFallbacks,     // two-tier sparse table: lookups that ended in the filter and went on through the direct table
     kSearchCounters = 16
 };
 

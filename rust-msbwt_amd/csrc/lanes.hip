@@ -82,20 +82,18 @@ constexpr bool kCounting = true;
 // One undecided query waiting in the ring: 24 bytes (k <= 32) or 36 (k <= 64).  The ring only ever holds
 // queries of ONE tile (it is refilled when empty), so the tile index is a wave-uniform register, not a field.
 // kPlaced (the instantiations for packed queries, which may come with a place for every count): 4 bytes more.
-template <int kWords, bool kPlaced>
+// kTier (the instantiations for the two-tier sparse table): 4 bytes more -- the query's index into the DIRECT table, should its lookup
+// end in the filter.
+template <int kWords, bool kPlaced, bool kTier>
 struct RingItemT {
     uint32_t l_lo, h_lo;
     uint32_t meta;        // l >> 32 (8 bits) | h >> 32 (8 bits) << 8 | remaining steps << 16 | lane in the tile << 24
     uint32_t w[kWords];   // remaining symbols, 3 bits each, next step in the low bits
-};
-template <int kWords>
-struct RingItemT<kWords, true> {
-    uint32_t l_lo, h_lo, meta;
-    uint32_t w[kWords];
-    uint32_t out;         // QuerySource::out_index / place_inline: where the count goes (else unused: tile and lane say it)
+    uint32_t extra[(kPlaced ? 1 : 0) + (kTier ? 1 : 0)];  // [0] kPlaced: QuerySource::out_index / place_inline, where the count goes; [last] kTier: direct-table index
+    static constexpr int kOutAt = 0, kDkeyAt = kPlaced ? 1 : 0;
 };
 
-template <int kWords, bool kPlaced>
+template <int kWords, bool kPlaced, bool kTier = false>
 struct LaneScratchT {
     static constexpr int kMaxK = kWords * 32 / 3;  // 32 or 64
     static constexpr int kRegions = kRegionsFor<kWords>;
@@ -110,10 +108,11 @@ struct LaneScratchT {
     // symbol codes), and at the start of a step its first 640 bytes hold the step's line addresses: they
     // are in registers (s_waitcnt lgkmcnt(0)) before the first LDS-DMA load is issued.
     uint4 lines[(kRegions / 2) * 136];   // 10.6 KiB
-    RingItemT<kWords, kPlaced> ring[kRing];  // 1.5 or 2.25 KiB (+ 256 bytes when kPlaced)
+    RingItemT<kWords, kPlaced, kTier> ring[kRing];  // 1.5 or 2.25 KiB (+ 256 bytes when kPlaced, + 256 when kTier)
     uint32_t cnt[kSearchCounters];       // optional search counters of this wave (kernels.hpp): in LDS, so that they cost no registers
 };
-static_assert(sizeof(LaneScratchT<6, true>) <= 160 * 1024 / 12, "12 one-wave workgroups per CU");
+static_assert(sizeof(LaneScratchT<6, true>) <= 160 * 1024 / 12 && sizeof(LaneScratchT<6, false, true>) <= 160 * 1024 / 12 && sizeof(LaneScratchT<3, true, true>) <= 160 * 1024 / 12,
+              "12 one-wave workgroups per CU (but for packed queries of k > 32 on a two-tier table: 8)");
 
 // uint4 index of the first of region i's 64 sixteen-byte pieces: pairs of regions take 136 pieces,
 // the odd one starting 72 in (64 + 8 of padding)
@@ -373,6 +372,62 @@ __device__ __forceinline__ bool sparse_scan_xwide(const uint4 *lines, uint32_t s
     return false;
 }
 
+// The TWO-TIER forms (sparse_table.hpp): 10 entries with 24-bit tags or 9 with 32-bit tags, the bucket's header in bytes 90..91 and eight
+// filter words behind it.  -> also `maybe`: the four filter bits of this key are all set in THIS bucket's filter (meaningful in the key's
+// own bucket: a suffix that occurs once has no entry anywhere, only those bits).
+__device__ __forceinline__ bool sparse_scan_tier(const uint4 *lines, uint32_t slot, uint32_t want, bool wide_layout, uint64_t &l, uint32_t &width, uint32_t &header, bool &maybe) {
+    const uint32_t base = line_base(slot), g = slot & 7u;
+    const uint4 c0 = lines[base + (0u ^ g)], c1 = lines[base + (1u ^ g)], c2 = lines[base + (2u ^ g)];
+    const uint32_t tags[kTierSlots] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y};
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(lines);
+    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(lines);
+    auto word_at = [&](uint32_t w) -> uint32_t { return words[(base + ((w >> 2) ^ g)) * 4u + (w & 3u)]; };
+    auto byte_at = [&](uint32_t b) -> uint32_t { return bytes[(base + ((b >> 4) ^ g)) * 16u + (b & 15u)]; };
+    const uint32_t nslots = wide_layout ? kTierWideSlots : kTierSlots, tag_mask = wide_layout ? ~0u : ((1u << kSparseTagBits) - 1u);
+    uint32_t hit = kTierSlots;
+#pragma unroll
+    for (int i = int(kTierSlots) - 1; i >= 0; --i) hit = ((tags[i] & tag_mask) == want && uint32_t(i) < nslots) ? uint32_t(i) : hit;  // the lowest matching slot
+    header = word_at(kTierHeaderByte / 4u) >> 16;
+    const uint32_t f = sparse_filter_hash(want), m = sparse_filter_mask(f);
+    maybe = (word_at(kTierFilterWord + sparse_filter_word(f)) & m) == m;
+    width = 0;
+    if (hit >= nslots) return false;
+    width = wide_layout ? byte_at(kTierWideWidthByte + hit) : (word_at(hit) >> kSparseTagBits);
+    if (width == 0u) return false;  // an empty slot (a key whose tag is 0 matches it)
+    const uint32_t lo = word_at((wide_layout ? kTierWideL0Word : kTierL0Word) + hit), hi = byte_at((wide_layout ? kTierWideHiByte : kTierHiByte) + hit);
+    l = (uint64_t(hi) << 32) | lo;
+    return true;
+}
+
+// (the k > 32 instantiations sit at their register limit: they take the two-tier scan as a call too)
+struct TierScanOut {
+    uint64_t l;
+    uint32_t width, header, hit, maybe;
+};
+__device__ __attribute__((noinline)) TierScanOut sparse_scan_tier_call(const uint4 *lines, uint32_t slot, uint32_t want, bool wide_layout) {  // (results by value: no stack)
+    TierScanOut o{0, 0, 0, 0, 0};
+    bool maybe = false;
+    o.hit = sparse_scan_tier(lines, slot, want, wide_layout, o.l, o.width, o.header, maybe) ? 1u : 0u;
+    o.maybe = maybe ? 1u : 0u;
+    return o;
+}
+
+// drops a WAVE-UNIFORM number of bits (0..95) of the packed symbols: whole words by selects, the rest by alignbit
+template <int kWords>
+__device__ __forceinline__ void consume_symbols_uniform(uint32_t (&w)[kWords], uint32_t bits) {
+    const uint32_t whole = bits >> 5, rest = bits & 31u;
+    uint32_t t[kWords + 1];
+#pragma unroll
+    for (int i = 0; i < kWords; ++i) {
+        t[i] = 0u;
+#pragma unroll
+        for (int j = i; j < kWords; ++j) t[i] = (uint32_t(i) + whole == uint32_t(j)) ? w[j] : t[i];
+    }
+    t[kWords] = 0u;
+#pragma unroll
+    for (int i = 0; i < kWords; ++i) w[i] = __builtin_amdgcn_alignbit(t[i + 1], t[i], rest);
+}
+
 // (the k > 32 instantiations sit at their register limit: they take the xwide scan as a call, not inlined)
 struct SparseScanOut {
     uint64_t l;
@@ -392,7 +447,11 @@ __device__ __attribute__((noinline)) SparseScanOut sparse_scan_xwide_call(const 
 // `table` = its bucket lines, `depth` = its depth, `table_side` = its side array.  A lookup is a search step of its own kind: the
 // lane's line is its key's bucket, fetched with the other lanes' lines, and the lane finds its entry among the line's 14 tags.
 // A compile-time switch for the same reason as kPacked -- and so that the direct-table kernels carry none of it.
-template <bool kReads, bool kPair, int kWords, bool kStride96, bool kPacked, bool kSparse>
+// kSparse = 2: the table is of the TWO-TIER form (entries for the suffixes at least 2 wide, filter bits for the ones that occur once):
+// a lookup that ends in the filter goes on through the DIRECT table (`dtable`: its line is the query's next step, decoded by the lane)
+// and searches from there -- the complete-table kernels (kSparse = 1) carry none of that.
+// kPair = false with kSparse (round 6): run blocks behind a sparse table -- the post-lookup steps are single-symbol steps.
+template <bool kReads, bool kPair, int kWords, bool kStride96, bool kPacked, int kSparse>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_count_kmers_lanes(const uint4 *__restrict__ blocks, uint64_t total,
                                                           const uint4 *__restrict__ table, uint32_t depth, uint32_t table_packed,
                                                           const uint32_t *__restrict__ filter, uint32_t filter_mask,
@@ -402,14 +461,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                                                           unsigned long long *__restrict__ tile_counter, uint32_t grain,
                                                           uint64_t *__restrict__ done, uint64_t done_seq, uint64_t *__restrict__ counters,
                                                           uint32_t format, const uint4 *__restrict__ run_overflow, uint32_t sparse_nbuckets,
-                                                          uint32_t sparse_probe) {
+                                                          uint32_t sparse_probe, const uint4 *__restrict__ dtable, uint32_t dinfo,
+                                                          const uint4 *__restrict__ dside) {
     static_assert(!(kReads && kPacked), "packed queries are a matrix-mode input");
-    static_assert(!kSparse || kPair, "the sparse table continues with pair steps");
-    using Scratch = LaneScratchT<kWords, kPacked>;
+    static_assert(kSparse >= 0 && kSparse <= 2, "0 = direct table, 1 = complete sparse table, 2 = two-tier sparse table");
+    constexpr bool kTier = kSparse == 2;
+    using Scratch = LaneScratchT<kWords, kPacked, kTier>;
     // run blocks (run_index.hpp; launch-uniform): `blocks` are 128-byte lines of 512 positions with 96 one-byte runs, decoded
     // by the lane that owns the query; single-symbol steps only (the kPair instantiations never see them)
     const bool runs = !kPair && !kPacked && format != 0u;  // (round 5: k <= 64 -- the long instantiation fits the decode after all: 163 / 168 VGPRs, no spill)
-    using RingItem = RingItemT<kWords, kPacked>;
+    using RingItem = RingItemT<kWords, kPacked, kTier>;
     constexpr int kPieces = Scratch::kMaxK / 16;  // 16-byte pieces of a tile per lane: 2 or 4
     constexpr int kRegions = Scratch::kRegions, kLineSlots = Scratch::kLineSlots;
     constexpr uint32_t kMaxSecond = Scratch::kMaxSecond;
@@ -429,9 +490,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     const bool stream_lines = (table_packed & 2u) != 0u;
     // the sparse table's layout follows its depth (launch-uniform): 14 entries with 24-bit tags up to depth 24, 12 with 32-bit tags beyond
     const bool sparse_wide_layout = kSparse && sparse_wide(depth);
-    const uint32_t sparse_nslots = sparse_slots(depth);
-    const bool sparse_xwide_layout = kSparse && sparse_xwide(depth);
-    auto scan_bucket = [&](uint32_t slot, uint64_t want, uint64_t &tl, uint32_t &tw, uint32_t &header) -> bool {  // want: the tag, up to 40 bits
+    const uint32_t sparse_nslots = sparse_slots(depth, kTier);
+    const bool sparse_xwide_layout = kSparse && !kTier && sparse_xwide(depth);
+    // two-tier: the direct table a lookup falls back to -- dd symbols deep (0: none, such a query searches from [0, total)), packed or flat
+    const uint32_t dd = kTier ? (dinfo & 0xFFu) : 0u;
+    const bool dpacked = kTier && ((dinfo >> 8) & 1u) != 0u;
+    const uint32_t dkey_mask = dd >= 16u ? ~0u : ((1u << (2u * dd)) - 1u);
+    auto scan_bucket = [&](uint32_t slot, uint64_t want, uint64_t &tl, uint32_t &tw, uint32_t &header, bool &maybe) -> bool {  // want: the tag, up to 40 bits
+        maybe = false;
+        if constexpr (kTier && kWords == 6) {
+            const TierScanOut o = sparse_scan_tier_call(ws.lines, slot, uint32_t(want), sparse_wide_layout);
+            tl = o.hit ? o.l : tl;
+            tw = o.width;
+            header = o.header;
+            maybe = o.maybe != 0u;
+            return o.hit != 0u;
+        } else if constexpr (kTier) {
+            return sparse_scan_tier(ws.lines, slot, uint32_t(want), sparse_wide_layout, tl, tw, header, maybe);
+        }
         if (sparse_xwide_layout) {
             if constexpr (kWords == 6) {
                 const SparseScanOut o = sparse_scan_xwide_call(ws.lines, slot, want);
@@ -498,6 +574,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     bool have = false;
     bool tmode = false;   // kSparse: the query is still to be looked up -- l = its bucket, h = its tag, the next step fetches the bucket line
     uint32_t tdist = 0;   // ... and how many buckets beyond its own the lookup has gone
+    bool tmaybe = false;  // kTier: ... and its own bucket's filter holds its bits (l >> 32 = its index into the direct table meanwhile)
+    bool dmode = false;   // kTier: the lookup ended in the filter -- l = the query's line of the DIRECT table, h = its slot there, fetched by the next step
     uint32_t ovf_l = 0, ovf_h = 0;  // run blocks: 1 + the overflow plane block this bound is to be ranked from (0: its run block)
     uint64_t l = 0, h = 0;
     uint32_t w[kWords], rem = 0;
@@ -607,7 +685,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             if (kSparse && prep_kind == 3u) {  // not looked up on the way (no free slot, a short search before it): its bucket is its first step
                 pl = prep_entry.x;  // bucket
                 ph = prep_entry.y;  // tag
-                skip = depth;
+                skip = kTier ? dd : depth;  // (two-tier: the symbols beyond the DIRECT table's stay until the lookup has hit)
+                lookup = true;
+            }
+            if (kTier && prep_kind == 5u) {  // its lookup rode along and ended in the filter: the direct table's line is its first step
+                pl = dpacked ? prep_entry.w / kPackedPerLine : (prep_entry.w >> 3);
+                ph = dpacked ? prep_entry.w - uint32_t(pl) * kPackedPerLine : (prep_entry.w & 7u);
+                skip = dd;
                 lookup = true;
             }
             if (kSparse && prep_kind == 4u) {  // looked up while the tile before it was searched (step D): l, width
@@ -657,10 +741,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 it.l_lo = uint32_t(pl);
                 it.h_lo = uint32_t(ph);
                 it.meta = uint32_t(pl >> 32) | (uint32_t(ph >> 32) << 8) | (prep_rem << 16) | (lane << 24);  // l, h < 2^40; rem <= 64
-                if (kSparse && lookup) it.meta = prep_entry.z | (prep_rem << 16) | (lane << 24) | (1u << 23);  // (z: buckets gone beyond its own so far, and the tag's high byte)
+                if (kSparse && lookup) it.meta = prep_entry.z | (prep_rem << 16) | (lane << 24) | (1u << 23);  // (z: buckets gone beyond its own so far, and the tag's high byte -- two-tier: bit 8 = direct-table lookup, bit 9 = in the filter)
 #pragma unroll
                 for (int i = 0; i < kWords; ++i) it.w[i] = prep_w[i];
-                if constexpr (kPacked) it.out = prep_out;
+                if constexpr (kPacked) it.extra[RingItem::kOutAt] = prep_out;
+                if constexpr (kTier) it.extra[RingItem::kDkeyAt] = prep_entry.w;
                 ws.ring[(ring_head + ring_count + at) & (kRing - 1)] = it;
             }
             ring_tile = prep_tile;  // the ring was empty: everything in it belongs to this tile
@@ -687,8 +772,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                     l = it.l_lo;
                     h = (uint64_t((it.meta >> 8) & 0xFFu) << 32) | it.h_lo;  // the tag (40 bits in the xwide layout)
                 }
+                if constexpr (kTier) {
+                    dmode = tmode && ((it.meta >> 8) & 1u) != 0u;
+                    tmaybe = tmode && ((it.meta >> 9) & 1u) != 0u;
+                    if (tmode) {
+                        h = it.h_lo;  // the tag (at most 32 bits), or the slot in the direct table's line
+                        l = dmode ? uint64_t(it.l_lo) : (uint64_t(it.extra[RingItem::kDkeyAt]) << 32) | it.l_lo;
+                        tmode = !dmode;
+                    }
+                }
                 qid = ring_tile * kTile + (it.meta >> 24);
-                if constexpr (kPacked) qid = place_of(qid, it.out);
+                if constexpr (kPacked) qid = place_of(qid, it.extra[RingItem::kOutAt]);
                 ovf_l = ovf_h = 0u;
                 have = true;
             }
@@ -698,7 +792,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
         }
         // a range outside the index would turn into a wild line address: end such a query with
         // u64::MAX and a status flag instead (never seen on a well-formed index; cheap insurance)
-        const bool broken = have && !(kSparse && tmode) && (h > total || l > h);
+        const bool broken = have && !(kSparse && tmode) && !(kTier && dmode) && (h > total || l > h);
         if (broken) {
             atomicOr(flags, kFlagInternal);
             if (debug != nullptr && atomicCAS(reinterpret_cast<unsigned long long *>(debug), 0ull, 1ull) == 0ull) {
@@ -784,6 +878,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                             prep_entry.x = sparse_bucket(x, 2u * depth, sparse_nbuckets);
                             prep_entry.y = sparse_tag(x, depth);
                             prep_entry.z = sparse_tag_hi(x, depth) << 8;  // low byte: buckets gone beyond its own; next byte: bits 32..39 of the tag (xwide layout; else 0)
+                            if constexpr (kTier) prep_entry.w = uint32_t(pq.tidx) & dkey_mask;  // where the direct table keeps this query's suffix
                             prep_kind = 3;
                         } else {
                             prep_entry = table_fetch(env, pq.tidx);  // stays in flight: consumed in step A of a later iteration
@@ -824,7 +919,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
         // ---- D: one search step of every busy lane ----
         const uint32_t s1 = w[0] & 7u, s2 = (w[0] >> 3) & 7u;
         const bool looking = kSparse && have && tmode;  // this step fetches the query's bucket of the sparse table
-        const bool pair = kPair && have && !looking && rem >= 2u && (acgt_bit(s1) & acgt_bit(s2)) != 0u;
+        const bool dlooking = kTier && have && dmode;   // ... its line of the direct table (two-tier: the lookup ended in the filter)
+        const bool pair = kPair && have && !looking && !dlooking && rem >= 2u && (acgt_bit(s1) & acgt_bit(s2)) != 0u;
         const uint32_t a2 = acgt_code(s1) & 3u, b2 = acgt_code(s2) & 3u;
         constexpr bool s96 = kStride96;  // compile-time: the stride-128 kernel carries no division
         const uint64_t base = pair ? reinterpret_cast<uint64_t>(pair_blocks) : reinterpret_cast<uint64_t>(blocks);
@@ -847,7 +943,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             one_line = line_l == line_h;
         }
         if (kSparse && looking) {
-            line_l = reinterpret_cast<uint64_t>(table) + l * 128u;
+            line_l = reinterpret_cast<uint64_t>(table) + uint64_t(kTier ? uint32_t(l) : l) * 128u;
+            one_line = true;
+        }
+        if (kTier && dlooking) {
+            line_l = reinterpret_cast<uint64_t>(dtable) + l * 128u;
             one_line = true;
         }
         const bool second = have && !one_line;
@@ -917,7 +1017,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             count(kCntSecondLines, __ballot(act && second));
             count(kCntSatOut, __ballot(have && !act));
             if (kSparse) {
-                count(kCntTableSteps, __ballot(act && looking) );
+                count(kCntTableSteps, __ballot(act && (looking || dlooking)));
                 count(kCntTableSteps, __ballot(riding));
                 count(kCntFirstLines, __ballot(riding));
                 count(kCntTableRides, __ballot(riding));
@@ -927,13 +1027,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             if (riding) {
                 uint64_t tl = 0;
                 uint32_t tw = 0, header = 0;
-                if (scan_bucket(slot_ride, (uint64_t((prep_entry.z >> 8) & 0xFFu) << 32) | prep_entry.y, tl, tw, header)) {
+                bool maybe = false;
+                const bool hit = scan_bucket(slot_ride, kTier ? uint64_t(prep_entry.y) : ((uint64_t((prep_entry.z >> 8) & 0xFFu) << 32) | prep_entry.y), tl, tw, header, maybe);
+                if (kTier && !hit && (prep_entry.z & 0xFFu) == 0u && maybe) prep_entry.z |= 1u << 9;  // its own bucket's filter holds its bits
+                if (hit) {
                     prep_entry.x = uint32_t(tl);
                     prep_entry.y = uint32_t(tl >> 32) | (tw << 8);
                     prep_kind = 4;
                 } else if (header > sparse_nslots && (prep_entry.z & 0xFFu) < sparse_probe) {  // entries of this bucket were displaced: the next one, next time
                     ++prep_entry.x;
                     ++prep_entry.z;
+                } else if (kTier && ((prep_entry.z >> 9) & 1u) != 0u) {  // no entry, but the filter knows it (occurs once, or a false positive): the direct table's path
+                    prep_entry.z |= 1u << 8;
+                    prep_kind = dd != 0u ? 5u : 2u;  // (no direct table: from [0, total))
                 } else {  // a miss in a complete table: the suffix does not occur (msbwt_core.rs:151-153)
                     store_count<kReads>(src, place_of(prep_tile * kTile + lane, prep_out), 0ull);
                     prep_kind = 0;
@@ -942,6 +1048,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             if (counting) {
                 count(kCntTableDisplaced, __ballot(riding && prep_kind == 3u));
                 count(kCntTableDecided, __ballot(riding && prep_kind == 0u));
+                if (kTier) count(kCntTierFallbacks, __ballot(riding && (prep_kind == 5u || prep_kind == 2u)));
             }
         }
         if (act) {
@@ -950,10 +1057,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
             if (kSparse && looking) {  // this step fetched the query's own bucket
                 uint64_t tl = 0;
                 uint32_t width = 0, header = 0;
-                const bool hit = scan_bucket(slot_l, h, tl, width, header);
+                bool maybe = false;
+                const bool hit = scan_bucket(slot_l, h, tl, width, header, maybe);
+                if (kTier && !hit && tdist == 0u && maybe) tmaybe = true;  // its own bucket's filter holds its bits
+                bool fell = false;
                 nl = nh = 0;
                 step_done = false;
                 if (hit) {
+                    if constexpr (kTier) {  // the symbols between the direct table's depth and this table's are answered now
+                        consume_symbols_uniform<kWords>(w, 3u * (depth - dd));
+                        rem -= depth - dd;
+                    }
                     l = tl;
                     h = tl + width;
                     if (width == kSparseEscapeWidth) {  // a high-copy suffix: its range is a flat entry of the side array, one more line
@@ -969,6 +1083,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 } else if (header > sparse_nslots && tdist < sparse_probe) {  // entries of this bucket were displaced: the next one
                     ++l;
                     ++tdist;
+                } else if (kTier && tmaybe) {  // no entry, but the filter knows it (occurs once, or a false positive): the direct table's path
+                    const uint32_t dkey = uint32_t(l >> 32);
+                    tmode = false;
+                    fell = true;
+                    if (dd != 0u) {
+                        dmode = true;
+                        l = dpacked ? dkey / kPackedPerLine : (dkey >> 3);
+                        h = dpacked ? dkey - uint32_t(l) * kPackedPerLine : (dkey & 7u);
+                    } else {  // no direct table: from [0, total) (w and rem were never cut)
+                        l = 0;
+                        h = total;
+                    }
                 } else {  // a miss in a complete table: the suffix does not occur (msbwt_core.rs:151-153)
                     store_count<kReads>(src, qid, 0ull);
                     have = false;
@@ -976,8 +1102,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 if (counting) {
                     count(kCntEscapeQueries, __ballot(hit && width == kSparseEscapeWidth));
                     count(kCntFirstLines, __ballot(hit && width == kSparseEscapeWidth));
-                    count(kCntTableDisplaced, __ballot(!hit && have));
+                    count(kCntTableDisplaced, __ballot(!hit && have && !fell));
                     count(kCntTableDecided, __ballot(!hit && !have));
+                    if (kTier) count(kCntTierFallbacks, __ballot(fell));
+                }
+            } else if (kTier && dlooking) {  // this step fetched the query's line of the direct table: its range after dd symbols
+                const uint32_t base_d = line_base(slot_l), g_d = slot_l & 7u, dslot = uint32_t(h);
+                const uint32_t *lw = reinterpret_cast<const uint32_t *>(ws.lines);
+                bool esc = false;
+                nl = nh = 0;
+                step_done = false;
+                if (dpacked) {  // u64 base | 30 x { l - base : 16, h - l : 16 } (search_common.hpp)
+                    const uint4 c0 = ws.lines[base_d + (0u ^ g_d)];
+                    const uint64_t b = (uint64_t(c0.y) << 32) | c0.x;
+                    const uint32_t word = 2u + dslot, e = lw[(base_d + ((word >> 2) ^ g_d)) * 4u + (word & 3u)];
+                    esc = (b & kPackedEscape) != 0ull;
+                    l = esc ? (b & ~kPackedEscape) * kSidePerLine + dslot : b + (e & 0xFFFFu);
+                    h = l + (e >> 16);
+                } else {  // flat: eight {l, h} entries per line
+                    const uint4 e = ws.lines[base_d + (dslot ^ g_d)];
+                    l = (uint64_t(e.y) << 32) | e.x;
+                    h = (uint64_t(e.w) << 32) | e.z;
+                }
+                if (esc) {  // an escape line (the suffixes of a high-copy repeat): its flat entry in the direct table's side array, one more line
+                    const uint4 e = dside[l];
+                    l = (uint64_t(e.y) << 32) | e.x;
+                    h = (uint64_t(e.w) << 32) | e.z;
+                }
+                dmode = false;
+                if (l == h) {  // the filter's false positive (or an absent k-mer that shares its bits): nothing occurs
+                    store_count<kReads>(src, qid, 0ull);
+                    have = false;
+                }
+                if (counting) {
+                    count(kCntEscapeQueries, __ballot(esc));
+                    count(kCntFirstLines, __ballot(esc));
+                    count(kCntTableDecided, __ballot(!have));
                 }
             } else if (pair) {
                 PairLine L;
@@ -1054,7 +1214,7 @@ constexpr uint64_t kMaxTiles = 1ull << 32;
 
 // The kernel is persistent: the grid is what the device keeps resident -- workgroups per CU
 // (occupancy API: LDS- and VGPR-bound, capped below) x CUs; tiles are dealt out by atomic tickets.
-template <bool kReads, bool kPair, int kWords, bool kStride96, bool kPacked, bool kSparse>
+template <bool kReads, bool kPair, int kWords, bool kStride96, bool kPacked, int kSparse>
 uint32_t resident_waves() {
     static const uint32_t cached = [] {
         int device = 0, cus = 0, per_cu = 0;
@@ -1077,7 +1237,7 @@ uint32_t resident_waves() {
     return cached;
 }
 
-template <bool kReads, bool kPair, int kWords, bool kStride96, bool kPacked, bool kSparse>
+template <bool kReads, bool kPair, int kWords, bool kStride96, bool kPacked, int kSparse>
 hipError_t launch_variant(hipStream_t stream, const IndexView &ix, const QuerySource &src, uint32_t *flags) {
     // (kSparse: the sparse table's lines, depth and side array travel in the direct table's arguments)
     const uint4 *table = static_cast<const uint4 *>(kSparse ? ix.sparse.lines : ix.table.entries);
@@ -1100,20 +1260,32 @@ hipError_t launch_variant(hipStream_t stream, const IndexView &ix, const QuerySo
                        static_cast<const uint4 *>(ix.blocks), ix.total, table, kSparse ? ix.sparse.depth : uint32_t(ix.table.depth), ((!kSparse && ix.table.packed) ? 1u : 0u) | (ix.stream_lines ? 2u : 0u),
                        filter, filter_mask, side, static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags, ix.debug,
                        tickets ? static_cast<unsigned long long *>(ix.tile_counter) : nullptr, grain, waves == 1 ? ix.done : nullptr, ix.done_seq, ix.counters,
-                       uint32_t(ix.block_format), static_cast<const uint4 *>(ix.overflow), ix.sparse.nbuckets, ix.sparse.probe);
+                       uint32_t(ix.block_format), static_cast<const uint4 *>(ix.overflow), ix.sparse.nbuckets, ix.sparse.probe,
+                       // two-tier: the direct table its filter sends queries to (depth | packed << 8), and that table's side array
+                       static_cast<const uint4 *>(kSparse == 2 ? ix.table.entries : nullptr),
+                       kSparse == 2 && ix.table.entries ? (uint32_t(ix.table.depth) & 0xFFu) | (ix.table.packed ? 0x100u : 0u) : 0u,
+                       static_cast<const uint4 *>(kSparse == 2 && ix.table.entries ? ix.table.side : nullptr));
     return hipGetLastError();
+}
+
+template <bool kReads, bool kPacked, int kSparse>
+hipError_t launch_sparse_shape(bool pair, bool longk, hipStream_t stream, const IndexView &ix, const QuerySource &src, uint32_t *flags) {
+    if (!pair) {  // run blocks behind a sparse table: single-symbol steps after the lookup (packed queries never reach run blocks)
+        if constexpr (kPacked) return hipErrorInvalidValue;
+        else return longk ? launch_variant<kReads, false, 6, false, false, kSparse>(stream, ix, src, flags) : launch_variant<kReads, false, 3, false, false, kSparse>(stream, ix, src, flags);
+    }
+    if (ix.pair_stride96) return longk ? launch_variant<kReads, true, 6, true, kPacked, kSparse>(stream, ix, src, flags) : launch_variant<kReads, true, 3, true, kPacked, kSparse>(stream, ix, src, flags);
+    return longk ? launch_variant<kReads, true, 6, false, kPacked, kSparse>(stream, ix, src, flags) : launch_variant<kReads, true, 3, false, kPacked, kSparse>(stream, ix, src, flags);
 }
 
 template <bool kReads, bool kPacked>
 hipError_t launch_shape(bool pair, bool longk, hipStream_t stream, const IndexView &ix, const QuerySource &src, uint32_t *flags) {
-    if (!pair) return longk ? launch_variant<kReads, false, 6, false, kPacked, false>(stream, ix, src, flags) : launch_variant<kReads, false, 3, false, kPacked, false>(stream, ix, src, flags);
     // the sparse table serves every query that is at least as long as its entries (shorter ones: the direct table)
-    if (sparse_serves(ix, src.k)) {
-        if (ix.pair_stride96) return longk ? launch_variant<kReads, true, 6, true, kPacked, true>(stream, ix, src, flags) : launch_variant<kReads, true, 3, true, kPacked, true>(stream, ix, src, flags);
-        return longk ? launch_variant<kReads, true, 6, false, kPacked, true>(stream, ix, src, flags) : launch_variant<kReads, true, 3, false, kPacked, true>(stream, ix, src, flags);
-    }
-    if (ix.pair_stride96) return longk ? launch_variant<kReads, true, 6, true, kPacked, false>(stream, ix, src, flags) : launch_variant<kReads, true, 3, true, kPacked, false>(stream, ix, src, flags);
-    return longk ? launch_variant<kReads, true, 6, false, kPacked, false>(stream, ix, src, flags) : launch_variant<kReads, true, 3, false, kPacked, false>(stream, ix, src, flags);
+    if (sparse_serves(ix, src.k))
+        return ix.sparse.tier ? launch_sparse_shape<kReads, kPacked, 2>(pair, longk, stream, ix, src, flags) : launch_sparse_shape<kReads, kPacked, 1>(pair, longk, stream, ix, src, flags);
+    if (!pair) return longk ? launch_variant<kReads, false, 6, false, kPacked, 0>(stream, ix, src, flags) : launch_variant<kReads, false, 3, false, kPacked, 0>(stream, ix, src, flags);
+    if (ix.pair_stride96) return longk ? launch_variant<kReads, true, 6, true, kPacked, 0>(stream, ix, src, flags) : launch_variant<kReads, true, 3, true, kPacked, 0>(stream, ix, src, flags);
+    return longk ? launch_variant<kReads, true, 6, false, kPacked, 0>(stream, ix, src, flags) : launch_variant<kReads, true, 3, false, kPacked, 0>(stream, ix, src, flags);
 }
 
 }  // namespace

@@ -16,7 +16,10 @@ namespace msbwt {
 struct SparseBuildReport {
     uint64_t distinct[kSparseMaxDepth + 1] = {};  // [d] = non-empty ranges at depth d (0 where the build did not pass)
     uint64_t escapes[kSparseMaxDepth + 1] = {};   // [d] = of which 255 or more wide
+    uint64_t singles[kSparseMaxDepth + 1] = {};   // [d] = of which exactly 1 wide: suffixes that occur once (on reads with errors, mostly error k-mers)
     uint64_t entries = 0, nescapes = 0, displaced = 0, nbuckets = 0;  // of the table that was filled
+    uint64_t filtered = 0;                        // two-tier form: suffixes that went into the filters instead of taking an entry
+    bool tier = false;
     int depth = 0, parent_depth = 0;
 };
 
@@ -30,7 +33,8 @@ hipError_t sparse_count_levels(const IndexView &ix, const void *flat_entries, in
 // Fill pass at `depth` (any depth the sizing pass reached or passed): `lines` (nbuckets x 128 bytes, zeroed here) and `side`
 // (nside = report->escapes[depth] entries of 16 bytes, may be nullptr when 0) are written; d_counts: nbuckets x u32 of scratch.
 // hipErrorInvalidValue when some entry found no slot within `probe` buckets (the caller retries with more buckets).
-hipError_t sparse_fill(const IndexView &ix, const void *flat_entries, int flat_depth, int depth, void *lines, uint64_t nbuckets, uint32_t probe,
+// tier: the two-tier form (sparse_table.hpp) -- ranges 1 wide set filter bits of their own bucket instead of taking an entry.
+hipError_t sparse_fill(const IndexView &ix, const void *flat_entries, int flat_depth, int depth, bool tier, void *lines, uint64_t nbuckets, uint32_t probe,
                        void *side, uint64_t nside, void *d_counts, void *d_work, size_t work_bytes, SparseBuildReport *report, hipStream_t stream);
 
 }  // namespace msbwt

@@ -7,6 +7,8 @@
 // the sizing pass reached (it advances two symbols at a time from the direct table's depth, at most to 23) whose table fits the
 // bytes available, skipping depths whose smallest permissible table (the tags need 2^(2d - 21) buckets) would be more than 16 x
 // larger than its entries need (toy indexes stay small); none fits -> no sparse table (the loader then builds the deep direct table).
+// Round 6: where the complete table of a depth does not fit, its TWO-TIER form (sparse_table.hpp) is tried before the next shallower
+// depth -- entries only for the suffixes that occur at least twice, filter bits for the rest.
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -20,6 +22,7 @@ struct SparseChoice {
     uint64_t nbuckets = 0;    // of the table at that depth
     uint64_t bytes = 0;       // bucket lines + side array
     uint64_t build_bytes = 0; // ... + the slot counters the fill pass needs beside them
+    bool tier = false;        // the two-tier form (sparse_table.hpp): entries for the suffixes at least 2 wide, filter bits for the rest
 };
 
 // How deep the AUTOMATIC table may go, given the k the index will mostly be asked about (msbwt_rle_set_query_length; 0 = unknown).
@@ -35,28 +38,37 @@ inline int sparse_auto_max_depth(int query_length) {
 // distinct[d] / wide[d]: non-empty ranges at depth d and how many of them are 255 or more wide (0 for depths the pass did not reach);
 // parent_depth: the direct table the pass started from; avail: bytes the table (and its build scratch) may take;
 // explicit_depth: 0 = automatic, else exactly that depth or nothing.
-inline SparseChoice choose_sparse_depth(const uint64_t *distinct, const uint64_t *wide, int parent_depth, int max_depth, uint64_t avail, int explicit_depth) {
+// singles[d]: of distinct[d], the suffixes that occur exactly once (nullptr: not counted -- no two-tier form); tiers: -1 = the complete
+// table where it fits, else the two-tier form of the SAME depth where that fits (reads with errors: the complete table follows the error
+// k-mers, the two-tier one the genome), else the next shallower depth; 0 = complete tables only; 1 = two-tier only.
+inline SparseChoice choose_sparse_depth(const uint64_t *distinct, const uint64_t *wide, int parent_depth, int max_depth, uint64_t avail, int explicit_depth,
+                                        const uint64_t *singles = nullptr, int tiers = 0) {
     SparseChoice none;
     for (int d = std::min(max_depth, kSparseMaxDepth); d >= kSparseMinDepth && d > parent_depth; --d) {
         if (explicit_depth ? d != explicit_depth : distinct[d] == 0) continue;  // not a level of the pass (the other parity), or nothing occurs
-        const uint64_t needed = uint64_t(double(distinct[d]) / sparse_load(d)) + 1, nb = sparse_buckets_for(d, distinct[d]);
-        const uint64_t lines = nb + kSparseMaxProbe;
-        if (lines > 0xFFFFFFFFull) continue;
-        // a table that the tags force to be far larger than its entries need is not worth its depth: 16 x for the cheap depths (a toy index
-        // gets a toy table), 4 x for depth 29, whose least size is 69 GB (a human-scale index fills it to 72 % of the aimed load; a
-        // chr20-sized one would fill 7 % and takes depth 27 in 4.3 GB instead)
-        const uint64_t slack = d == 29 ? 4 : 16;
-        if (!explicit_depth && sparse_min_buckets(d) > std::max<uint64_t>(slack * needed, 65536)) continue;
-        SparseChoice c;
-        c.depth = d;
-        c.nbuckets = nb;
-        c.bytes = lines * 128 + wide[d] * 16;
-        c.build_bytes = c.bytes + lines * sizeof(uint32_t);
-        if (c.build_bytes > avail) {
-            if (explicit_depth) return none;
-            continue;
+        for (int tier = 0; tier <= 1; ++tier) {
+            if (tier ? (tiers == 0 || singles == nullptr || d > kTierMaxDepth) : tiers == 1) continue;
+            const uint64_t single = tier ? std::min(singles[d], distinct[d]) : 0, entries = distinct[d] - single;
+            const uint64_t needed = uint64_t(double(entries) / sparse_load(d, tier != 0)) + 1;
+            const uint64_t nb = tier ? sparse_tier_buckets_for(d, entries, single) : sparse_buckets_for(d, distinct[d]);
+            const uint64_t lines = nb + kSparseMaxProbe;
+            if (lines > 0xFFFFFFFFull) continue;
+            // a table that the tags force to be far larger than its entries need is not worth its depth: 16 x for the cheap depths (a toy index
+            // gets a toy table), 4 x for depth 29, whose least size is 69 GB (a human-scale index fills it to 72 % of the aimed load; a
+            // chr20-sized one would fill 7 % and takes depth 27 in 4.3 GB instead)
+            const uint64_t slack = d == 29 ? 4 : 16;
+            const uint64_t data_needs = std::max<uint64_t>(needed, tier ? uint64_t(double(single) / kTierMaxSinglesPerBucket) + 1 : 0);
+            if (!explicit_depth && sparse_min_buckets(d) > std::max<uint64_t>(slack * data_needs, 65536)) continue;
+            SparseChoice c;
+            c.depth = d;
+            c.nbuckets = nb;
+            c.tier = tier != 0;
+            c.bytes = lines * 128 + wide[d] * 16;
+            c.build_bytes = c.bytes + lines * sizeof(uint32_t);
+            if (c.build_bytes > avail) continue;
+            return c;
         }
-        return c;
+        if (explicit_depth) return none;
     }
     return none;
 }

@@ -33,8 +33,10 @@ constexpr int kCurLevel = 0;    // [0 .. 32): nodes appended to the frontier of 
 constexpr int kAccLevel = 32;   // [32 .. 64): the same summed over all chunks that completed
 constexpr int kAccEscape = 64;  // [64 .. 96): nodes 255 or more wide, per depth
 constexpr int kCurEscape = 96;  // [96 .. 128): the same for the chunk in hand
-constexpr int kOverflow = 128, kFailed = 129, kSideCursor = 130, kDisplaced = 131;
-constexpr int kCursorWords = 160;
+constexpr int kOverflow = 128, kFailed = 129, kSideCursor = 130, kDisplaced = 131, kFiltered = 132;
+constexpr int kCurSingle = 160;  // [160 .. 192): nodes exactly 1 wide (suffixes that occur once), per depth, of the chunk in hand
+constexpr int kAccSingle = 192;  // [192 .. 224): the same summed over all chunks that completed
+constexpr int kCursorWords = 224;
 static_assert(kSparseMaxDepth < 32, "a cursor per depth the expansion can reach");
 
 // this thread's first of `mine` consecutive slots behind *cursor: one atomic per workgroup.  Every thread of the block calls it.
@@ -144,6 +146,7 @@ struct FillEnv {
     uint4 *side;
     uint32_t nbuckets, probe, n;  // n = 2 depth
     uint64_t nside;      // entries the side array holds
+    uint32_t tier;       // two-tier form: ranges 1 wide set filter bits in their own bucket instead of taking an entry
 };
 
 // puts the entry of (key, [nl, nh)) into its bucket; `cur`: the cursor block (side cursor, displaced, failed)
@@ -152,7 +155,14 @@ __device__ __forceinline__ void sparse_insert(const FillEnv &env, uint64_t key, 
     uint32_t b = sparse_bucket(x, env.n, env.nbuckets);
     const uint32_t depth = env.n >> 1;
     const bool wide = sparse_wide(depth), xwide = sparse_xwide(depth);  // launch-uniform: the layout follows the depth (sparse_table.hpp)
-    const uint32_t tag = sparse_tag(x, depth), tag_hi = sparse_tag_hi(x, depth), slots = sparse_slots(depth);
+    const bool tier = env.tier != 0u;
+    const uint32_t tag = sparse_tag(x, depth), tag_hi = sparse_tag_hi(x, depth), slots = sparse_slots(depth, tier);
+    if (tier && nh - nl == 1u) {  // occurs once: four bits of one filter word of its OWN bucket (never displaced), no entry
+        const uint32_t f = sparse_filter_hash(tag);
+        atomicOr(reinterpret_cast<uint32_t *>(env.lines + uint64_t(b) * 8u) + kTierFilterWord + sparse_filter_word(f), sparse_filter_mask(f));
+        atomicAdd(cur + kFiltered, 1ull);
+        return;
+    }
     uint64_t lval = nl;
     uint32_t wf = uint32_t(nh - nl);
     if (nh - nl >= kSparseEscapeWidth) {
@@ -169,7 +179,16 @@ __device__ __forceinline__ void sparse_insert(const FillEnv &env, uint64_t key, 
         const uint32_t slot = atomicAdd(env.counts + b, 1u);
         if (slot < slots) {
             uint32_t *line = reinterpret_cast<uint32_t *>(env.lines + uint64_t(b) * 8u);
-            if (xwide) {
+            if (tier && wide) {
+                line[slot] = tag;
+                line[kTierWideL0Word + slot] = uint32_t(lval);
+                reinterpret_cast<uint8_t *>(line)[kTierWideHiByte + slot] = uint8_t(lval >> 32);
+                reinterpret_cast<uint8_t *>(line)[kTierWideWidthByte + slot] = uint8_t(wf);
+            } else if (tier) {
+                line[slot] = tag | (wf << kSparseTagBits);
+                line[kTierL0Word + slot] = uint32_t(lval);
+                reinterpret_cast<uint8_t *>(line)[kTierHiByte + slot] = uint8_t(lval >> 32);
+            } else if (xwide) {
                 line[slot] = tag;
                 line[kSparseXL0Word + slot] = uint32_t(lval);
                 reinterpret_cast<uint8_t *>(line)[kSparseXTagHiByte + slot] = uint8_t(tag_hi);
@@ -207,7 +226,7 @@ __global__ __launch_bounds__(kThreads) void k_sparse_expand_pair(const Node *__r
     const bool s96 = stride96 != 0u;
     for (uint64_t base = uint64_t(blockIdx.x) * kThreads; base < n; base += uint64_t(gridDim.x) * kThreads) {
         const uint64_t i = base + threadIdx.x;
-        uint32_t nonempty = 0, wide = 0;
+        uint32_t nonempty = 0, wide = 0, single = 0;
         PairSixteen L, H;
         Node nd{0, 0, 0};
         uint64_t sb_l = 0, sb_h = 0;
@@ -225,6 +244,7 @@ __global__ __launch_bounds__(kThreads) void k_sparse_expand_pair(const Node *__r
                 for (uint32_t p = 0; p < 16; ++p) {
                     nonempty |= (H.rel[p] != L.rel[p] ? 1u : 0u) << p;
                     wide |= (H.rel[p] - L.rel[p] >= kSparseEscapeWidth ? 1u : 0u) << p;
+                    single |= (H.rel[p] - L.rel[p] == 1u ? 1u : 0u) << p;
                 }
             } else {  // rare: the bounds lie in different superblocks
 #pragma unroll
@@ -232,6 +252,7 @@ __global__ __launch_bounds__(kThreads) void k_sparse_expand_pair(const Node *__r
                     const uint64_t nl = pair_super[sb_l * 16u + p] + L.rel[p], nh = pair_super[sb_h * 16u + p] + H.rel[p];
                     nonempty |= (nh != nl ? 1u : 0u) << p;
                     wide |= (nh - nl >= kSparseEscapeWidth ? 1u : 0u) << p;
+                    single |= (nh - nl == 1u ? 1u : 0u) << p;
                 }
             }
         }
@@ -240,10 +261,12 @@ __global__ __launch_bounds__(kThreads) void k_sparse_expand_pair(const Node *__r
             if (env.lines == nullptr) {
                 block_add(mine, cur + kCurLevel + depth + 2u);
                 block_add(uint32_t(__popc(wide)), cur + kCurEscape + depth + 2u);
+                block_add(uint32_t(__popc(single)), cur + kCurSingle + depth + 2u);
                 continue;
             }
         } else {
             block_add(uint32_t(__popc(wide)), cur + kCurEscape + depth + 2u);
+            block_add(uint32_t(__popc(single)), cur + kCurSingle + depth + 2u);
         }
         uint64_t at = kFinal ? 0ull : reserve(mine, cur + kCurLevel + depth + 2u);
         if (!kFinal && mine != 0u && at + mine > cap) {
@@ -291,7 +314,7 @@ __global__ __launch_bounds__(kThreads) void k_sparse_expand_plane(const Node *__
     const uint64_t n = min(uint64_t(cur[kCurLevel + depth]), in_cap);
     for (uint64_t base = uint64_t(blockIdx.x) * kThreads; base < n; base += uint64_t(gridDim.x) * kThreads) {
         const uint64_t i = base + threadIdx.x;
-        uint32_t mine = 0, wide = 0;
+        uint32_t mine = 0, wide = 0, single = 0;
         uint64_t nl[4], nh[4];
         Node nd{0, 0, 0};
         if (i < n) {
@@ -302,11 +325,13 @@ __global__ __launch_bounds__(kThreads) void k_sparse_expand_plane(const Node *__
             for (int q = 0; q < 4; ++q) {
                 mine += nh[q] != nl[q] ? 1u : 0u;
                 wide += nh[q] - nl[q] >= kSparseEscapeWidth ? 1u : 0u;
+                single += nh[q] - nl[q] == 1u ? 1u : 0u;
             }
         }
         if (env.lines == nullptr) {
             block_add(mine, cur + kCurLevel + depth + 1u);
             block_add(wide, cur + kCurEscape + depth + 1u);
+            block_add(single, cur + kCurSingle + depth + 1u);
             continue;
         }
         if (i < n) {
@@ -323,15 +348,17 @@ __global__ void k_sparse_tally(unsigned long long *cur) {
     if (i < 32u) {
         cur[kAccLevel + i] += cur[kCurLevel + i];
         cur[kAccEscape + i] += cur[kCurEscape + i];
+        cur[kAccSingle + i] += cur[kCurSingle + i];
         cur[kCurLevel + i] = 0ull;
         cur[kCurEscape + i] = 0ull;
+        cur[kCurSingle + i] = 0ull;
     }
 }
 
 // bytes 126..127 of every bucket: how many entries wanted it
-__global__ __launch_bounds__(256) void k_sparse_headers(uint4 *__restrict__ lines, const uint32_t *__restrict__ counts, uint64_t nlines) {
+__global__ __launch_bounds__(256) void k_sparse_headers(uint4 *__restrict__ lines, const uint32_t *__restrict__ counts, uint64_t nlines, uint32_t header_byte) {
     for (uint64_t b = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; b < nlines; b += uint64_t(gridDim.x) * blockDim.x)
-        reinterpret_cast<uint16_t *>(lines + b * 8u)[kSparseHeaderByte / 2] = uint16_t(min(counts[b], 0xFFFFu));
+        reinterpret_cast<uint16_t *>(lines + b * 8u)[header_byte / 2] = uint16_t(min(counts[b], 0xFFFFu));
 }
 
 uint32_t grid_for_nodes(uint64_t n) {
@@ -414,7 +441,7 @@ hipError_t sparse_count_levels(const IndexView &ix, const void *flat_entries, in
     if (w.cap < 1024) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(w.cur, 0, kCursorWords * sizeof(unsigned long long), stream);
     if (e != hipSuccess) return e;
-    const FillEnv none{nullptr, nullptr, nullptr, 0, 0, uint32_t(2 * max_depth), 0};
+    const FillEnv none{nullptr, nullptr, nullptr, 0, 0, uint32_t(2 * max_depth), 0, 0};
     const uint64_t parents = flat_entries ? (uint64_t(1) << (2 * flat_depth)) : 1;
     g_plan = ChunkPlan{flat_entries, flat_depth, max_depth, w.cap, {}};
     // Chunks of parents: the first is small, the following ones are sized by what the last one's largest frontier was, aiming at a
@@ -432,6 +459,7 @@ hipError_t sparse_count_levels(const IndexView &ix, const void *flat_entries, in
             np = std::max<uint64_t>(1, c.np / 2);
             e = hipMemsetAsync(w.cur + kCurLevel, 0, 32 * sizeof(unsigned long long), stream);
             if (e == hipSuccess) e = hipMemsetAsync(w.cur + kCurEscape, 0, 32 * sizeof(unsigned long long), stream);
+            if (e == hipSuccess) e = hipMemsetAsync(w.cur + kCurSingle, 0, 32 * sizeof(unsigned long long), stream);
             if (e == hipSuccess) e = hipMemsetAsync(w.cur + kOverflow, 0, sizeof(unsigned long long), stream);
             if (e != hipSuccess) return e;
             continue;
@@ -452,15 +480,16 @@ hipError_t sparse_count_levels(const IndexView &ix, const void *flat_entries, in
     for (int d = 0; d <= kSparseMaxDepth; ++d) {
         report->distinct[d] = cur[kAccLevel + d];
         report->escapes[d] = cur[kAccEscape + d];
+        report->singles[d] = cur[kAccSingle + d];
     }
     return hipSuccess;
 }
 
-hipError_t sparse_fill(const IndexView &ix, const void *flat_entries, int flat_depth, int depth, void *lines, uint64_t nbuckets, uint32_t probe, void *side,
+hipError_t sparse_fill(const IndexView &ix, const void *flat_entries, int flat_depth, int depth, bool tier, void *lines, uint64_t nbuckets, uint32_t probe, void *side,
                        uint64_t nside, void *d_counts, void *d_work, size_t work_bytes, SparseBuildReport *report, hipStream_t stream) {
     if (flat_entries == nullptr) flat_depth = 0;
     if (!ix.pair_blocks || !lines || !d_counts || depth < kSparseMinDepth || depth > kSparseMaxDepth || flat_depth >= depth || nbuckets == 0 ||
-        nbuckets + probe > 0xFFFFFFFFull || int(probe) > sparse_probe_limit(depth, nbuckets))
+        nbuckets + probe > 0xFFFFFFFFull || int(probe) > sparse_probe_limit(depth, nbuckets) || (tier && depth > kTierMaxDepth))
         return hipErrorInvalidValue;
     const Work w = carve(d_work, work_bytes);
     const uint64_t nlines = nbuckets + probe;
@@ -469,7 +498,7 @@ hipError_t sparse_fill(const IndexView &ix, const void *flat_entries, int flat_d
     if (e == hipSuccess) e = hipMemsetAsync(d_counts, 0, nlines * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     const FillEnv env{static_cast<uint4 *>(lines), static_cast<uint32_t *>(d_counts), static_cast<uint4 *>(side), uint32_t(nbuckets), probe, uint32_t(2 * depth),
-                      side ? nside : 0};
+                      side ? nside : 0, tier ? 1u : 0u};
     // The chunking of the sizing pass holds for every depth up to the one it was made for, of either parity: the pair levels are the
     // same ones (a frontier at depth d does not depend on where the expansion ends), and the last level is never materialised.  Without
     // one (a fill that was not preceded by its sizing pass): small chunks.
@@ -486,7 +515,7 @@ hipError_t sparse_fill(const IndexView &ix, const void *flat_entries, int flat_d
         hipLaunchKernelGGL(k_sparse_tally, dim3(1), dim3(64), 0, stream, w.cur);
     }
     hipLaunchKernelGGL(k_sparse_headers, dim3(uint32_t(std::min<uint64_t>((nlines + 255) / 256, 2048))), dim3(256), 0, stream, static_cast<uint4 *>(lines),
-                       static_cast<const uint32_t *>(d_counts), nlines);
+                       static_cast<const uint32_t *>(d_counts), nlines, tier ? kTierHeaderByte : kSparseHeaderByte);
     std::vector<unsigned long long> cur(kCursorWords);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(cur.data(), w.cur, cur.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream);
@@ -498,7 +527,9 @@ hipError_t sparse_fill(const IndexView &ix, const void *flat_entries, int flat_d
     report->nbuckets = nbuckets;
     report->nescapes = cur[kSideCursor];
     report->displaced = cur[kDisplaced];
-    report->entries = report->distinct[depth];
+    report->tier = tier;
+    report->filtered = cur[kFiltered];
+    report->entries = report->distinct[depth] - (tier ? cur[kFiltered] : 0ull);
     return hipSuccess;
 }
 

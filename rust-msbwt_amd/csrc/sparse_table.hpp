@@ -46,6 +46,24 @@
 //     bytes 126..127 header    (> 11 = entries were displaced)
 // Uniqueness: (probe + 1) * W <= 2^40 -- 2^25 buckets suffice again, and 7 entries per bucket (the same 64 %) make 18.3 bytes per
 // distinct suffix: 54.5 GB for the 2.98e9 distinct 31-mers of the error-free human-scale index.
+//
+// TWO-TIER form (round 6; depths up to 29): for read sets WITH errors.  The complete table's size follows the distinct suffixes, and
+// on reads with substitutions most of those are error k-mers that occur ONCE (30x human reads, 0.5 % errors: 1.3e10 distinct 23-mers
+// of which about 3e9 -- the genome's -- occur more than once: 185 GB complete).  The two-tier table keeps an ENTRY only for the
+// suffixes whose range is at least 2 wide ("solid") and, for the ones that occur once, sets 4 bits of one of the 8 FILTER words of
+// their own bucket line (a blocked Bloom filter inside the line the lookup fetches anyway: no false negatives).  A lookup that finds
+// its tag is served as before; one that finds neither its tag nor its filter bits is count 0, exactly as in the complete table (every
+// suffix that occurs is either an entry or in the filter); one whose filter bits are set (a suffix that occurs once -- or a false
+// positive, about 1 % at 21 such suffixes per bucket) continues through the DIRECT table and the search: the reference's own path
+// (src/rle_bwt.rs:202-287), so the count stays exact whatever the filter says.  Layout (24-bit tags, depths up to 24): 10 entries
+//     words  0..9    tag[i] | width << 24      (width 2..254; 255 = ESCAPE; 0 = empty slot)
+//     words 10..19   l_lo[i]
+//     bytes 80..89   l_hi[i]
+//     bytes 90..91   header (entries that wanted this bucket; > 10 = some were displaced)
+//     words 23..30   the filter: key -> one word (3 hash bits) and 4 bits in it (4 x 5 hash bits)
+// and with 32-bit tags (depths 25..29): 9 entries -- tags in words 0..8, l_lo in words 9..17, l_hi in bytes 72..80, widths in bytes
+// 81..89, header and filter as above.  Size: solid / 6.4 (5.76) buckets, at least singles / 32 (the filter's load): the 30x human
+// read set with errors keeps depth 23 in about 60 GB.
 #pragma once
 #include <cstdint>
 
@@ -66,6 +84,12 @@ constexpr int kSparseWideFrom = 25;
 constexpr uint32_t kSparseXSlots = 11;       // ... and of the xwide layout (depths 30..31): 40-bit tags
 constexpr uint32_t kSparseXL0Word = 11, kSparseXTagHiByte = 88, kSparseXHiByte = 99, kSparseXWidthByte = 110;
 constexpr int kSparseXFrom = 30;
+// two-tier form: entries per bucket (24-bit / 32-bit tags), where its fields sit, the filter
+constexpr uint32_t kTierSlots = 10, kTierL0Word = 10, kTierHiByte = 80;
+constexpr uint32_t kTierWideSlots = 9, kTierWideL0Word = 9, kTierWideHiByte = 72, kTierWideWidthByte = 81;
+constexpr uint32_t kTierHeaderByte = 90, kTierFilterWord = 23, kTierFilterWords = 8;
+constexpr int kTierMaxDepth = 29;                 // (the 40-bit-tag layout of depths 30..31 has no two-tier form)
+constexpr double kTierMaxSinglesPerBucket = 32.0; // filter load the builder accepts: 4 keys per 32-bit word, 2.5 % false positives
 constexpr uint32_t kSparseEscapeWidth = 255;  // width field of an entry whose range lives in the side array
 constexpr uint32_t kSparseMaxProbe = 15;      // a key lives at most this many buckets behind its own
 constexpr int kSparseMinDepth = 16, kSparseMaxDepth = 31;
@@ -74,9 +98,23 @@ constexpr double kSparseLoad = 9.0;           // entries per bucket the builder 
 
 MSBWT_HD bool sparse_wide(uint32_t depth) { return depth >= uint32_t(kSparseWideFrom); }   // (xwide included: the tag's low word is whole)
 MSBWT_HD bool sparse_xwide(uint32_t depth) { return depth >= uint32_t(kSparseXFrom); }
-MSBWT_HD uint32_t sparse_slots(uint32_t depth) { return sparse_xwide(depth) ? kSparseXSlots : sparse_wide(depth) ? kSparseWideSlots : kSparseSlots; }
+MSBWT_HD uint32_t sparse_slots(uint32_t depth, bool tier = false) {
+    if (tier) return sparse_wide(depth) ? kTierWideSlots : kTierSlots;
+    return sparse_xwide(depth) ? kSparseXSlots : sparse_wide(depth) ? kSparseWideSlots : kSparseSlots;
+}
+// two-tier filter: the word (0..7) and the four bits of a key, from its tag (unique within a bucket's probe window, so two keys of a
+// bucket never share all of it)
+MSBWT_HD uint32_t sparse_filter_hash(uint32_t tag) {
+    uint32_t f = tag * 0x9E3779B1u;
+    f ^= f >> 15;
+    f *= 0x85EBCA77u;
+    f ^= f >> 13;
+    return f;
+}
+MSBWT_HD uint32_t sparse_filter_word(uint32_t f) { return f >> 29; }
+MSBWT_HD uint32_t sparse_filter_mask(uint32_t f) { return (1u << (f & 31u)) | (1u << ((f >> 5) & 31u)) | (1u << ((f >> 10) & 31u)) | (1u << ((f >> 15) & 31u)); }
 MSBWT_HD uint32_t sparse_tag_bits(uint32_t depth) { return sparse_xwide(depth) ? 40u : sparse_wide(depth) ? 32u : kSparseTagBits; }
-inline double sparse_load(int depth) { return kSparseLoad * double(sparse_slots(uint32_t(depth))) / double(kSparseSlots); }  // the same 64 % of the slots
+inline double sparse_load(int depth, bool tier = false) { return kSparseLoad * double(sparse_slots(uint32_t(depth), tier)) / double(kSparseSlots); }  // the same 64 % of the slots
 constexpr uint32_t kSparseL0Word = 14, kSparseHiByte = 112, kSparseHeaderByte = 126;
 
 struct SparseView {
@@ -85,6 +123,7 @@ struct SparseView {
     uint32_t depth = 0;            // symbols an entry stands for
     uint32_t probe = 0;            // buckets a lookup may go beyond its own
     const void *side = nullptr;    // 16-byte {l, h} entries of the ESCAPE entries
+    uint32_t tier = 0;             // 1 = two-tier form: entries for the suffixes at least 2 wide, filter bits for the ones that occur once
 };
 
 // the bijection of n-bit words (n = 2 depth, 32 <= n <= 62)
@@ -136,6 +175,12 @@ inline uint64_t sparse_buckets_for(int depth, uint64_t entries, double load = 0.
     const uint64_t want = uint64_t(double(entries) / (load > 0.0 ? load : sparse_load(depth))) + 1;
     const uint64_t least = sparse_min_buckets(depth);
     return want > least ? want : least;
+}
+// ... of the two-tier form: `solid` entries at its load, and room in the filters for `singles` suffixes that occur once
+inline uint64_t sparse_tier_buckets_for(int depth, uint64_t solid, uint64_t singles) {
+    const uint64_t by_entries = sparse_buckets_for(depth, solid, sparse_load(depth, true));
+    const uint64_t by_filter = uint64_t(double(singles) / kTierMaxSinglesPerBucket) + 1;
+    return by_entries > by_filter ? by_entries : by_filter;
 }
 
 }  // namespace msbwt

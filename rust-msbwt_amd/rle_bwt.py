@@ -301,7 +301,7 @@ class RleBWT(BWT):
         return {"lines": a.value, "escape_lines": b.value, "side_bytes": c.value}
 
     COUNTER_NAMES = ("wave_steps", "lane_steps", "pair_steps", "second_lines", "sat_out", "escape_queries", "escape_restarts",
-                     "table_decided", "searched", "first_lines", "table_steps", "table_displaced", "table_rides", "waves_worked")
+                     "table_decided", "searched", "first_lines", "table_steps", "table_displaced", "table_rides", "waves_worked", "tier_fallbacks")
 
     # ---- sparse suffix table (include/msbwt_hip.h, msbwt_rle_set_sparse_table) ----
     def set_sparse_table(self, depth):
@@ -320,20 +320,33 @@ class RleBWT(BWT):
     def get_query_length(self):
         return int(_lib.lib().msbwt_rle_get_query_length(self._h))
 
+    def set_sparse_tiers(self, mode):
+        """Two-tier form of the sparse table (entries for the suffixes that occur at least twice, filter bits for the rest -- read sets with
+        errors): -1 = where the complete table of a depth does not fit (default), 0 = never, 1 = always.  Results never depend on it."""
+        rc = _lib.lib().msbwt_rle_set_sparse_tiers(self._h, int(mode))
+        if rc:
+            _raise(rc, self._h)
+
+    def get_sparse_tiers(self):
+        """True when the sparse table in HBM is of the two-tier form."""
+        return bool(_lib.lib().msbwt_rle_get_sparse_tiers(self._h))
+
     def get_sparse_table(self):
         """Depth of the sparse suffix table in HBM, 0 = none."""
         return int(_lib.lib().msbwt_rle_get_sparse_table(self._h))
 
     def sparse_table_info(self):
         """What msbwt_rle_sparse_table_info reports, by name; "distinct" / "wide": {depth: count} for the depths the build passed."""
-        out = (C.c_uint64 * 80)()
+        out = (C.c_uint64 * _lib.SPARSE_INFO_WORDS)()
         rc = _lib.lib().msbwt_rle_sparse_table_info(self._h, out)
         if rc:
             _raise(rc, self._h)
         info = {"depth": int(out[0]), "entries": int(out[1]), "buckets": int(out[2]), "bytes": int(out[3]), "side_entries": int(out[4]),
-                "side_bytes": int(out[5]), "displaced": int(out[6]), "parent_depth": int(out[7]), "probe": int(out[9])}
+                "side_bytes": int(out[5]), "displaced": int(out[6]), "parent_depth": int(out[7]), "two_tier": bool(out[8]), "probe": int(out[9]),
+                "filtered": int(out[42])}
         info["distinct"] = {d: int(out[10 + d]) for d in range(32) if out[10 + d]}
         info["wide"] = {d: int(out[45 + d]) for d in range(32) if out[10 + d]}
+        info["once"] = {d: int(out[80 + d]) for d in range(32) if out[10 + d]}
         return info
 
     def download_sparse_table(self):

@@ -69,6 +69,8 @@ extern "C" {
     // the k the index will mostly be asked about (0 = unknown): the automatic sparse table then reaches min(k, 27) instead of 23
     fn msbwt_rle_set_query_length(bwt: *mut MsbwtRle, k: c_int) -> c_int;
     fn msbwt_rle_get_query_length(bwt: *const MsbwtRle) -> c_int;
+    fn msbwt_rle_set_sparse_tiers(bwt: *mut MsbwtRle, mode: c_int) -> c_int;
+    fn msbwt_rle_get_sparse_tiers(bwt: *const MsbwtRle) -> c_int;
     fn msbwt_auto_sparse_max_depth(query_length: c_int) -> c_int;
     fn msbwt_rle_sparse_table_info(bwt: *const MsbwtRle, out: *mut u64) -> c_int;
     // one batch counted and gathered as a pipeline (pieces searched while earlier pieces' counts travel over RCCL)
@@ -194,9 +196,18 @@ impl GpuRleBWT {
 
     pub fn query_length(&self) -> i32 { unsafe { msbwt_rle_get_query_length(self.raw) } }
 
+    /// Two-tier form of the sparse table (entries for the suffixes that occur at least twice, filter bits for the rest -- read sets with
+    /// errors): -1 = where the complete table of a depth does not fit (default), 0 = never, 1 = always.  Results never change.
+    pub fn set_sparse_tiers(&mut self, mode: i32) {
+        let rc = unsafe { msbwt_rle_set_sparse_tiers(self.raw, mode) };
+        if rc != MSBWT_OK { panic!("set_sparse_tiers: {}", self.last_error()); }
+    }
+
+    pub fn sparse_tiers(&self) -> bool { unsafe { msbwt_rle_get_sparse_tiers(self.raw) != 0 } }
+
     /// Depth of the sparse suffix table in HBM (0 = none) and how many distinct suffixes of that length occur.
     pub fn sparse_table(&self) -> (i32, u64) {
-        let mut info = [0u64; 80];
+        let mut info = [0u64; 120];
         let rc = unsafe { msbwt_rle_sparse_table_info(self.raw, info.as_mut_ptr()) };
         if rc != MSBWT_OK { panic!("sparse_table_info: {}", self.last_error()); }
         (unsafe { msbwt_rle_get_sparse_table(self.raw) }, info[1])

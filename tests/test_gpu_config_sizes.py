@@ -109,6 +109,39 @@ def test_c4_real_bwt_random_and_read_derived_31mers():
         if name == "reads":
             assert int(a.min()) >= 1
         del d_q, a, b
+    # Round 6: the TWO-TIER form of the sparse table on this read set (0.5 % substitutions: 2.4e8 distinct 23-mers, 3.7 x its genome's, most of
+    # them error k-mers that occur once).  Solid, once-only and absent 31-mers -- read windows, and read windows with one symbol changed --
+    # count n / 1 / 0 exactly as with the complete table and as the oracle says; the table holds entries only for the suffixes that occur
+    # at least twice.
+    bwt.set_search_kernel("lanes")
+    q = synth.read_kmers(reads, k, limit=12_000_000, seed=9)
+    mut = q[:4_000_000].copy()
+    mut[np.arange(len(mut)), rng.integers(0, k, size=len(mut))] = np.array([1, 2, 3, 5], dtype=np.uint8)[rng.integers(0, 4, size=len(mut))]
+    q = np.ascontiguousarray(np.concatenate([q, mut]))
+    d_q = torch.from_numpy(q).to(dev)
+    complete = _count_matrix(torch, dev, bwt, d_q)
+    info0 = bwt.sparse_table_info()
+    assert info0["depth"] == 23 and not info0["two_tier"]
+    bwt.set_sparse_tiers(1)
+    info1 = bwt.sparse_table_info()
+    assert bwt.get_sparse_tiers() and info1["depth"] == 23 and info1["two_tier"]
+    assert info1["entries"] + info1["filtered"] == info0["entries"] == info1["distinct"][23] and info1["filtered"] == info1["once"][23] > info1["entries"]
+    bwt.set_search_counters(True)
+    tiered = _count_matrix(torch, dev, bwt, d_q)
+    cnt = bwt.search_counters(torch.cuda.current_stream(dev).cuda_stream)
+    bwt.set_search_counters(False)
+    assert torch.equal(tiered, complete)
+    assert cnt["tier_fallbacks"] > 0.05 * len(q)      # the once-only suffixes (and a few false positives) took the direct table's path
+    ids = np.sort(rng.choice(len(q), size=1_000_000, replace=False))
+    exp = ref.count_kmers(q[ids], nthreads=NCPU)
+    assert np.array_equal(tiered[torch.from_numpy(ids).to(dev)].cpu().numpy().astype(np.uint64), exp)
+    assert (exp == 0).sum() > 50_000 and (exp == 1).sum() > 50_000 and (exp > 1).sum() > 500_000
+    # k between the direct table's depth and the sparse table's, and beyond 32
+    for kk in (17, 21, 22, 23, 24, 40):
+        qs = np.ascontiguousarray(synth.read_kmers(reads, kk, limit=1_000_000, seed=kk))
+        assert np.array_equal(_count_matrix(torch, dev, bwt, torch.from_numpy(qs).to(dev)).cpu().numpy().astype(np.uint64), ref.count_kmers(qs, nthreads=NCPU)), kk
+    bwt.set_sparse_tiers(-1)
+    assert not bwt.get_sparse_tiers() and torch.equal(_count_matrix(torch, dev, bwt, d_q), complete)
 
 
 def test_stream_beyond_2_pow_33_symbols_hbm_regime():

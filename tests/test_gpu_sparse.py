@@ -316,3 +316,223 @@ def test_when_no_depth_fits_the_direct_table_is_built_instead_and_the_counts_sta
         assert np.array_equal(b.count_kmers(q), ref.count_kmers(q)), k
     b.set_memory_budget(0)
     assert b.get_sparse_table() >= 16 and b.device_bytes() == full
+
+
+# ---- the two-tier form (round 6; csrc/sparse_table.hpp): entries for the suffixes that occur at least twice, filter bits for the rest ----
+def tier_lookup(lines, side, info, key):
+    """What the kernel does with one key on a downloaded TWO-TIER table: -> ("entry", l, h) | ("filter",) | None (count 0)."""
+    b, tag = C.c_uint32(), C.c_uint64()
+    assert _lib.lib().msbwt_sparse_hash64(int(key), info["depth"], info["buckets"], C.byref(b), C.byref(tag)) == 0
+    wide = info["depth"] >= 25
+    nslots = 9 if wide else 10
+    word, mask = C.c_uint32(), C.c_uint32()
+    assert _lib.lib().msbwt_sparse_filter_bits(tag.value, C.byref(word), C.byref(mask)) == 0
+    assert 0 <= word.value < 8 and bin(mask.value).count("1") <= 4 and mask.value != 0
+    home = lines[b.value]
+    maybe = (int(home[23 + word.value]) & mask.value) == mask.value
+    for dist in range(info["probe"] + 1):
+        line = lines[b.value + dist]
+        raw = line.view(np.uint8)
+        for slot in range(nslots):
+            t = int(line[slot])
+            if wide:
+                width, hit, lo = int(raw[81 + slot]), t == tag.value, int(line[9 + slot]) | (int(raw[72 + slot]) << 32)
+            else:
+                width, hit, lo = t >> 24, (t & 0xFFFFFF) == tag.value, int(line[10 + slot]) | (int(raw[80 + slot]) << 32)
+            if width != 0 and hit:
+                assert width >= 2, "a suffix that occurs once has no entry"
+                return ("entry",) + ((int(side[lo][0]), int(side[lo][1])) if width == 255 else (lo, lo + width))
+        header = int(raw[90]) | (int(raw[91]) << 8)
+        if header <= nslots:
+            break
+    return ("filter",) if maybe else None
+
+
+def tier_slots_in_use(lines, info):
+    raw = lines.view(np.uint8).reshape(len(lines), 128)
+    return int((raw[:, 81:90] != 0).sum()) if info["depth"] >= 25 else int(((lines[:, :10] >> 24) != 0).sum())
+
+
+@pytest.mark.parametrize("depth", [16, 17, 20, 24, 25, 27, 28])
+def test_two_tier_table_holds_the_solid_suffixes_and_filters_the_ones_that_occur_once(depth, monkeypatch):
+    """MSBWT_SPARSE_TIERS=1: every suffix that occurs at least twice has an entry with the oracle's range; every suffix that occurs once has
+    NO entry and its four filter bits set in its own bucket; an absent suffix is a miss or (rarely) a filter false positive; the slots
+    in use are exactly the solid suffixes."""
+    reads = read_set(31, 3000, 700, 60, repeats=4, err=0.02)
+    b, ref = load_pair(bwt_of(reads), monkeypatch, depth, MSBWT_SPARSE_TIERS=1)
+    assert b.get_sparse_table() == depth and b.get_sparse_tiers() and b.get_pair_index()
+    info = b.sparse_table_info()
+    assert info["two_tier"]
+    lines, side = b.download_sparse_table()
+    present = np.unique(np.lib.stride_tricks.sliding_window_view(reads, depth, axis=1).reshape(-1, depth), axis=0)
+    l, h = oracle_ranges(ref, present)
+    once = (h - l) == 1
+    assert once.sum() > 100 and (~once).sum() > 100          # reads with errors: both kinds
+    assert info["distinct"][depth] == len(present) and info["once"][depth] == int(once.sum()) == info["filtered"]
+    assert info["entries"] == int((~once).sum()) == tier_slots_in_use(lines, info)
+    for key, el, eh in zip(table_key(present), l, h):
+        got = tier_lookup(lines, side, info, key)
+        assert got == (("filter",) if eh - el == 1 else ("entry", int(el), int(eh)))
+    absent = random_kmers(5, 4000, depth)
+    al, ah = oracle_ranges(ref, absent)
+    false_pos = 0
+    for key, el, eh in zip(table_key(absent), al, ah):
+        got = tier_lookup(lines, side, info, key)
+        if eh > el:
+            assert got == (("filter",) if eh - el == 1 else ("entry", int(el), int(eh)))
+        else:
+            assert got in (None, ("filter",))
+            false_pos += got is not None
+    assert false_pos < 0.1 * len(absent)
+    # the shallower levels' counts of suffixes that occur once
+    for d, n in info["once"].items():
+        if 4 <= d <= depth and d in info["distinct"]:
+            w = np.lib.stride_tricks.sliding_window_view(reads, d, axis=1).reshape(-1, d)
+            _, cnt = np.unique(w, axis=0, return_counts=True)
+            assert n == int((cnt == 1).sum()), d
+
+
+@pytest.mark.parametrize("direct", ["packed", "flat", "none"])
+@pytest.mark.parametrize("stride", [96, 128])
+@pytest.mark.parametrize("depth", [16, 19, 23, 25, 28])
+def test_counts_with_the_two_tier_table_equal_the_oracle(depth, stride, direct, monkeypatch):
+    """Solid, once-only, absent and mutated k-mers (counts n / 1 / 0 exact) through the two-tier table: a lookup that ends in the filter goes
+    on through the direct table -- packed, flat, or none at all (from [0, total)) -- and the search."""
+    if direct != "packed" and (stride == 128 or depth in (19, 28)):
+        pytest.skip("the direct-table variants are covered at stride 96, depths 16 / 23 / 25")
+    env = {"MSBWT_SPARSE_TIERS": 1, "MSBWT_PAIR_STRIDE": stride}
+    if direct == "flat":
+        env["MSBWT_TABLE_PACKED"] = 0
+    if direct == "none":
+        env["MSBWT_TABLE_DEPTH"] = 0
+    reads = read_set(121 + depth, 5000, 900, 80, repeats=6, err=0.01)
+    b, ref = load_pair(bwt_of(reads), monkeypatch, depth, **env)
+    assert b.get_sparse_table() == depth and b.get_sparse_tiers() and b.get_pair_stride() == stride
+    assert (b.get_table_depth() == 0) == (direct == "none") and (b.get_table_packed() if direct == "packed" else not b.get_table_packed())
+    rng = np.random.default_rng(depth)
+    for k in [depth, depth + 1, depth + 2, 31, 32, 33, 47, 64]:
+        if k < depth or k > 80:
+            continue
+        windows = np.lib.stride_tricks.sliding_window_view(reads, k, axis=1).reshape(-1, k)
+        q = np.concatenate([windows[rng.integers(0, len(windows), size=4000)], random_kmers(k, 1500, k)])
+        mut = windows[rng.integers(0, len(windows), size=2000)].copy()
+        pos = rng.integers(0, k, size=len(mut))
+        mut[np.arange(len(mut)), pos] = ACGT[rng.integers(0, 4, size=len(mut))]
+        odd = windows[rng.integers(0, len(windows), size=600)].copy()
+        odd[np.arange(len(odd)), rng.integers(0, k, size=len(odd))] = rng.choice([0, 4], size=len(odd))
+        q = np.ascontiguousarray(np.concatenate([q, mut, odd]))
+        rng.shuffle(q)
+        exp = ref.count_kmers(q)
+        assert (exp == 1).sum() > 200 and (exp == 0).sum() > 200 and (exp > 1).sum() > 200
+        b.set_search_counters(True)
+        got = b.count_kmers(q)
+        cnt = b.search_counters(0)
+        b.set_search_counters(False)
+        assert np.array_equal(got, exp), k
+        assert cnt["tier_fallbacks"] > 100, cnt     # the once-only suffixes went down the direct table's path
+        if k <= 64:
+            plain = q[np.isin(q, ACGT).all(axis=1)]
+            assert np.array_equal(b.count_kmers_packed(msbwt.rle_bwt.pack_2bit(plain), k), ref.count_kmers(plain)), k
+    # many more tiles than resident waves: most lookups ride along with the search of the tile before theirs (the other way into the filter)
+    k = 31
+    windows = np.lib.stride_tricks.sliding_window_view(reads, k, axis=1).reshape(-1, k)
+    q = np.ascontiguousarray(np.concatenate([windows] * 6 + [random_kmers(9, 20000, k)]))
+    b.set_search_counters(True)
+    got = b.count_kmers(q)
+    cnt = b.search_counters(0)
+    b.set_search_counters(False)
+    assert np.array_equal(got, ref.count_kmers(q))
+    assert cnt["table_rides"] > 0.2 * 6 * len(windows) and cnt["tier_fallbacks"] > 1000
+    # the fused read windows, both strands
+    k = max(depth, 25)
+    fwd, rc = b.count_read_kmers(reads[:200], k, ascii=False, forward=True, revcomp=True)
+    windows = np.lib.stride_tricks.sliding_window_view(reads[:200], k, axis=1)
+    assert np.array_equal(fwd, ref.count_kmers(windows.reshape(-1, k)).reshape(fwd.shape))
+    rcq = np.array([orc.reverse_complement_i(w) for w in windows.reshape(-1, k)], dtype=np.uint8)
+    assert np.array_equal(rc, ref.count_kmers(rcq).reshape(rc.shape))
+    # the complete table of the same depth, then the automatic choice (complete: everything fits here), then two-tier again: counts never change
+    q = np.ascontiguousarray(windows.reshape(-1, k)[:6000])
+    exp = ref.count_kmers(q)
+    for mode, tiers in ((0, False), (-1, False), (1, True)):
+        b.set_sparse_tiers(mode)
+        assert b.get_sparse_table() == depth and b.get_sparse_tiers() == tiers
+        assert np.array_equal(b.count_kmers(q), exp), mode
+    twin = b.replicate(b.device_ordinal())
+    assert twin.get_sparse_tiers() and np.array_equal(twin.count_kmers(q), exp)
+
+
+def test_two_tier_table_with_high_copy_suffixes_and_escape_lines_of_the_direct_table(monkeypatch):
+    """Repeats: wide entries of the two-tier table (side array) AND escape lines of the packed direct table its filter sends queries to."""
+    rng = np.random.default_rng(3)
+    genome = ACGT[rng.integers(0, 4, size=40000)]
+    unit = ACGT[rng.integers(0, 4, size=40)]
+    reads = [genome[s:s + 50] for s in rng.integers(0, len(genome) - 50, size=2500)]
+    reads += [np.concatenate([unit, unit])[o:o + 50] for o in rng.integers(0, 30, size=600)]
+    reads = np.stack(reads)
+    flip = rng.random(reads.shape) < 0.01
+    reads = np.where(flip, ACGT[rng.integers(0, 4, size=reads.shape)], reads)
+    b, ref = load_pair(bwt_of(reads), monkeypatch, 16, MSBWT_SPARSE_TIERS=1, MSBWT_TABLE_DEPTH=3, MSBWT_TABLE_PACKED=1)
+    info, tinfo = b.sparse_table_info(), b.table_info()
+    assert b.get_sparse_tiers() and info["side_entries"] > 0 and b.get_table_packed() and tinfo["escape_lines"] > 0 and tinfo["side_bytes"] > 0
+    for k in (16, 31, 40):
+        windows = np.lib.stride_tricks.sliding_window_view(reads, k, axis=1).reshape(-1, k)
+        q = np.ascontiguousarray(np.concatenate([windows] * 3 + [random_kmers(9, 20000, k)]))
+        b.set_search_counters(True)
+        got = b.count_kmers(q)
+        cnt = b.search_counters(0)
+        b.set_search_counters(False)
+        assert np.array_equal(got, ref.count_kmers(q)), k
+        assert cnt["tier_fallbacks"] > 0 and cnt["escape_queries"] > 0
+    # without the direct table's side array the two-tier form is not built (an escape line could not be followed from the filter's path)
+    b.set_table_side(0)
+    assert not b.get_sparse_tiers()
+    q = np.ascontiguousarray(np.lib.stride_tricks.sliding_window_view(reads, 31, axis=1).reshape(-1, 31)[:20000])
+    assert np.array_equal(b.count_kmers(q), ref.count_kmers(q))
+
+
+@pytest.mark.parametrize("tiers", [0, 1])
+def test_run_blocks_behind_a_sparse_table(tiers, monkeypatch):
+    """MSBWT_BLOCKS=runs (the memory-lean format) with a sparse table (round 6): the table is built at load time from temporary plane and
+    pair blocks that are freed again; lookups continue with single-symbol steps over the run blocks."""
+    monkeypatch.setenv("MSBWT_BLOCKS", "runs")
+    reads = read_set(91, 20000, 5000, 90, repeats=10, err=0.01)
+    b, ref = load_pair(bwt_of(reads), monkeypatch, 19, MSBWT_SPARSE_TIERS=tiers)
+    assert b.get_block_format() == "runs" and not b.get_pair_index()
+    assert b.get_sparse_table() == 19 and b.get_sparse_tiers() == bool(tiers)
+    info = b.sparse_table_info()
+    present = np.unique(np.lib.stride_tricks.sliding_window_view(reads, 19, axis=1).reshape(-1, 19), axis=0)
+    assert info["distinct"][19] == len(present)
+    # the table costs exactly its own bytes on top of the run blocks and their direct table
+    monkeypatch.setenv("MSBWT_SPARSE_TABLE", "0")
+    lean = RleBWT()
+    lean.load_vector(bwt_of(reads))
+    assert lean.get_sparse_table() == 0 and b.device_bytes() == lean.device_bytes() + info["bytes"] + info["side_bytes"]
+    rng = np.random.default_rng(1)
+    for k in (8, 18, 19, 20, 31, 33, 64):
+        windows = np.lib.stride_tricks.sliding_window_view(reads, k, axis=1).reshape(-1, k)
+        mut = windows[rng.integers(0, len(windows), size=3000)].copy()
+        mut[np.arange(len(mut)), rng.integers(0, k, size=len(mut))] = ACGT[rng.integers(0, 4, size=len(mut))]
+        odd = windows[rng.integers(0, len(windows), size=500)].copy()
+        odd[np.arange(len(odd)), rng.integers(0, k, size=len(odd))] = rng.choice([0, 4], size=len(odd))
+        q = np.ascontiguousarray(np.concatenate([windows[::3], random_kmers(k, 5000, k), mut, odd]))
+        b.set_search_counters(True)
+        got = b.count_kmers(q)
+        cnt = b.search_counters(0)
+        b.set_search_counters(False)
+        assert np.array_equal(got, ref.count_kmers(q)), k
+        assert np.array_equal(lean.count_kmers(q), got), k
+        if k >= 19:
+            assert cnt["table_steps"] > 0 and cnt["pair_steps"] == 0, cnt
+            assert bool(cnt["tier_fallbacks"]) == bool(tiers), cnt
+    fwd, rc = b.count_read_kmers(reads[:300], 31, ascii=False, forward=True, revcomp=True)
+    windows = np.lib.stride_tricks.sliding_window_view(reads[:300], 31, axis=1)
+    assert np.array_equal(fwd, ref.count_kmers(windows.reshape(-1, 31)).reshape(fwd.shape))
+    rcq = np.array([orc.reverse_complement_i(w) for w in windows.reshape(-1, 31)], dtype=np.uint8)
+    assert np.array_equal(rc, ref.count_kmers(rcq).reshape(rc.shape))
+    twin = b.replicate(b.device_ordinal())
+    q = np.ascontiguousarray(windows.reshape(-1, 31)[:5000])
+    assert twin.get_sparse_table() == 19 and np.array_equal(twin.count_kmers(q), ref.count_kmers(q))
+    # the table goes when asked to (it cannot come back without a load: the plane blocks it was built from are gone)
+    b.set_sparse_table(0)
+    assert b.get_sparse_table() == 0 and b.device_bytes() == lean.device_bytes()
+    assert np.array_equal(b.count_kmers(q), ref.count_kmers(q))

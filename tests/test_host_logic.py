@@ -572,3 +572,57 @@ def test_automatic_sparse_depth_follows_the_distinct_counts():
     depth, nbytes = choose(c4_deep, 200 * GB, query_length=29)
     assert depth == 27 and nbytes < 4.4 * GB                       # 69 GB for 2.7e8 entries is not worth two symbols
     assert choose(c2, 200 * GB, query_length=21)[0] == 21
+
+
+def test_two_tier_sparse_table_is_chosen_where_the_complete_one_does_not_fit():
+    """csrc/sparse_policy.hpp through msbwt_auto_sparse_choice (no device).  A 30x human read set WITH 0.5 % substitutions counts about 1.3e10
+    distinct 23-mers of which the genome's 3e9 occur more than once: the complete depth-23 table needs 185 GB, the two-tier one
+    -- entries for the suffixes that occur at least twice, filter bits for the rest -- about 60 GB, so with 120 GB free the two-tier form of
+    depth 23 is what the loader builds; where the complete table fits it is preferred; tiers = 0 / 1 force either form."""
+    def choose(distinct, once, avail, parent=13, tiers=-1, query_length=0, wide=None):
+        d, w, o = (C.c_uint64 * 32)(), (C.c_uint64 * 32)(), (C.c_uint64 * 32)()
+        for k, v in distinct.items():
+            d[k] = int(v)
+        for k, v in once.items():
+            o[k] = int(v)
+        for k, v in (wide or {}).items():
+            w[k] = int(v)
+        depth, tier, nbytes = C.c_int(), C.c_int(), C.c_uint64()
+        assert _lib.lib().msbwt_auto_sparse_choice(d, w, o, parent, int(avail), query_length, tiers, C.byref(depth), C.byref(tier), C.byref(nbytes)) == 0
+        return depth.value, tier.value, nbytes.value
+
+    GB = 10 ** 9
+    noisy = {13: 67108864, 15: 1.07e9, 17: 9.0e9, 19: 1.05e10, 21: 1.17e10, 23: 1.29e10}
+    once = {13: 0, 15: 2.0e7, 17: 6.2e9, 19: 7.5e9, 21: 8.7e9, 23: 9.9e9}
+    depth, tier, nbytes = choose(noisy, once, 120 * GB)
+    assert (depth, tier) == (23, 1) and 55 * GB < nbytes < 65 * GB          # 3.0e9 entries at 6.4 per 128-byte bucket
+    assert choose(noisy, once, 200 * GB)[:2] == (23, 0)                       # the complete table where it fits (185 GB)
+    assert choose(noisy, once, 120 * GB, tiers=0)[0] == 0                     # complete tables only: nothing fits
+    assert choose(noisy, once, 200 * GB, tiers=1)[:2] == (23, 1)
+    assert choose(noisy, once, 50 * GB)[0] == 0                               # not even the two-tier form of any depth: the deep direct table
+    # the filter's load bounds the table from below: 32 once-only suffixes per bucket at most
+    few_solid = {13: 1000, 15: 10**6, 17: 10**9, 19: 2 * 10**9}
+    few_once = {17: 10**9 - 10**6, 19: 2 * 10**9 - 10**6}
+    depth, tier, nbytes = choose(few_solid, few_once, 20 * GB, tiers=1)
+    assert (depth, tier) == (19, 1) and nbytes >= ((2 * 10**9 - 10**6) // 32) * 128
+    # error-free reads: nothing occurs once, the complete table always wins
+    human = {13: 67108864, 15: 1006827312, 17: 2735962851, 19: 2964035516, 21: 2979123385, 23: 2980069347}
+    assert choose(human, {23: 120, 21: 80}, 80 * GB)[:2] == (23, 0)
+    # a declared k: the two-tier form reaches depth 29 (32-bit tags, 9 entries per bucket); depths 30..31 have no two-tier form
+    deep = dict(noisy)
+    deep.update({25: 1.41e10, 27: 1.53e10, 29: 1.65e10, 31: 1.77e10})
+    deep_once = dict(once)
+    deep_once.update({25: 1.11e10, 27: 1.23e10, 29: 1.35e10, 31: 1.47e10})
+    depth, tier, nbytes = choose(deep, deep_once, 120 * GB, query_length=31)
+    assert (depth, tier) == (29, 1) and nbytes <= 120 * GB
+    assert choose(deep, deep_once, 70 * GB, query_length=31)[:2] == (27, 1)   # depth 29 needs 2^29 buckets (69 GB + its slot counters)
+    assert choose(deep, deep_once, 64 * GB, query_length=31)[:2] == (23, 1)   # 5.76 entries per bucket at depths 25..29, 6.4 up to 24
+    # the filter as a pure function: a word 0..7 and at most four bits, the same for the same tag
+    word, mask, w2, m2 = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    seen = set()
+    for tag in list(range(2000)) + [0xFFFFFF, 0xFFFFFFFF, 0x12345678]:
+        assert _lib.lib().msbwt_sparse_filter_bits(tag, C.byref(word), C.byref(mask)) == 0
+        assert _lib.lib().msbwt_sparse_filter_bits(tag, C.byref(w2), C.byref(m2)) == 0
+        assert (word.value, mask.value) == (w2.value, m2.value) and word.value < 8 and 1 <= bin(mask.value).count("1") <= 4
+        seen.add((word.value, mask.value))
+    assert len(seen) > 1900 and len({w for w, _ in seen}) == 8

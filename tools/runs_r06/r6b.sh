@@ -1,17 +1,10 @@
 #!/bin/bash
-# round 6: rocprofv3 evidence for the kernels of the merged tree (profiles/r06_v1; afterwards tools/profile_collect.sh r06_v1 <name> for each).
-# Two calls: "r6b.sh big" = human, human_runs, human_repeats;  "r6b.sh small" = c4, c4r, c2, c3_fused
-( while sleep 60; do echo "... $(date +%T)"; done ) & hb=$!
-if [ "$1" = big ]; then
-  bash tools/profile_bench.sh r06_v1 human 2>&1 | tail -2 &&
-  PROF_PASSES="stats FETCH_SIZE WRITE_SIZE TCC_HIT_sum" bash tools/profile_bench.sh r06_v1 human_runs --blocks runs --queries 100000000 2>&1 | tail -2 &&
-  PROF_PASSES="stats FETCH_SIZE WRITE_SIZE TCC_HIT_sum" bash tools/profile_bench.sh r06_v1 human_repeats --genome repeats 2>&1 | tail -2
-else
-  bash tools/profile_bench.sh r06_v1 c4_reads --workload c4 2>&1 | tail -2 &&
-  bash tools/profile_bench.sh r06_v1 c4r_reads --workload c4r 2>&1 | tail -2 &&
-  bash tools/profile_bench.sh r06_v1 c2 --workload c2 2>&1 | tail -2 &&
-  bash tools/profile_bench.sh r06_v1 c3_fused --workload c3 --fused 2>&1 | tail -2
-fi
-rc=$?
-kill $hb
-exit $rc
+# round 6: the two-tier sparse table and the sparse table behind run blocks, first time on a GPU -- their own tests, then the C4-sized one, then bench smoke
+out=gpurun_out/r6b; mkdir -p $out
+python -c "import __graft_entry__ as g; g.build()" > $out/build.log 2>&1 || { tail -5 $out/build.log; exit 1; }
+timeout -k 10 500 python -m pytest tests/test_gpu_sparse.py -x -q -m gpu > $out/sparse.log 2>&1; rc=$?; echo "sparse tests rc=$rc"; tail -3 $out/sparse.log
+[ $rc -eq 0 ] || { grep -n "Error\|error\|assert \|FAILED\|^E " $out/sparse.log | head -40; exit $rc; }
+timeout -k 10 400 python -m pytest tests/test_gpu_config_sizes.py -x -q -m gpu -k "c4_real" > $out/c4.log 2>&1; rc=$?; echo "c4 test rc=$rc"; tail -3 $out/c4.log
+[ $rc -eq 0 ] || { grep -n "Error\|error\|assert \|FAILED\|^E " $out/c4.log | head -40; exit $rc; }
+timeout -k 10 500 python -m pytest tests/test_bench_smoke.py -x -q -m gpu > $out/smoke.log 2>&1; rc=$?; echo "bench smoke rc=$rc"; tail -3 $out/smoke.log
+[ $rc -eq 0 ] || { grep -n "Error\|error\|assert \|FAILED\|^E " $out/smoke.log | head -40; exit $rc; }
