@@ -1500,6 +1500,65 @@ def main():
                     result["c4_budgeted"] = line_b
                 except msbwt.MsbwtError as e:
                     result["c4_budgeted"] = {"error": repr(e), "modes": modes}
+            # The drop-in caller's path (a Rust caller behind the trait hands over HOST slices: msbwt_rle_count_kmers, ..._packed): the same
+            # 31-mers from host memory and their counts back to it, PCIe copies inside the timed region -- never `value` -- next to what this
+            # box's PCIe link moves when both directions are busy (pinned buffers of the same sizes, two streams).
+            if name == "c4" and not args.no_variants:
+                try:
+                    nh = min(n4, 30_000_000)
+                    h_q = d_q4[:nh].cpu().numpy()
+                    exp_h = o4[:nh].cpu().numpy().astype(np.uint64)
+                    out_h = np.zeros(nh, dtype=np.uint64)     # touched: no first-touch page faults inside the timed region
+
+                    def best_of(fn, reps=3):
+                        fn()
+                        best = None
+                        for _ in range(reps):
+                            t_h = time.perf_counter()
+                            fn()
+                            dt_h = time.perf_counter() - t_h
+                            best = dt_h if best is None else min(best, dt_h)
+                        return best
+
+                    host = {"queries": nh, "k": 31}
+                    t_b = best_of(lambda: bwt4.count_kmers(h_q, out=out_h))
+                    host.update({"bytes_qps": nh / t_b, "bytes_GBps": (h_q.nbytes + out_h.nbytes) / t_b / 1e9, "bytes_equal": bool(np.array_equal(out_h, exp_h))})
+                    w_h = msbwt.rle_bwt.pack_2bit(h_q)
+                    for bits, tag in ((64, "packed_u64"), (32, "packed_u32")):
+                        o_p = np.zeros(nh, dtype=np.uint64 if bits == 64 else np.uint32)
+                        t_p = best_of(lambda: bwt4.count_kmers_packed(w_h, 31, count_bits=bits, out=o_p))
+                        host.update({tag + "_qps": nh / t_p, tag + "_GBps": (w_h.nbytes + o_p.nbytes) / t_p / 1e9,
+                                     tag + "_equal": bool(np.array_equal(o_p.astype(np.uint64), exp_h))})
+                    # the link itself: H2D of the query bytes and D2H of the counts at the same time, pinned
+                    for tag, n_in, n_out in (("pcie_bytes_shape", h_q.nbytes, 8 * nh), ("pcie_packed_u32_shape", w_h.nbytes, 4 * nh)):
+                        hin, hout = torch.empty(n_in, dtype=torch.uint8).pin_memory(), torch.empty(n_out, dtype=torch.uint8).pin_memory()
+                        din, dout = torch.empty(n_in, dtype=torch.uint8, device=dev), torch.zeros(n_out, dtype=torch.uint8, device=dev)
+                        s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+
+                        def both():
+                            with torch.cuda.stream(s_in):
+                                din.copy_(hin, non_blocking=True)
+                            with torch.cuda.stream(s_out):
+                                hout.copy_(dout, non_blocking=True)
+                            s_in.synchronize()
+                            s_out.synchronize()
+                        host[tag + "_GBps"] = (n_in + n_out) / best_of(both) / 1e9
+                        del hin, hout, din, dout
+                    host["pcie_both_ways_GBps"] = host["pcie_bytes_shape_GBps"]
+                    host["fraction_of_the_link"] = {"bytes": host["bytes_GBps"] / host["pcie_bytes_shape_GBps"],
+                                                    "packed_u32": host["packed_u32_GBps"] / host["pcie_packed_u32_shape_GBps"]}
+                    host["note"] = ("msbwt_rle_count_kmers / msbwt_rle_count_kmers_packed on HOST arrays of %d read-derived 31-mers of this line (pinned three-stage pipeline, "
+                                    "csrc/host_pipeline.hpp), best of 3; *_GBps = bytes in + bytes out per second; pcie_*_shape_GBps = what the link moves with "
+                                    "pinned buffers of the same sizes copied in both directions at once: the host path is bound by the link (and by the pageable-to-pinned "
+                                    "staging copy on the host), not by the kernel" % nh)
+                    if not (host["bytes_equal"] and host["packed_u64_equal"] and host["packed_u32_equal"]):
+                        log("PARITY FAILURE: the host-pointer entry points count differently from the device path")
+                        result["value"] = None
+                        rc = 1
+                    result["host_api"] = host
+                    del h_q, w_h, out_h
+                except Exception as e:  # noqa: BLE001  (a measurement aid: never the reason a bench line is lost)
+                    result["host_api"] = {"error": repr(e)}
             if not args.no_oracle:
                 from oracle import oracle as orc
                 ref4 = orc.OracleRleBWT(8)

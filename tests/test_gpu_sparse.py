@@ -384,9 +384,9 @@ def test_two_tier_table_holds_the_solid_suffixes_and_filters_the_ones_that_occur
             assert got in (None, ("filter",))
             false_pos += got is not None
     assert false_pos < 0.1 * len(absent)
-    # the shallower levels' counts of suffixes that occur once
+    # the shallower levels' counts of suffixes that occur once (the level the expansion starts from is only seeded, not examined)
     for d, n in info["once"].items():
-        if 4 <= d <= depth and d in info["distinct"]:
+        if max(4, info["parent_depth"] + 1) <= d <= depth and d in info["distinct"]:
             w = np.lib.stride_tricks.sliding_window_view(reads, d, axis=1).reshape(-1, d)
             _, cnt = np.unique(w, axis=0, return_counts=True)
             assert n == int((cnt == 1).sum()), d

@@ -49,6 +49,9 @@ def main():
         total = o.get_total_size()
         b = msbwt.RleBWT()
         b.set_block_format("runs" if rng.random() < 0.25 else "planes")   # the memory-lean format now and then
+        # (run blocks build their sparse table at load time only -- round 6 -- so its depth and form are drawn before the load)
+        b.set_sparse_table(int(rng.choice([-1, -1, 0, 16, 17, 19, 20, 23, 25, 28])))
+        b.set_sparse_tiers(int(rng.choice([-1, 0, 1, 1])))
         b.load_vector(rle)
         assert b.get_total_size() == total
         for _ in range(3):
@@ -62,6 +65,7 @@ def main():
             b.set_table_side(int(rng.integers(0, 2)))              # round 4: escape lines from the side array, or restarted
             b.set_batch_order(int(rng.choice([-1, 0, 1, 1])))      # ... the library's own ordering pass forced on half the time
             b.set_sparse_table(int(rng.choice([-1, -1, 0, 16, 17, 18, 19, 20, 23, 25, 27, 28, 30, 31])))   # round 5: sparse suffix table: automatic, off, or a depth
+            b.set_sparse_tiers(int(rng.choice([-1, 0, 1, 1])))     # round 6: the two-tier form of the sparse table (filter -> direct table) forced on half the time
             b.set_line_streaming(int(rng.choice([-1, 0, 1, 1])))   # ... kernel revision 3: the non-temporal line loads forced on half the time
             if rng.random() < 0.15:                                # ... and a memory budget now and then (rebuilds the optional structures)
                 b.set_memory_budget(int(b.device_bytes() * float(rng.choice([0.2, 0.5, 0.9]))) + 1)
