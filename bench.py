@@ -323,7 +323,7 @@ def live_pmc_traffic(extra_args, queries, kernel_substr="k_count_kmers", counter
     for counter in counters:
         out_dir = tempfile.mkdtemp(prefix="msbwt_pmc_", dir="/tmp")
         cmd = [prof, "--pmc", counter, "--kernel-include-regex", kernel_substr, "--kernel-trace", "--output-format", "csv", "-d", out_dir, "-o", "run",
-               "--", sys.executable, os.path.abspath(__file__), "--no-oracle", "--no-c5", "--no-c4", "--no-live-pmc", "--no-sorted", "--queries", str(queries),
+               "--", sys.executable, os.path.abspath(__file__), "--no-oracle", "--no-c5", "--no-c4", "--no-live-pmc", "--no-sorted", "--no-variants", "--queries", str(queries),
                "--steps", "2", "--warmup", "1"] + list(extra_args)
         try:
             done = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=patience)

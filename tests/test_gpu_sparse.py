@@ -436,13 +436,13 @@ def test_counts_with_the_two_tier_table_equal_the_oracle(depth, stride, direct, 
     # many more tiles than resident waves: most lookups ride along with the search of the tile before theirs (the other way into the filter)
     k = 31
     windows = np.lib.stride_tricks.sliding_window_view(reads, k, axis=1).reshape(-1, k)
-    q = np.ascontiguousarray(np.concatenate([windows] * 6 + [random_kmers(9, 20000, k)]))
+    q = np.ascontiguousarray(np.concatenate([windows] * 12 + [random_kmers(9, 20000, k)]))
     b.set_search_counters(True)
     got = b.count_kmers(q)
     cnt = b.search_counters(0)
     b.set_search_counters(False)
     assert np.array_equal(got, ref.count_kmers(q))
-    assert cnt["table_rides"] > 0.2 * 6 * len(windows) and cnt["tier_fallbacks"] > 1000
+    assert cnt["table_rides"] > 0.1 * 12 * len(windows) and cnt["tier_fallbacks"] > 1000, cnt
     # the fused read windows, both strands
     k = max(depth, 25)
     fwd, rc = b.count_read_kmers(reads[:200], k, ascii=False, forward=True, revcomp=True)

@@ -14,7 +14,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG/$NAME
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-LEAN="--no-cpu-baseline --no-c5 --no-c4 --no-live-pmc --no-sorted --parity-sample 20000 --stats-sample 200000"
+LEAN="--no-cpu-baseline --no-c5 --no-c4 --no-live-pmc --no-sorted --no-variants --parity-sample 20000 --stats-sample 200000"
 
 # PROF_PASSES (optional): which passes to run, by first word -- default "stats FETCH_SIZE WRITE_SIZE TCC_HIT_sum SQ_WAVE_CYCLES"
 PASSES=${PROF_PASSES:-stats FETCH_SIZE WRITE_SIZE TCC_HIT_sum SQ_WAVE_CYCLES}
