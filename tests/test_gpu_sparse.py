@@ -462,31 +462,31 @@ def test_counts_with_the_two_tier_table_equal_the_oracle(depth, stride, direct, 
 
 
 def test_two_tier_table_with_high_copy_suffixes_and_escape_lines_of_the_direct_table(monkeypatch):
-    """Repeats: wide entries of the two-tier table (side array) AND escape lines of the packed direct table its filter sends queries to."""
-    rng = np.random.default_rng(3)
-    genome = ACGT[rng.integers(0, 4, size=40000)]
-    unit = ACGT[rng.integers(0, 4, size=40)]
-    reads = [genome[s:s + 50] for s in rng.integers(0, len(genome) - 50, size=2500)]
-    reads += [np.concatenate([unit, unit])[o:o + 50] for o in rng.integers(0, 30, size=600)]
-    reads = np.stack(reads)
-    flip = rng.random(reads.shape) < 0.01
-    reads = np.where(flip, ACGT[rng.integers(0, 4, size=reads.shape)], reads)
-    b, ref = load_pair(bwt_of(reads), monkeypatch, 16, MSBWT_SPARSE_TIERS=1, MSBWT_TABLE_DEPTH=3, MSBWT_TABLE_PACKED=1)
+    """Repeats: wide entries of the two-tier table (side array) AND escape lines of the packed direct table its filter sends queries to
+    (a shallow packed table over 4e6 symbols: nearly every line has a delta beyond 16 bits)."""
+    import synth
+    genome = synth.repeat_genome(200_000, 5)
+    reads = synth.reads(genome, 27_000, 150, 6, 0.005)
+    rle = synth.rle_encode(synth.build_msbwt_symbols(reads))
+    b, ref = load_pair(rle, monkeypatch, 16, MSBWT_SPARSE_TIERS=1, MSBWT_TABLE_DEPTH=3, MSBWT_TABLE_PACKED=1)
     info, tinfo = b.sparse_table_info(), b.table_info()
-    assert b.get_sparse_tiers() and info["side_entries"] > 0 and b.get_table_packed() and tinfo["escape_lines"] > 0 and tinfo["side_bytes"] > 0
+    assert b.get_sparse_tiers() and info["side_entries"] > 0 and b.get_table_packed() and b.get_table_depth() == 5
+    assert tinfo["escape_lines"] >= 33 and tinfo["side_bytes"] == tinfo["escape_lines"] * 512
     for k in (16, 31, 40):
-        windows = np.lib.stride_tricks.sliding_window_view(reads, k, axis=1).reshape(-1, k)
-        q = np.ascontiguousarray(np.concatenate([windows] * 3 + [random_kmers(9, 20000, k)]))
+        q = np.ascontiguousarray(np.concatenate([synth.read_kmers(reads, k, limit=150_000, seed=k), random_kmers(9, 20000, k)]))
         b.set_search_counters(True)
         got = b.count_kmers(q)
         cnt = b.search_counters(0)
         b.set_search_counters(False)
-        assert np.array_equal(got, ref.count_kmers(q)), k
-        assert cnt["tier_fallbacks"] > 0 and cnt["escape_queries"] > 0
+        exp = ref.count_kmers(q)
+        assert np.array_equal(got, exp), k
+        assert (exp == 1).sum() > 1000 and exp.max() >= 255
+        # every lookup that ended in the filter read an escape line of the direct table and then its side entry
+        assert cnt["tier_fallbacks"] > 1000 and cnt["escape_queries"] >= cnt["tier_fallbacks"] * 0.9, cnt
     # without the direct table's side array the two-tier form is not built (an escape line could not be followed from the filter's path)
     b.set_table_side(0)
-    assert not b.get_sparse_tiers()
-    q = np.ascontiguousarray(np.lib.stride_tricks.sliding_window_view(reads, 31, axis=1).reshape(-1, 31)[:20000])
+    assert not b.get_sparse_tiers() and b.get_sparse_table() == 16
+    q = synth.read_kmers(reads, 31, limit=50_000, seed=3)
     assert np.array_equal(b.count_kmers(q), ref.count_kmers(q))
 
 
