@@ -281,7 +281,11 @@ int msbwt_rle_get_table_packed(const msbwt_rle *bwt);
  * [4] entries in the side array, [5] its bytes, [6] entries displaced to a later bucket, [7] depth of the direct table the build
  * started from, [9] buckets a lookup may go beyond its own, [10 + d] DISTINCT d-symbol suffixes that occur (d = 0..31; 0 where the
  * build did not pass: it advances two symbols at a time), [45 + d] of which 255 or more wide, [80 + d] of which exactly 1 wide (suffixes
- * that occur once: on reads with errors, mostly error k-mers), [8] 1 = the table is of the two-tier form, [42] suffixes in its filters.
+ * that occur once: on reads with errors, mostly error k-mers), [8] 1 = the table is of the two-tier form, [42] suffixes in its filters,
+ * [43] depth of the SECOND, shallower level (0 = none) and [44] its bytes: with k undeclared the table is 23 deep and serves k >= 23; where
+ * the deep direct table of an index without a sparse table (packed depth 17) does not fit beside it but a table of the 17-symbol suffixes
+ * does, that one is built as well and serves 17 <= k < 23 (MSBWT_SPARSE_SECOND=0: never), so that no k loses to the index without a
+ * sparse table.
  * The counts are kept even when no table was built.
  * TWO-TIER form (msbwt_rle_set_sparse_tiers; rust-msbwt_amd/csrc/sparse_table.hpp): the complete table's size follows the distinct
  * suffixes, and on reads WITH errors most of those occur once (a 30x human read set with 0.5 % substitutions: 1.3e10 distinct 23-mers,

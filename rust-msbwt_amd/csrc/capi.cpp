@@ -65,6 +65,14 @@ struct msbwt_rle {
     uint32_t sparse_nbuckets = 0, sparse_probe = 0;
     int sparse_depth = 0;
     bool sparse_tier = false;        // the table in HBM is of the two-tier form (entries for the suffixes at least 2 wide, filter bits for the rest)
+    // second, shallower sparse table (round 6; k undeclared): serves the queries shorter than the first one's entries (17 <= k < 23), which would
+    // otherwise fall to the direct table -- shallow beside a sparse table -- and lose 1.5-2.5 x against the index without one
+    void *d_sparse2 = nullptr, *d_sparse2_side = nullptr;
+    uint64_t sparse2_bytes = 0, sparse2_side_bytes = 0, sparse2_entries = 0;
+    uint32_t sparse2_nbuckets = 0, sparse2_probe = 0;
+    int sparse2_depth = 0;
+    bool sparse2_tier = false;
+    int wanted_second = -1;          // -1 = automatic (k undeclared, the deep direct table does not fit, this one does), 0 = never
     int wanted_tiers = -1;           // -1 = two-tier where the complete table of a depth does not fit, 0 = complete tables only, 1 = two-tier only
     int wanted_streaming = -1;       // index lines fetched non-temporally: -1 = when the random-access arrays dwarf the caches, 0 = never, 1 = always
     int wanted_sparse = -1;          // -1 = automatic (beside a pair index, as deep as the data and HBM allow, at most 23 -- or what query_length says), 0 = off, 16..28 = that depth
@@ -206,6 +214,13 @@ void release_sparse(msbwt_rle *h) {
     h->sparse_depth = 0;
     h->sparse_tier = false;
     h->sparse_report = SparseBuildReport{};
+    if (h->d_sparse2) (void)hipFree(h->d_sparse2);
+    if (h->d_sparse2_side) (void)hipFree(h->d_sparse2_side);
+    h->d_sparse2 = h->d_sparse2_side = nullptr;
+    h->sparse2_bytes = h->sparse2_side_bytes = h->sparse2_entries = 0;
+    h->sparse2_nbuckets = h->sparse2_probe = 0;
+    h->sparse2_depth = 0;
+    h->sparse2_tier = false;
 }
 
 void release_index(msbwt_rle *h) {
@@ -264,6 +279,14 @@ IndexView view_of(msbwt_rle *h) {
         v.sparse.probe = h->sparse_probe;
         v.sparse.side = h->d_sparse_side;
         v.sparse.tier = h->sparse_tier ? 1u : 0u;
+        if (h->d_sparse2) {
+            v.sparse2.lines = h->d_sparse2;
+            v.sparse2.nbuckets = h->sparse2_nbuckets;
+            v.sparse2.depth = uint32_t(h->sparse2_depth);
+            v.sparse2.probe = h->sparse2_probe;
+            v.sparse2.side = h->d_sparse2_side;
+            v.sparse2.tier = h->sparse2_tier ? 1u : 0u;
+        }
     }
     v.debug = h->d_flags ? reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(h->d_flags) + 64) : nullptr;
     return v;  // tile_counter: with_tickets()
@@ -394,7 +417,19 @@ int rebuild_filter(msbwt_rle *h) {
 // Optional structure: when nothing fits (or a step fails for want of memory) the handle simply has none -- unless a depth was
 // asked for explicitly, which is then an error.  keep_free: bytes that what is built afterwards (the packed direct table) still
 // needs; allowance: what a memory budget leaves for this table (kNoBudget: none in force).
-int build_sparse(msbwt_rle *h, uint64_t keep_free, uint64_t allowance) {
+// deep_direct_depth: the flat depth of the DEEP direct table that is kept beside the sparse table when HBM is plentiful (rebuild_table; 0 =
+// not in question) -- where that one fits no second sparse level is built.
+constexpr int kSparseSecondDepth = 17;  // entries of the second, shallower level (what the packed direct table of round 4 reached)
+
+bool deep_direct_fits(const msbwt_rle *h, int flat_depth_wanted) {
+    if (flat_depth_wanted <= 0 || flat_depth_wanted + 2 > 18 || h->planned) return false;
+    size_t free_b = 0, total_b = 0;
+    const uint64_t flat_deep = (uint64_t(1) << (2 * flat_depth_wanted)) * 16, packed = packed_table_bytes(flat_depth_wanted + 2);
+    const uint64_t need = flat_deep + packed + packed / 8;  // (the packer's side array of escape lines: an eighth at most in practice)
+    return hipMemGetInfo(&free_b, &total_b) == hipSuccess && uint64_t(free_b) + h->table_bytes >= need + uint64_t(total_b) / 8;
+}
+
+int build_sparse(msbwt_rle *h, uint64_t keep_free, uint64_t allowance, int deep_direct_depth = 0) {
     release_sparse(h);
     const bool verbose = std::getenv("MSBWT_VERBOSE") != nullptr;
     const bool explicit_depth = h->wanted_sparse > 0;
@@ -489,6 +524,50 @@ int build_sparse(msbwt_rle *h, uint64_t keep_free, uint64_t allowance) {
         std::fprintf(stderr, "[msbwt] sparse table: depth %d%s, %llu entries in %u buckets (%.2f per bucket, %llu displaced, %llu in the side array, %llu in the filters), %.2f GB\n", chosen,
                      choice.tier ? " two-tier" : "", (unsigned long long)rep.entries, h->sparse_nbuckets, double(rep.entries) / double(nbuckets), (unsigned long long)rep.displaced,
                      (unsigned long long)rep.nescapes, (unsigned long long)rep.filtered, double(h->sparse_bytes + h->sparse_side_bytes) / 1e9);
+    // ---- a second, shallower level for the queries this table is too deep for (sparse_for, kernels.hpp) ----------------------------------
+    // With k undeclared the table above is 23 deep and k = 17..22 fall to the direct table, which stays at packed depth 15 beside a sparse
+    // table: measured at human scale (round 6, present k-mers), k = 17 / 19 / 21 run 2.5 / 1.8 / 1.5 x slower than on the index WITHOUT a
+    // sparse table (packed depth 17).  Where the deep direct table itself fits (rebuild_table keeps it then) nothing is needed; otherwise the
+    // same sizing counts and chunk plan fill a table of the suffixes of 17 symbols -- when it fits what is left, an eighth of the device still
+    // free.  A declared k gets none (the caller has said what it will ask), an explicit depth neither.
+    if (!explicit_depth && h->wanted_second != 0 && h->query_length == 0 && chosen > kSparseSecondDepth && !deep_direct_fits(h, deep_direct_depth) &&
+        hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const uint64_t used = h->sparse_bytes + h->sparse_side_bytes;
+        const uint64_t avail2 = std::min<uint64_t>(allowance > used ? allowance - used : 0, uint64_t(free_b) > spare ? uint64_t(free_b) - spare : 0);
+        const SparseChoice second = choose_sparse_depth(rep.distinct, rep.escapes, flat_depth, std::min(kSparseSecondDepth, chosen - 1), avail2, 0, rep.singles, tiers);
+        if (second.depth) {
+            Temps two;  // (its own buffers: the first table's are the handle's by now)
+            SparseBuildReport rep2 = rep;
+            const int probe2 = sparse_probe_limit(second.depth, second.nbuckets);
+            const uint64_t lines2 = second.nbuckets + uint64_t(std::max(probe2, 0)), nside2 = rep.escapes[second.depth];
+            e = probe2 >= 1 ? hipSuccess : hipErrorInvalidValue;
+            if (e == hipSuccess && nside2) e = hipMalloc(&two.side, nside2 * 16);
+            if (e == hipSuccess) e = hipMalloc(&two.lines, lines2 * 128);
+            if (e == hipSuccess) e = hipMalloc(&two.counts, lines2 * sizeof(uint32_t));
+            if (e == hipSuccess)
+                e = sparse_fill(view_of(h), flat, flat_depth, second.depth, second.tier, two.lines, second.nbuckets, uint32_t(probe2), two.side, nside2, two.counts, tmp.work, work_bytes, &rep2,
+                                h->stream);
+            if (e == hipSuccess) {
+                h->d_sparse2 = two.lines;
+                h->d_sparse2_side = two.side;
+                two.lines = two.side = nullptr;
+                h->sparse2_bytes = lines2 * 128;
+                h->sparse2_side_bytes = nside2 * 16;
+                h->sparse2_entries = rep2.entries;
+                h->sparse2_nbuckets = uint32_t(second.nbuckets);
+                h->sparse2_probe = uint32_t(probe2);
+                h->sparse2_depth = second.depth;
+                h->sparse2_tier = second.tier;
+                if (verbose)
+                    std::fprintf(stderr, "[msbwt] sparse table, second level: depth %d%s, %llu entries in %u buckets, %.2f GB (serves %d <= k < %d)\n", second.depth,
+                                 second.tier ? " two-tier" : "", (unsigned long long)rep2.entries, h->sparse2_nbuckets, double(h->sparse2_bytes + h->sparse2_side_bytes) / 1e9,
+                                 second.depth, chosen);
+            } else {  // optional: an entry without a slot, no memory -- the index simply has no second level
+                (void)hipGetLastError();
+                if (verbose) std::fprintf(stderr, "[msbwt] sparse table, second level: %s -- none built\n", hipGetErrorString(e));
+            }
+        }
+    }
     return MSBWT_OK;
 }
 
@@ -566,7 +645,7 @@ int rebuild_table(msbwt_rle *h, bool allow_sparse = true) {
             const uint64_t held = h->nblocks * kBlockBytes + h->pair_bytes + direct;
             allowance = h->memory_budget > held ? h->memory_budget - held : 0;
         }
-        rc = build_sparse(h, (pack && h->d_table) ? packed_table_bytes(depth + 2) : 0, allowance);
+        rc = build_sparse(h, (pack && h->d_table) ? packed_table_bytes(depth + 2) : 0, allowance, (capped && pack) ? uncapped_depth : 0);
         if (rc) return rc;
         if (!h->d_sparse && capped) {  // no depth fit: the direct table as if there were no sparse one (the distinct counts stay on record)
             const SparseBuildReport counted = h->sparse_report;
@@ -579,22 +658,19 @@ int rebuild_table(msbwt_rle *h, bool allow_sparse = true) {
     // last symbols).  Capped at packed depth 15 those lose against the index without a sparse table (round 6, human scale, present
     // k-mers: k = 17 2.5 x, k = 19 1.8 x, k = 21 1.5 x slower than behind the packed depth-17 table) -- so where HBM is plentiful (a
     // chr20-sized index: 15 GB of 288) the deep direct table is kept AS WELL: nothing is lost for any k.  Not under a memory budget
-    // (the plan has sized the table), and not where it would take the eighth of the device left to the caller's batches.
-    if (capped && h->d_sparse && h->d_table && pack && !h->planned && uncapped_depth + 2 <= 18) {
-        size_t free_b = 0, total_b = 0;
-        const uint64_t flat_deep = (uint64_t(1) << (2 * uncapped_depth)) * 16, need = flat_deep + packed_table_bytes(uncapped_depth + 2) + packed_table_bytes(uncapped_depth + 2) / 8;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && uint64_t(free_b) + h->table_bytes >= need + uint64_t(total_b) / 8) {
-            if (h->d_filter) (void)hipFree(h->d_filter);
-            h->d_filter = nullptr;
-            h->filter_depth = 0;
-            (void)hipFree(h->d_table);
-            h->d_table = nullptr;
-            h->table_depth = 0;
-            h->table_bytes = 0;
-            depth = uncapped_depth;
-            rc = build_flat(depth);
-            if (rc) return rc;
-        }
+    // (the plan has sized the table), and not where it would take the eighth of the device left to the caller's batches (deep_direct_fits);
+    // there build_sparse has tried a second, shallower sparse level instead.
+    if (capped && h->d_sparse && !h->d_sparse2 && h->d_table && pack && deep_direct_fits(h, uncapped_depth)) {
+        if (h->d_filter) (void)hipFree(h->d_filter);
+        h->d_filter = nullptr;
+        h->filter_depth = 0;
+        (void)hipFree(h->d_table);
+        h->d_table = nullptr;
+        h->table_depth = 0;
+        h->table_bytes = 0;
+        depth = uncapped_depth;
+        rc = build_flat(depth);
+        if (rc) return rc;
     }
     if (!h->d_table || !pack) return rc;
     // Packed form, two levels deeper (kernels.hpp, launch_pack_table): every level removes a line fetch
@@ -1236,6 +1312,7 @@ msbwt_rle *msbwt_rle_new_on_device(uint8_t bin_power, int device) {
         const int d = std::strcmp(env, "auto") == 0 ? -1 : std::atoi(env);
         h->wanted_sparse = (d == 0 || d == -1 || (d >= kSparseMinDepth && d <= kSparseMaxDepth)) ? d : -1;
     }
+    if (const char *env = std::getenv("MSBWT_SPARSE_SECOND")) h->wanted_second = std::strcmp(env, "auto") == 0 ? -1 : (std::atoi(env) ? -1 : 0);
     if (const char *env = std::getenv("MSBWT_SPARSE_TIERS")) h->wanted_tiers = std::strcmp(env, "auto") == 0 ? -1 : (std::atoi(env) ? 1 : 0);
     if (const char *env = std::getenv("MSBWT_PAIR_INDEX")) h->wanted_pair = std::atoi(env) ? 1 : 0;
     if (const char *env = std::getenv("MSBWT_PAIR_STRIDE")) h->wanted_pair_stride = std::atoi(env);
@@ -1710,6 +1787,7 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
     h->wanted_table_side = src->wanted_table_side;
     h->wanted_sparse = src->wanted_sparse;
     h->wanted_tiers = src->wanted_tiers;
+    h->wanted_second = src->wanted_second;
     h->query_length = src->query_length;
     h->wanted_streaming = src->wanted_streaming;
     h->wanted_block_format = src->wanted_block_format;
@@ -1755,6 +1833,8 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
         {&src->d_pair_super, &h->d_pair_super, src->d_pair_super ? psz.super_bytes : 0},
         {&src->d_sparse, &h->d_sparse, src->d_sparse ? size_t(src->sparse_bytes) : 0},
         {&src->d_sparse_side, &h->d_sparse_side, src->d_sparse_side ? size_t(src->sparse_side_bytes) : 0},
+        {&src->d_sparse2, &h->d_sparse2, src->d_sparse2 ? size_t(src->sparse2_bytes) : 0},
+        {&src->d_sparse2_side, &h->d_sparse2_side, src->d_sparse2_side ? size_t(src->sparse2_side_bytes) : 0},
     };
     for (const Piece &p : pieces) {
         if (!p.bytes || !*p.from) continue;
@@ -1780,6 +1860,13 @@ msbwt_rle *msbwt_rle_replicate(const msbwt_rle *csrc, int device) {
     h->sparse_depth = src->sparse_depth;
     h->sparse_tier = src->sparse_tier;
     h->sparse_report = src->sparse_report;
+    h->sparse2_bytes = src->sparse2_bytes;
+    h->sparse2_side_bytes = src->sparse2_side_bytes;
+    h->sparse2_entries = src->sparse2_entries;
+    h->sparse2_nbuckets = src->sparse2_nbuckets;
+    h->sparse2_probe = src->sparse2_probe;
+    h->sparse2_depth = src->sparse2_depth;
+    h->sparse2_tier = src->sparse2_tier;
     h->typical_width = src->typical_width;
     h->pair_overlap_bytes = src->pair_overlap_bytes;
     h->filter_depth = src->filter_depth;
@@ -2235,6 +2322,8 @@ int msbwt_rle_sparse_table_info(const msbwt_rle *ch, uint64_t *out) {
         out[8] = h->sparse_tier ? 1 : 0;
         out[9] = h->sparse_probe;
         out[42] = r.filtered;
+        out[43] = uint64_t(h->sparse2_depth);
+        out[44] = h->sparse2_bytes + h->sparse2_side_bytes;
     }
     out[7] = uint64_t(r.parent_depth);
     for (int d = 0; d <= kSparseMaxDepth; ++d) {
@@ -2416,7 +2505,7 @@ int msbwt_rle_search_kernel_for(const msbwt_rle *h, size_t k) {
 uint64_t msbwt_rle_device_bytes(const msbwt_rle *h) {
     if (!h || !h->loaded) return 0;
     return h->nblocks * kBlockBytes + h->overflow_bytes + (h->d_table ? uint64_t(h->table_bytes) + h->table_side_bytes : 0) + h->pair_bytes +
-           (h->d_filter ? (uint64_t(1) << (2 * h->filter_depth)) / 8 : 0) + h->sparse_bytes + h->sparse_side_bytes;
+           (h->d_filter ? (uint64_t(1) << (2 * h->filter_depth)) / 8 : 0) + h->sparse_bytes + h->sparse_side_bytes + h->sparse2_bytes + h->sparse2_side_bytes;
 }
 
 int msbwt_rle_set_kernel_timing(msbwt_rle *h, int enabled) {

@@ -68,12 +68,21 @@ struct IndexView {
     // optional sparse suffix table (sparse_table.hpp): the ranges of the suffixes that occur, deeper than the direct table
     // reaches; the lanes kernel looks up queries of at least its depth there (beside a pair index), shorter ones in `table`
     SparseView sparse;
+    // optional SECOND, shallower sparse table (round 6): serves the queries shorter than the first one's entries -- with k undeclared the
+    // first table is 23 deep, and k = 17..22 would otherwise fall to the direct table, which stays shallow beside a sparse table
+    SparseView sparse2;
 };
 
-inline bool sparse_serves(const IndexView &ix, uint32_t k) {
+// the sparse table that serves k-symbol queries: the deepest one whose entries are no longer than k (nullptr: the direct table)
+inline const SparseView *sparse_for(const IndexView &ix, uint32_t k) {
     // (beside a pair index, or -- round 6 -- on run blocks, whose table was built from pair blocks that are gone again)
-    return ix.sparse.lines != nullptr && (ix.pair_blocks != nullptr || ix.block_format == kBlocksRuns) && k >= ix.sparse.depth;
+    if (ix.pair_blocks == nullptr && ix.block_format != kBlocksRuns) return nullptr;
+    if (ix.sparse.lines != nullptr && k >= ix.sparse.depth) return &ix.sparse;
+    if (ix.sparse2.lines != nullptr && k >= ix.sparse2.depth) return &ix.sparse2;
+    return nullptr;
 }
+
+inline bool sparse_serves(const IndexView &ix, uint32_t k) { return sparse_for(ix, k) != nullptr; }
 
 // indices into IndexView::counters
 enum SearchCounter {

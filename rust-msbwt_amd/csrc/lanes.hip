@@ -1239,8 +1239,10 @@ uint32_t resident_waves() {
 
 template <bool kReads, bool kPair, int kWords, bool kStride96, bool kPacked, int kSparse>
 hipError_t launch_variant(hipStream_t stream, const IndexView &ix, const QuerySource &src, uint32_t *flags) {
-    // (kSparse: the sparse table's lines, depth and side array travel in the direct table's arguments)
-    const uint4 *table = static_cast<const uint4 *>(kSparse ? ix.sparse.lines : ix.table.entries);
+    // (kSparse: the sparse table's lines, depth and side array travel in the direct table's arguments; `sp`: the one of the two that serves this k)
+    const SparseView none{};
+    const SparseView &sp = kSparse && sparse_for(ix, src.k) ? *sparse_for(ix, src.k) : none;
+    const uint4 *table = static_cast<const uint4 *>(kSparse ? sp.lines : ix.table.entries);
     const uint32_t *filter = ix.table.entries ? ix.table.filter : nullptr;
     const uint32_t filter_mask = filter ? uint32_t((1ull << (2 * ix.table.filter_depth)) - 1ull) : 0u;
     const uint64_t tiles = (src.n + kTile - 1) / kTile;
@@ -1255,12 +1257,12 @@ hipError_t launch_variant(hipStream_t stream, const IndexView &ix, const QuerySo
     }
     // tiles per ticket: about eight tickets per wave at least, sixteen tiles at most
     const uint32_t grain = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(16, tiles / (waves * 8))));
-    const uint4 *side = static_cast<const uint4 *>(kSparse ? ix.sparse.side : (table ? ix.table.side : nullptr));
+    const uint4 *side = static_cast<const uint4 *>(kSparse ? sp.side : (table ? ix.table.side : nullptr));
     hipLaunchKernelGGL((k_count_kmers_lanes<kReads, kPair, kWords, kStride96, kPacked, kSparse>), dim3(uint32_t(waves)), dim3(64), 0, stream,
-                       static_cast<const uint4 *>(ix.blocks), ix.total, table, kSparse ? ix.sparse.depth : uint32_t(ix.table.depth), ((!kSparse && ix.table.packed) ? 1u : 0u) | (ix.stream_lines ? 2u : 0u),
+                       static_cast<const uint4 *>(ix.blocks), ix.total, table, kSparse ? sp.depth : uint32_t(ix.table.depth), ((!kSparse && ix.table.packed) ? 1u : 0u) | (ix.stream_lines ? 2u : 0u),
                        filter, filter_mask, side, static_cast<const uint4 *>(ix.pair_blocks), ix.pair_super, src, flags, ix.debug,
                        tickets ? static_cast<unsigned long long *>(ix.tile_counter) : nullptr, grain, waves == 1 ? ix.done : nullptr, ix.done_seq, ix.counters,
-                       uint32_t(ix.block_format), static_cast<const uint4 *>(ix.overflow), ix.sparse.nbuckets, ix.sparse.probe,
+                       uint32_t(ix.block_format), static_cast<const uint4 *>(ix.overflow), sp.nbuckets, sp.probe,
                        // two-tier: the direct table its filter sends queries to (depth | packed << 8), and that table's side array
                        static_cast<const uint4 *>(kSparse == 2 ? ix.table.entries : nullptr),
                        kSparse == 2 && ix.table.entries ? (uint32_t(ix.table.depth) & 0xFFu) | (ix.table.packed ? 0x100u : 0u) : 0u,
@@ -1282,7 +1284,7 @@ template <bool kReads, bool kPacked>
 hipError_t launch_shape(bool pair, bool longk, hipStream_t stream, const IndexView &ix, const QuerySource &src, uint32_t *flags) {
     // the sparse table serves every query that is at least as long as its entries (shorter ones: the direct table)
     if (sparse_serves(ix, src.k))
-        return ix.sparse.tier ? launch_sparse_shape<kReads, kPacked, 2>(pair, longk, stream, ix, src, flags) : launch_sparse_shape<kReads, kPacked, 1>(pair, longk, stream, ix, src, flags);
+        return sparse_for(ix, src.k)->tier ? launch_sparse_shape<kReads, kPacked, 2>(pair, longk, stream, ix, src, flags) : launch_sparse_shape<kReads, kPacked, 1>(pair, longk, stream, ix, src, flags);
     if (!pair) return longk ? launch_variant<kReads, false, 6, false, kPacked, 0>(stream, ix, src, flags) : launch_variant<kReads, false, 3, false, kPacked, 0>(stream, ix, src, flags);
     if (ix.pair_stride96) return longk ? launch_variant<kReads, true, 6, true, kPacked, 0>(stream, ix, src, flags) : launch_variant<kReads, true, 3, true, kPacked, 0>(stream, ix, src, flags);
     return longk ? launch_variant<kReads, true, 6, false, kPacked, 0>(stream, ix, src, flags) : launch_variant<kReads, true, 3, false, kPacked, 0>(stream, ix, src, flags);

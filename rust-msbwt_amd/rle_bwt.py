@@ -343,7 +343,7 @@ class RleBWT(BWT):
             _raise(rc, self._h)
         info = {"depth": int(out[0]), "entries": int(out[1]), "buckets": int(out[2]), "bytes": int(out[3]), "side_entries": int(out[4]),
                 "side_bytes": int(out[5]), "displaced": int(out[6]), "parent_depth": int(out[7]), "two_tier": bool(out[8]), "probe": int(out[9]),
-                "filtered": int(out[42])}
+                "filtered": int(out[42]), "second_depth": int(out[43]), "second_bytes": int(out[44])}
         info["distinct"] = {d: int(out[10 + d]) for d in range(32) if out[10 + d]}
         info["wide"] = {d: int(out[45 + d]) for d in range(32) if out[10 + d]}
         info["once"] = {d: int(out[80 + d]) for d in range(32) if out[10 + d]}

@@ -266,6 +266,15 @@ def test_human_scale_9e10_symbols_against_the_oracle():
         bwt.set_search_kernel(mode)
         got = _count_matrix(torch, dev, bwt, d_q).cpu().numpy().astype(np.uint64)
         assert np.array_equal(got, exp), mode
+    # round 6: k between the direct table's depth and the sparse table's.  With k undeclared a SECOND sparse level (the 17-symbol suffixes,
+    # 39 GB) serves 17 <= k < 23 -- the packed depth-17 direct table does not fit beside the first -- and k = 16 takes the direct table
+    assert info["second_depth"] == 17 and 35e9 < info["second_bytes"] < 45e9 and bwt.device_bytes() < 260e9, info
+    bwt.set_search_kernel("lanes")
+    for kk in (16, 17, 19, 21, 22, 23, 24):
+        short = torch.cat([present[:1_000_000, k - kk:], absent[:200_000, k - kk:]]).contiguous()
+        got = _count_matrix(torch, dev, bwt, short).cpu().numpy().astype(np.uint64)
+        assert np.array_equal(got, ref.count_kmers(short.cpu().numpy(), nthreads=NCPU)), kk
+        assert got[:1_000_000].min() >= 1
     # without the sparse table the loader builds what rounds 2-4 measured: the depth-17 packed direct table (73 GB, 238 GB in all)
     bwt.set_sparse_table(0)
     assert bwt.get_sparse_table() == 0 and bwt.get_table_depth() == 17 and bwt.device_bytes() > 230e9
