@@ -91,21 +91,28 @@ def lookup_depth(bwt, k):
     """Symbols the suffix-table lookup of a k-symbol query stands for on this index: the sparse table's depth when it serves the
     query (k >= its depth, lanes kernel), else the direct table's (0 = none applies)."""
     sparse = bwt.get_sparse_table()
-    if sparse and k >= sparse and bwt.search_kernel_for(k) == "lanes":
-        return sparse
+    if sparse and bwt.search_kernel_for(k) == "lanes":
+        if k >= sparse:
+            return sparse
+        second = bwt.sparse_table_info()["second_depth"]   # round 6: a second, shallower level for the queries the first is too deep for
+        if second and k >= second:
+            return second
     direct = bwt.get_table_depth()
     return direct if k >= direct else 0
 
 
 def kernel_label(bwt, k, fused):
     """Name (as in the rocprofv3 kernel trace) of the kernel the library runs for this index and k:
-    k_count_kmers_lanes<kReads, kPair, kWords, kStride96, kPacked, kSparse> (csrc/lanes.hip)."""
+    k_count_kmers_lanes<kReads, kPair, kWords, kStride96, kPacked, kSparse> (csrc/lanes.hip; kSparse: 0 = direct table, 1 = complete
+    sparse table, 2 = its two-tier form)."""
     which = bwt.search_kernel_for(k)
     reads, words = ("true" if fused else "false"), (3 if k <= 32 else 6)
     if which == "lanes":
         pair, s96 = bwt.get_pair_index(), bwt.get_pair_index() and bwt.get_pair_stride() == 96
-        sparse = bool(bwt.get_sparse_table()) and k >= bwt.get_sparse_table()
-        return "k_count_kmers_lanes<%s,%s,%d,%s,false,%s>" % (reads, "true" if pair else "false", words, "true" if s96 else "false", "true" if sparse else "false")
+        info = bwt.sparse_table_info() if bwt.get_sparse_table() else None
+        served = bool(info) and (k >= info["depth"] or (info["second_depth"] and k >= info["second_depth"]))
+        sparse = 0 if not served else (2 if info["two_tier"] else 1)
+        return "k_count_kmers_lanes<%s,%s,%d,%s,false,%d>" % (reads, "true" if pair else "false", words, "true" if s96 else "false", sparse)
     return "k_count_kmers_tiled<%s,%d>" % (reads, words) if which == "groups" else "k_count_kmers_generic"
 
 

@@ -530,7 +530,9 @@ int build_sparse(msbwt_rle *h, uint64_t keep_free, uint64_t allowance, int deep_
     // sparse table (packed depth 17).  Where the deep direct table itself fits (rebuild_table keeps it then) nothing is needed; otherwise the
     // same sizing counts and chunk plan fill a table of the suffixes of 17 symbols -- when it fits what is left, an eighth of the device still
     // free.  A declared k gets none (the caller has said what it will ask), an explicit depth neither.
-    if (!explicit_depth && h->wanted_second != 0 && h->query_length == 0 && chosen > kSparseSecondDepth && !deep_direct_fits(h, deep_direct_depth) &&
+    // (run blocks are the memory-lean format: no second level there)
+    if (!explicit_depth && h->wanted_second != 0 && h->wanted_block_format == kBlocksPlanes && h->query_length == 0 && chosen > kSparseSecondDepth &&
+        !deep_direct_fits(h, deep_direct_depth) &&
         hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         const uint64_t used = h->sparse_bytes + h->sparse_side_bytes;
         const uint64_t avail2 = std::min<uint64_t>(allowance > used ? allowance - used : 0, uint64_t(free_b) > spare ? uint64_t(free_b) - spare : 0);

@@ -495,7 +495,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     // two-tier: the direct table a lookup falls back to -- dd symbols deep (0: none, such a query searches from [0, total)), packed or flat
     const uint32_t dd = kTier ? (dinfo & 0xFFu) : 0u;
     const bool dpacked = kTier && ((dinfo >> 8) & 1u) != 0u;
-    const uint32_t dkey_mask = dd >= 16u ? ~0u : ((1u << (2u * dd)) - 1u);
+    const uint64_t dkey_mask = (1ull << (2u * dd)) - 1ull;  // (dd <= 18: the direct table's index takes up to 36 bits -- a query carries its LINE there (32 bits) and its slot in the line (5 bits))
     auto scan_bucket = [&](uint32_t slot, uint64_t want, uint64_t &tl, uint32_t &tw, uint32_t &header, bool &maybe) -> bool {  // want: the tag, up to 40 bits
         maybe = false;
         if constexpr (kTier && kWords == 6) {
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     bool have = false;
     bool tmode = false;   // kSparse: the query is still to be looked up -- l = its bucket, h = its tag, the next step fetches the bucket line
     uint32_t tdist = 0;   // ... and how many buckets beyond its own the lookup has gone
-    bool tmaybe = false;  // kTier: ... and its own bucket's filter holds its bits (l >> 32 = its index into the direct table meanwhile)
+    bool tmaybe = false;  // kTier: ... and its own bucket's filter holds its bits (l >> 32 = its line of the direct table meanwhile, tdist >> 8 its slot there)
     bool dmode = false;   // kTier: the lookup ended in the filter -- l = the query's line of the DIRECT table, h = its slot there, fetched by the next step
     uint32_t ovf_l = 0, ovf_h = 0;  // run blocks: 1 + the overflow plane block this bound is to be ranked from (0: its run block)
     uint64_t l = 0, h = 0;
@@ -689,8 +689,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 lookup = true;
             }
             if (kTier && prep_kind == 5u) {  // its lookup rode along and ended in the filter: the direct table's line is its first step
-                pl = dpacked ? prep_entry.w / kPackedPerLine : (prep_entry.w >> 3);
-                ph = dpacked ? prep_entry.w - uint32_t(pl) * kPackedPerLine : (prep_entry.w & 7u);
+                pl = prep_entry.w;
+                ph = (prep_entry.z >> 10) & 31u;
                 skip = dd;
                 lookup = true;
             }
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 it.l_lo = uint32_t(pl);
                 it.h_lo = uint32_t(ph);
                 it.meta = uint32_t(pl >> 32) | (uint32_t(ph >> 32) << 8) | (prep_rem << 16) | (lane << 24);  // l, h < 2^40; rem <= 64
-                if (kSparse && lookup) it.meta = prep_entry.z | (prep_rem << 16) | (lane << 24) | (1u << 23);  // (z: buckets gone beyond its own so far, and the tag's high byte -- two-tier: bit 8 = direct-table lookup, bit 9 = in the filter)
+                if (kSparse && lookup) it.meta = prep_entry.z | (prep_rem << 16) | (lane << 24) | (1u << 23);  // (z: buckets gone beyond its own so far, and the tag's high byte -- two-tier: bit 8 = direct-table lookup, bit 9 = in the filter, bits 10..14 = slot in the direct table's line)
 #pragma unroll
                 for (int i = 0; i < kWords; ++i) it.w[i] = prep_w[i];
                 if constexpr (kPacked) it.extra[RingItem::kOutAt] = prep_out;
@@ -778,6 +778,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                     if (tmode) {
                         h = it.h_lo;  // the tag (at most 32 bits), or the slot in the direct table's line
                         l = dmode ? uint64_t(it.l_lo) : (uint64_t(it.extra[RingItem::kDkeyAt]) << 32) | it.l_lo;
+                        tdist |= ((it.meta >> 10) & 31u) << 8;  // the slot travels beside the distance
                         tmode = !dmode;
                     }
                 }
@@ -878,7 +879,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                             prep_entry.x = sparse_bucket(x, 2u * depth, sparse_nbuckets);
                             prep_entry.y = sparse_tag(x, depth);
                             prep_entry.z = sparse_tag_hi(x, depth) << 8;  // low byte: buckets gone beyond its own; next byte: bits 32..39 of the tag (xwide layout; else 0)
-                            if constexpr (kTier) prep_entry.w = uint32_t(pq.tidx) & dkey_mask;  // where the direct table keeps this query's suffix
+                            if constexpr (kTier) {  // where the direct table keeps this query's suffix: line (w) and slot in it (z, bits 10..14)
+                                const uint64_t dk = pq.tidx & dkey_mask, dline = dpacked ? dk / kPackedPerLine : dk >> 3;
+                                prep_entry.w = uint32_t(dline);
+                                prep_entry.z |= uint32_t(dk - dline * (dpacked ? uint64_t(kPackedPerLine) : 8ull)) << 10;
+                            }
                             prep_kind = 3;
                         } else {
                             prep_entry = table_fetch(env, pq.tidx);  // stays in flight: consumed in step A of a later iteration
@@ -1059,7 +1064,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 uint32_t width = 0, header = 0;
                 bool maybe = false;
                 const bool hit = scan_bucket(slot_l, h, tl, width, header, maybe);
-                if (kTier && !hit && tdist == 0u && maybe) tmaybe = true;  // its own bucket's filter holds its bits
+                if (kTier && !hit && (tdist & 0xFFu) == 0u && maybe) tmaybe = true;  // its own bucket's filter holds its bits
                 bool fell = false;
                 nl = nh = 0;
                 step_done = false;
@@ -1080,17 +1085,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                         store_count<kReads>(src, qid, h - l);
                         have = false;
                     }
-                } else if (header > sparse_nslots && tdist < sparse_probe) {  // entries of this bucket were displaced: the next one
+                } else if (header > sparse_nslots && (kTier ? (tdist & 0xFFu) : tdist) < sparse_probe) {  // entries of this bucket were displaced: the next one
                     ++l;
                     ++tdist;
                 } else if (kTier && tmaybe) {  // no entry, but the filter knows it (occurs once, or a false positive): the direct table's path
-                    const uint32_t dkey = uint32_t(l >> 32);
                     tmode = false;
                     fell = true;
                     if (dd != 0u) {
                         dmode = true;
-                        l = dpacked ? dkey / kPackedPerLine : (dkey >> 3);
-                        h = dpacked ? dkey - uint32_t(l) * kPackedPerLine : (dkey & 7u);
+                        h = tdist >> 8;
+                        l = l >> 32;
                     } else {  // no direct table: from [0, total) (w and rem were never cut)
                         l = 0;
                         h = total;

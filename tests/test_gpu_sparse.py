@@ -392,7 +392,7 @@ def test_two_tier_table_holds_the_solid_suffixes_and_filters_the_ones_that_occur
             assert n == int((cnt == 1).sum()), d
 
 
-@pytest.mark.parametrize("direct", ["packed", "flat", "none"])
+@pytest.mark.parametrize("direct", ["packed", "flat", "none", "deep"])
 @pytest.mark.parametrize("stride", [96, 128])
 @pytest.mark.parametrize("depth", [16, 19, 23, 25, 28])
 def test_counts_with_the_two_tier_table_equal_the_oracle(depth, stride, direct, monkeypatch):
@@ -400,7 +400,14 @@ def test_counts_with_the_two_tier_table_equal_the_oracle(depth, stride, direct, 
     on through the direct table -- packed, flat, or none at all (from [0, total)) -- and the search."""
     if direct != "packed" and (stride == 128 or depth in (19, 28)):
         pytest.skip("the direct-table variants are covered at stride 96, depths 16 / 23 / 25")
+    if direct == "deep" and depth != 23:
+        pytest.skip("the deep direct table (73 GB) once")
     env = {"MSBWT_SPARSE_TIERS": 1, "MSBWT_PAIR_STRIDE": stride}
+    if direct == "deep":   # packed depth 17, what a chr20-sized index keeps beside its sparse table: its index takes 34 bits
+        import torch
+        if torch.cuda.mem_get_info(0)[0] < 120 * 10**9:
+            pytest.skip("needs 120 GB of free HBM")
+        env.update({"MSBWT_TABLE_DEPTH": 15, "MSBWT_TABLE_PACKED": 1})
     if direct == "flat":
         env["MSBWT_TABLE_PACKED"] = 0
     if direct == "none":
@@ -408,7 +415,8 @@ def test_counts_with_the_two_tier_table_equal_the_oracle(depth, stride, direct, 
     reads = read_set(121 + depth, 5000, 900, 80, repeats=6, err=0.01)
     b, ref = load_pair(bwt_of(reads), monkeypatch, depth, **env)
     assert b.get_sparse_table() == depth and b.get_sparse_tiers() and b.get_pair_stride() == stride
-    assert (b.get_table_depth() == 0) == (direct == "none") and (b.get_table_packed() if direct == "packed" else not b.get_table_packed())
+    assert (b.get_table_depth() == 0) == (direct == "none") and (b.get_table_packed() if direct in ("packed", "deep") else not b.get_table_packed())
+    assert direct != "deep" or b.get_table_depth() == 17
     rng = np.random.default_rng(depth)
     for k in [depth, depth + 1, depth + 2, 31, 32, 33, 47, 64]:
         if k < depth or k > 80:
