@@ -806,8 +806,11 @@ int build_sparse_for_runs(msbwt_rle *h) {
         h->table_bytes = tab ? parent_bytes : 0;
         h->table_packed = false;
     }
-    // what the budget leaves once the run blocks and their (flat) direct table are paid for; the conversion's peak stays free
-    uint64_t allowance = kNoBudget;
+    // what the budget leaves once the run blocks and their (flat) direct table are paid for; the conversion's peak stays free.  Run blocks
+    // are the memory-LEAN format: left to itself the table may take twice what the blocks take and no more (human scale: 42 GB beside 27 GB
+    // of run blocks -- lines per query halve; a 3e7-symbol stream, whose depth-23 table the tags would force to 4.3 GB: none) -- an explicit
+    // depth or a memory budget says otherwise.
+    uint64_t allowance = h->wanted_sparse < 0 ? 2 * run_peak : kNoBudget;
     if (h->memory_budget) {
         const uint64_t held = run_peak + parent_bytes;
         allowance = h->memory_budget > held ? h->memory_budget - held : 0;
