@@ -1038,7 +1038,8 @@ def test_run_block_format_is_selectable_and_lean():
         b.set_pair_index(0)
         b.load_vector(rle)
         assert b.get_block_format() == fmt and b.get_total_size() == total
-        sizes[fmt] = b.device_bytes()
+        info = b.sparse_table_info()   # (the `sparse` pass of this file asks for a depth-16 table explicitly: run blocks get one too since round 6 -- not counted here)
+        sizes[fmt] = b.device_bytes() - info["bytes"] - info["side_bytes"] - info["second_bytes"]
         assert np.array_equal(b.count_kmers(q1), exp[0])
         assert np.array_equal(b.count_kmers(q2), exp[1])
         b.set_table_depth(6)
@@ -1071,7 +1072,9 @@ def test_run_blocks_fall_back_to_the_host_builder_when_the_device_peak_does_not_
         b.load_vector(rle)
         assert b.get_block_format() == "runs" and b.get_total_size() == total
         assert np.array_equal(b.count_kmers(q), exp)
-        sizes.append(b.device_bytes())
+        info = b.sparse_table_info()   # (a sparse table -- the `sparse` pass asks for one -- is built from the device builder's plane blocks only)
+        assert free is None or info["depth"] == 0
+        sizes.append(b.device_bytes() - info["bytes"] - info["side_bytes"] - info["second_bytes"])
     assert sizes[0] == sizes[1]
     assert msbwt._lib.lib().msbwt_run_build_fits_device(total, int(0.6 * total)) == 0
 
