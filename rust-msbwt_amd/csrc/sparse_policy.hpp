@@ -47,7 +47,8 @@ inline SparseChoice choose_sparse_depth(const uint64_t *distinct, const uint64_t
     for (int d = std::min(max_depth, kSparseMaxDepth); d >= kSparseMinDepth && d > parent_depth; --d) {
         if (explicit_depth ? d != explicit_depth : distinct[d] == 0) continue;  // not a level of the pass (the other parity), or nothing occurs
         for (int tier = 0; tier <= 1; ++tier) {
-            if (tier ? (tiers == 0 || singles == nullptr || d > kTierMaxDepth) : tiers == 1) continue;
+            // (tiers = 1 asks for the two-tier form wherever it exists: depths 30..31 have none and stay complete)
+            if (tier ? (tiers == 0 || singles == nullptr || d > kTierMaxDepth) : (tiers == 1 && singles != nullptr && d <= kTierMaxDepth)) continue;
             const uint64_t single = tier ? std::min(singles[d], distinct[d]) : 0, entries = distinct[d] - single;
             const uint64_t needed = uint64_t(double(entries) / sparse_load(d, tier != 0)) + 1;
             const uint64_t nb = tier ? sparse_tier_buckets_for(d, entries, single) : sparse_buckets_for(d, distinct[d]);
