@@ -620,6 +620,9 @@ int rebuild_table(msbwt_rle *h, bool allow_sparse = true) {
         depth = kDirectDepthBesideSparse;
         capped = true;
     }
+    // (run blocks behind a sparse table -- built at load time, build_sparse_for_runs: the lean format keeps its flat direct table at depth 13,
+    // 1 GB instead of 17, for the queries the sparse table does not serve)
+    if (h->block_format == kBlocksRuns && h->d_sparse && automatic && depth > kDirectDepthBesideSparse) depth = kDirectDepthBesideSparse;
     if (depth <= 0 && !try_sparse) return MSBWT_OK;
     if (depth + 2 > 18) pack = false;
     auto build_flat = [&](int d) -> int {
@@ -752,7 +755,17 @@ int build_sparse_for_runs(msbwt_rle *h) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return MSBWT_OK;
     const PairIndexSizes sz = pair_index_sizes(h->nblocks, 128);
-    const uint64_t run_bytes = run_block_count(h->totals.total) * kBlockBytes, run_peak = run_bytes + run_bytes / 8;  // (what the conversion will need beside the planes)
+    // what the conversion will need beside the planes: the run blocks and their overflow blocks -- counted from the planes, as the conversion does
+    const uint64_t run_bytes = run_block_count(h->totals.total) * kBlockBytes;
+    uint64_t run_peak = run_bytes + run_bytes / 8;
+    {
+        unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(h->d_flags) + kPackScratchOffset), nover = 0;
+        hipError_t e = launch_run_block_count(h->d_blocks, h->nblocks, h->totals.total, d_cnt, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&nover, d_cnt, sizeof nover, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) run_peak = run_bytes + uint64_t(nover) * 256;
+        else (void)hipGetLastError();
+    }
     const int parent = std::min(kDirectDepthBesideSparse, std::max(0, auto_flat_table_depth(h->totals.total, h->nblocks * kBlockBytes)));
     const uint64_t parent_bytes = parent > 0 ? (uint64_t(1) << (2 * parent)) * 16 : 0;
     if (sz.pair_block_bytes + sz.super_bytes + sz.scratch_bytes + parent_bytes + run_peak > uint64_t(free_b) - uint64_t(free_b) / 32) {
@@ -807,9 +820,9 @@ int build_sparse_for_runs(msbwt_rle *h) {
         h->table_packed = false;
     }
     // what the budget leaves once the run blocks and their (flat) direct table are paid for; the conversion's peak stays free.  Run blocks
-    // are the memory-LEAN format: left to itself the table may take twice what the blocks take and no more (human scale: 42 GB beside 27 GB
-    // of run blocks -- lines per query halve; a 3e7-symbol stream, whose depth-23 table the tags would force to 4.3 GB: none) -- an explicit
-    // depth or a memory budget says otherwise.
+    // are the memory-LEAN format: left to itself the table (with its build scratch) may take twice what the finished blocks take and no more
+    // (human scale: 26.8 GB of run blocks -> 53.6 GB: the depth-23 table, 42 GB, or for a declared k = 31 the depth-27 one, 49 GB; a 3e7-symbol
+    // stream, whose depth-23 table the tags would force to 4.3 GB: none) -- an explicit depth or a memory budget says otherwise.
     uint64_t allowance = h->wanted_sparse < 0 ? 2 * run_peak : kNoBudget;
     if (h->memory_budget) {
         const uint64_t held = run_peak + parent_bytes;

@@ -9,6 +9,6 @@ MSBWT_VERBOSE=1 timeout -k 10 400 python bench.py $common --query-length-hint 0 
 echo "runs, k undeclared: $(show $out/runs_k_unknown.json)"
 MSBWT_VERBOSE=1 timeout -k 10 400 python bench.py $common --extras-file $out/runs_k31.json > $out/runs_k31.line 2> $out/runs_k31.err || { tail -5 $out/runs_k31.err; exit 1; }
 echo "runs, k = 31 declared: $(show $out/runs_k31.json)"
-MSBWT_VERBOSE=1 timeout -k 10 400 python bench.py $common --query-length-hint 0 --sparse-tiers 1 --extras-file $out/runs_two_tier.json > $out/runs_two_tier.line 2> $out/runs_two_tier.err || { tail -5 $out/runs_two_tier.err; exit 1; }
-echo "runs, k undeclared, two-tier forced: $(show $out/runs_two_tier.json)"
+MSBWT_VERBOSE=1 timeout -k 10 400 python bench.py $common --k 21 --extras-file $out/runs_k21.json > $out/runs_k21.line 2> $out/runs_k21.err || { tail -5 $out/runs_k21.err; exit 1; }
+echo "runs, k = 21 declared: $(show $out/runs_k21.json)"
 grep -h "sparse table\|load:" $out/runs_k_unknown.err | head -12
