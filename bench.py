@@ -430,7 +430,7 @@ def compact_record(full, extras_path):
 
     out = pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
     cfg = full.get("config", {})
-    out["config"] = pick(cfg, ("k", "queries_per_step", "queries_per_gpu", "bwt_symbols", "index_bytes", "table_depth", "direct_table_depth", "sparse_table_depth",
+    out["config"] = pick(cfg, ("k", "query_kind", "queries_per_step", "queries_per_gpu", "bwt_symbols", "index_bytes", "table_depth", "direct_table_depth", "sparse_table_depth",
                                "sparse_table_tiers", "query_length_hint", "pair_index", "pair_stride", "block_format"))
     out["config"]["workload"] = short(str(cfg.get("workload", "")).split(".  ")[0], 420)
     if "parallelism" in cfg:
@@ -940,7 +940,7 @@ def main():
     d_counts = stitch(d_all, d_out, nq, cap)
     # the repeat-genome lab line: what a k-mer costs by copy number AT THIS SIZE (human copy numbers: 10^5 and more occurrences)
     main_bins = None
-    if exact_bwt and args.genome == "repeats" and not multi and d_q is not None:
+    if exact_bwt and args.genome == "repeats" and not multi and d_q is not None and not args.no_variants:
         main_bins, main_bins_ok = copy_number_bins(bwt, d_q, d_counts, k, ((1, 100), (100, 1000), (1000, 10_000), (10_000, 100_000), (100_000, 1_000_000), (1_000_000, 1 << 62)))
 
     # per-rank view of the timed region: the count kernel alone (HIP events on the launch stream), and the exchange
@@ -1112,7 +1112,7 @@ def main():
         "dtype": "u64",
         "data": "synthetic",
         "config": {
-            "workload": wl, "k": k, "queries_per_step": job_queries, "queries_per_gpu": mine_n if strong else nq,
+            "workload": wl, "k": k, "query_kind": kind, "queries_per_step": job_queries, "queries_per_gpu": mine_n if strong else nq,
             "bwt_symbols": total, "index_bytes": bwt.device_bytes(),
             "table_depth": lookup_depth(bwt, k), "direct_table_depth": bwt.get_table_depth(), "sparse_table_depth": bwt.get_sparse_table(),
             "sparse_table_tiers": 2 if bwt.get_sparse_tiers() else (1 if bwt.get_sparse_table() else 0),

@@ -65,7 +65,7 @@ print(json.dumps(d, indent=1))
 if "traffic_bytes_per_launch" in d:
     import bench as bench_mod
     workload = cfg["workload"].split(":", 1)[0] + ("+repeats" if "REPEAT-BEARING" in cfg["workload"] else "")   # (bench.py --genome repeats)
-    kind = "walk" if "LF-walk" in cfg["workload"] else "reads" if "read-derived" in cfg["workload"] else "random"
+    kind = cfg.get("query_kind") or ("walk" if "LF-walk" in cfg["workload"] else "reads" if "read-derived" in cfg["workload"] else "random")
     entry = {
         "workload": workload, "k": cfg["k"], "table_depth": cfg["table_depth"], "pair_index": cfg["pair_index"], "pair_stride": cfg.get("pair_stride"),
         "query_kind": kind, "fused": "prepared in-kernel" in cfg["workload"], "bwt_symbols": cfg["bwt_symbols"], "queries_per_launch": nq,
