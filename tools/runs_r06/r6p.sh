@@ -20,5 +20,11 @@ small)
   PROF_PASSES="$LIGHT" bash tools/profile_bench.sh r06_v1 c4r_reads --workload c4r 2>&1 | tail -2 &&
   bash tools/profile_bench.sh r06_v1 c2 --workload c2 2>&1 | tail -2 &&
   bash tools/profile_bench.sh r06_v1 c3_fused --workload c3 --fused 2>&1 | tail -2 ;;
-*) echo "usage: r6p.sh big1|big2|small"; exit 2 ;;
+small2)   # the C4-sized lines on READ-DERIVED 31-mers (what the two-tier form is about; `small` ran BASELINE configs[3]'s random ones), + the repeat genome's stats pass again
+  bash tools/profile_bench.sh r06_v1 c4_reads --workload c4 --query-kind reads 2>&1 | tail -2 &&
+  PROF_PASSES="$LIGHT SQ_WAVE_CYCLES" bash tools/profile_bench.sh r06_v1 c4_two_tier --workload c4 --query-kind reads --query-length-hint 0 --sparse-tiers 1 2>&1 | tail -2 &&
+  PROF_PASSES="$LIGHT SQ_WAVE_CYCLES" bash tools/profile_bench.sh r06_v1 c4_k_unknown --workload c4 --query-kind reads --query-length-hint 0 2>&1 | tail -2 &&
+  PROF_PASSES="$LIGHT" bash tools/profile_bench.sh r06_v1 c4r_reads --workload c4r --query-kind reads 2>&1 | tail -2 &&
+  PROF_PASSES="stats" bash tools/profile_bench.sh r06_v1 human_repeats --genome repeats 2>&1 | tail -2 ;;
+*) echo "usage: r6p.sh big1|big2|small|small2"; exit 2 ;;
 esac
