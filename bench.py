@@ -54,7 +54,7 @@ HUMAN_SYMBOLS = 9e10
 # everything that decides which bytes a query makes the kernel move: the kernels, the block layouts and their
 # builders, and the policies that pick table depth and pair spacing
 # (order.hip -- the library's batch-ordering passes -- is not among them: they are off unless forced, and no default line runs them)
-KERNEL_SOURCES = ["kernels.hip", "lanes.hip", "search_common.hpp", "rank_ops.hpp", "kernels.hpp", "plane_index.hpp",
+KERNEL_SOURCES = ["kernels.hip", "lanes.hip", "lanes_kernel.hpp", "lanes_tier.hip", "lanes_wide.hip", "lanes_xwide.hip", "search_common.hpp", "rank_ops.hpp", "kernels.hpp", "plane_index.hpp",
                   "pair_index.hip", "device_build.hip", "table_policy.hpp", "sparse_table.hpp", "sparse_table.hip"]
 NARROW_MAX = 32767
 
@@ -103,15 +103,16 @@ def lookup_depth(bwt, k):
 
 def kernel_label(bwt, k, fused):
     """Name (as in the rocprofv3 kernel trace) of the kernel the library runs for this index and k:
-    k_count_kmers_lanes<kReads, kPair, kWords, kStride96, kPacked, kSparse> (csrc/lanes.hip; kSparse: 0 = direct table, 1 = complete
-    sparse table, 2 = its two-tier form)."""
+    k_count_kmers_lanes<kReads, kPair, kWords, kStride96, kPacked, kSparse> (csrc/lanes_kernel.hpp; kSparse: 0 = direct table, sparse table with
+    1 = 24-bit tags, 3 = 32-bit tags (depths 25..29), 4 = 40-bit tags (30..31), 2 = the two-tier form)."""
     which = bwt.search_kernel_for(k)
     reads, words = ("true" if fused else "false"), (3 if k <= 32 else 6)
     if which == "lanes":
         pair, s96 = bwt.get_pair_index(), bwt.get_pair_index() and bwt.get_pair_stride() == 96
         info = bwt.sparse_table_info() if bwt.get_sparse_table() else None
         served = bool(info) and (k >= info["depth"] or (info["second_depth"] and k >= info["second_depth"]))
-        sparse = 0 if not served else (2 if info["two_tier"] else 1)
+        served_depth = 0 if not served else (info["depth"] if k >= info["depth"] else info["second_depth"])
+        sparse = 0 if not served else (2 if info["two_tier"] else 4 if served_depth >= 30 else 3 if served_depth >= 25 else 1)
         return "k_count_kmers_lanes<%s,%s,%d,%s,false,%d>" % (reads, "true" if pair else "false", words, "true" if s96 else "false", sparse)
     return "k_count_kmers_tiled<%s,%d>" % (reads, words) if which == "groups" else "k_count_kmers_generic"
 

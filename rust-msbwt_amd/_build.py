@@ -6,8 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmsbwt_hip.so")
-SOURCES = ["capi.cpp", "kernels.hip", "lanes.hip", "sparse_table.hip", "device_build.hip", "pair_index.hip", "gather.hip", "order.hip", "run_build.hip", "plane_index.cpp", "run_index.cpp", "npy_io.cpp", "rle_codec.cpp"]
-HEADERS = ["kernels.hpp", "sparse_table.hpp", "sparse_build.hpp", "sparse_policy.hpp", "device_build.hpp", "pair_index.hpp", "gather.hpp", "order.hpp", "run_build.hpp", "rank_ops.hpp", "search_common.hpp", "host_pipeline.hpp", "plane_index.hpp", "run_index.hpp", "table_policy.hpp", "npy_io.hpp", "rle_codec.hpp", os.path.join("..", "..", "include", "msbwt_hip.h")]
+SOURCES = ["capi.cpp", "kernels.hip", "lanes.hip", "lanes_tier.hip", "lanes_wide.hip", "lanes_xwide.hip", "sparse_table.hip", "device_build.hip", "pair_index.hip", "gather.hip", "order.hip", "run_build.hip", "plane_index.cpp", "run_index.cpp", "npy_io.cpp", "rle_codec.cpp"]
+HEADERS = ["kernels.hpp", "lanes_kernel.hpp", "sparse_table.hpp", "sparse_build.hpp", "sparse_policy.hpp", "device_build.hpp", "pair_index.hpp", "gather.hpp", "order.hpp", "run_build.hpp", "rank_ops.hpp", "search_common.hpp", "host_pipeline.hpp", "plane_index.hpp", "run_index.hpp", "table_policy.hpp", "npy_io.hpp", "rle_codec.hpp", os.path.join("..", "..", "include", "msbwt_hip.h")]
 
 
 def hipcc():
