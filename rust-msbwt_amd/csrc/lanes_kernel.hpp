@@ -470,6 +470,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     static_assert(!(kReads && kPacked), "packed queries are a matrix-mode input");
     static_assert(kSparse >= 0 && kSparse <= 4, "0 = direct table; sparse table: 1 = 24-bit tags (depths up to 24), 2 = two-tier form, 3 = 32-bit tags (25..29), 4 = 40-bit tags (30..31)");
     constexpr bool kTier = kSparse == 2, kWideTags = kSparse == 3, kXwide = kSparse == 4;
+    constexpr int kReach = kSparse >= 2 ? 32 : 24;  // how deep this kernel's table index may reach (search_common.hpp, pack_row_swar)
     using Scratch = LaneScratchT<kWords, kPacked, kTier>;
     // run blocks (run_index.hpp; launch-uniform): `blocks` are 128-byte lines of 512 positions with 96 one-byte runs, decoded
     // by the lane that owns the query; single-symbol steps only (the kPair instantiations never see them)
@@ -860,16 +861,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                 if (kPacked) {
                     pack_two_bit<kWords>(k, depth, (uint64_t(packed_words.y) << 32) | packed_words.x, (uint64_t(packed_words.w) << 32) | packed_words.z, pq);
                 } else if (!kReads) {
-                    pack_query<false, kWords>(src, depth, stage_bytes + lane * k, q0 + lane, pq);
+                    pack_query<false, kWords, kReach>(src, depth, stage_bytes + lane * k, q0 + lane, pq);
                 } else if (reads_fast) {
                     // window j of the tile starts o bytes into the span (k - 1 more once the read border is
                     // crossed); forward: the row at F + o; reverse complement: the row at C + 256 - o - k --
                     // either way a k-byte row packed exactly like a row of a query matrix
                     const uint32_t j = lane >> wshift, o = j + (j >= tile_n0 ? k - 1u : 0u);
                     const bool rc = src.strands == 3u ? (lane & 1u) != 0u : src.strands == 2u;
-                    pack_query<false, kWords>(src, depth, stage_bytes + (rc ? 512u - o - k : o), q0 + lane, pq);
+                    pack_query<false, kWords, kReach>(src, depth, stage_bytes + (rc ? 512u - o - k : o), q0 + lane, pq);
                 } else {
-                    pack_query<true, kWords>(src, depth, stage_bytes, q0 + lane, pq);
+                    pack_query<true, kWords, kReach>(src, depth, stage_bytes, q0 + lane, pq);
                 }
                 if (pq.bad) {  // the reference asserts (msbwt_core.rs:127)
                     store_count<kReads>(src, place_of(q0 + lane, prep_out), ~0ull);

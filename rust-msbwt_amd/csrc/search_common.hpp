@@ -228,7 +228,10 @@ __device__ __forceinline__ uint32_t tail_byte_mask(uint32_t d, uint32_t first) {
 //   table index    bytes outside the table's reach read as 'A' so that nothing borrows from them; A C G T -> 0..3 is
 //                  y - 1 - (y >> 2) per byte, the four 2-bit codes of a dword are gathered the same way; a '$' / 'N'
 //                  inside the reach (low two bits zero) turns the table off for this query.
-template <int kWords>
+// kReach: how many steps deep a table index may reach in this kernel (24: direct tables and the 24-bit-tag sparse table, as until round 5;
+// 32: the deeper sparse layouts) -- the index costs a dozen instructions per four symbols, and the lookup-heavy lines of small indexes
+// notice them (round 6, same box: C2 read-derived 21-mers 0.273 -> 0.297 ms with every kernel paying for 32).
+template <int kWords, int kReach = 32>
 __device__ __forceinline__ void pack_row_swar(uint32_t k, uint32_t depth, const uint8_t *row, PackedQuery<kWords> &pq) {
     constexpr int kBits = PackedQuery<kWords>::kBits;
     constexpr uint32_t kBlock = kWords == 3 ? 32u : 64u, D = kBlock / 4u;
@@ -248,7 +251,7 @@ __device__ __forceinline__ void pack_row_swar(uint32_t k, uint32_t depth, const 
         const uint32_t z = ((y >> 8) | (y << 3)) & 0x003F003Fu;
         const uint32_t g = ((z >> 16) | (z << 6)) & 0xFFFu;
         constexpr_shift_or12<kBits>(pq.bits, g, 12u * u);
-        if (u < 8u) {  // the tables reach at most 29 steps deep (sparse_table.hpp): the block's last 32 symbols
+        if (u < uint32_t(kReach) / 4u) {  // the tables of this kernel reach at most kReach steps deep (sparse_table.hpp)
             const uint32_t dm = tail_byte_mask(d, first_d);
             const uint32_t ys = (y & dm) | (0x01010101u & ~dm);
             const uint32_t low2 = ys & 0x03030303u;
@@ -258,7 +261,7 @@ __device__ __forceinline__ void pack_row_swar(uint32_t k, uint32_t depth, const 
             tidx |= uint64_t(((z2 >> 16) | (z2 << 4)) & 0xFFu) << (8u * u);
         }
     }
-    pq.tidx = tidx & ((1ull << (2u * min(depth, 31u))) - 1ull);
+    pq.tidx = tidx & ((1ull << (2u * min(depth, uint32_t(kReach >= 32 ? 31 : kReach)))) - 1ull);
     pq.bad = bad != 0u;
     pq.acgt = nonacgt == 0u;
 }
@@ -288,12 +291,12 @@ __device__ __forceinline__ void pack_two_bit(uint32_t k, uint32_t depth, uint64_
     pq.acgt = true;
 }
 
-template <bool kReads, int kWords>
+template <bool kReads, int kWords, int kReach = 32>
 __device__ __forceinline__ void pack_query(const QuerySource &src, uint32_t depth, const uint8_t *staged, uint64_t v,
                                            PackedQuery<kWords> &pq) {
     if constexpr (!kReads) {
         (void)v;
-        pack_row_swar<kWords>(src.k, depth, staged, pq);
+        pack_row_swar<kWords, kReach>(src.k, depth, staged, pq);
         return;
     }
     constexpr int kBits = PackedQuery<kWords>::kBits;
