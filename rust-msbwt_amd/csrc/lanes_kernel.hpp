@@ -1086,7 +1086,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                     l = tl;
                     h = tl + width;
                     if (width == kSparseEscapeWidth) {  // a high-copy suffix: its range is a flat entry of the side array, one more line
-                        const uint4 e = table_side[tl];
+                        uint4 e = table_side[tl];
+                        // The wait for this rare load stays HERE (the empty asm is a use of its registers).  Round 6 found what happens
+                        // otherwise: the loaded registers simply BECOME l and h, their first use is the next iteration's address arithmetic,
+                        // and the compiler puts s_waitcnt vmcnt(0) in front of it -- in EVERY iteration, for every lane: the tile bytes and
+                        // table lines fetched a step ahead are waited for at once, setup no longer runs ahead of memory (C3 fused 15.5 ->
+                        // 17.2 ms on the same box; eleven vmcnt(0) more in the kernel than round 5's had).
+                        asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z), "+v"(e.w));
                         l = (uint64_t(e.y) << 32) | e.x;
                         h = (uint64_t(e.w) << 32) | e.z;
                     }
@@ -1139,7 +1145,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                     h = (uint64_t(e.w) << 32) | e.z;
                 }
                 if (esc) {  // an escape line (the suffixes of a high-copy repeat): its flat entry in the direct table's side array, one more line
-                    const uint4 e = dside[l];
+                    uint4 e = dside[l];
+                    asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z), "+v"(e.w));  // (waited for here, not by the next iteration: see the sparse table's side array above)
                     l = (uint64_t(e.y) << 32) | e.x;
                     h = (uint64_t(e.w) << 32) | e.z;
                 }
