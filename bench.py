@@ -470,7 +470,7 @@ def compact_record(full, extras_path):
         for flag in ("counts_equal_headline", "counts_equal_unordered_run", "equals_torch_path"):
             if flag in line:
                 extras[key + "_" + flag] = line[flag]
-        for num in ("sparse_table_depth", "direct_table_depth", "lines_per_query"):
+        for num in ("sparse_table_depth", "second_level_depth", "direct_table_depth", "lines_per_query"):
             if num in line:
                 extras[key + "_" + num] = line[num]
     if isinstance(full.get("c4_budgeted"), dict):
@@ -1209,6 +1209,14 @@ def main():
     short_k_samples = {}
     if want_variants:
         t0 = time.time()
+        # (the tables are rebuilt BEFORE the batch returns to HBM: the loader leaves an eighth of the device free for the caller's batches, and
+        # counted on top of a batch that is already resident that reserve is what the second sparse level would have fitted in)
+        undeclared_error = None
+        try:
+            if bwt.get_query_length() != 0:
+                bwt.set_query_length(0)
+        except msbwt.MsbwtError as e:
+            undeclared_error = e
         d_q, d_counts = h_q.to(dev), h_counts.to(dev)
         del h_q, h_counts
 
@@ -1254,9 +1262,11 @@ def main():
 
         short_k = {}
         try:
-            if bwt.get_query_length() != 0:
-                bwt.set_query_length(0)
-            result["undeclared_k"] = dict(variant_line(), note="the same index after msbwt_rle_set_query_length(0): the automatic sparse table stops at depth 23")
+            if undeclared_error is not None:
+                raise undeclared_error
+            result["undeclared_k"] = dict(variant_line(), second_level_depth=bwt.sparse_table_info()["second_depth"],
+                                          note="the same index after msbwt_rle_set_query_length(0): the automatic sparse table stops at depth 23 (+ a second level of "
+                                               "17-symbol suffixes for 17 <= k < 23 where it fits)")
             short_k_lines("default", short_k)
             bwt.set_sparse_table(0)
             result["headline_sparse_off"] = dict(variant_line(), note="the same index after msbwt_rle_set_sparse_table(0): no sparse table, the deep direct table")
