@@ -84,6 +84,13 @@ def test_bench_default_run_carries_the_real_msbwt_line():
     for rec in (r["short_k"]["k17"], r["short_k"]["k19"], r["short_k"]["k21"]):
         assert rec["default_qps"] > 0 and rec["sparse_off_qps"] > 0 and rec["counts_equal"] is True
     assert r["short_k"]["parity"]["mismatches"] == 0 and r["short_k"]["parity"]["checked"] > 0
+    # round 6: the C4 line's modes (complete / two-tier / budgeted / no sparse table) and the host-pointer path, all counting like the line
+    modes = r["c4_budgeted"]["modes"]
+    assert set(modes) == {"complete", "two_tier", "two_tier_budgeted", "fallback"} and all(m["counts_equal_the_line"] and m["value"] > 0 for m in modes.values())
+    assert modes["fallback"]["sparse_table_depth"] == 0 and compact["extras"]["c4_budgeted_two_tier_qps"] == modes["two_tier"]["value"]
+    host = r["host_api"]
+    assert "error" not in host and host["bytes_equal"] and host["packed_u64_equal"] and host["packed_u32_equal"] and host["pcie_both_ways_GBps"] > 0
+    assert compact["extras"]["host_api_bytes_qps"] == host["bytes_qps"] > 0
     c4 = r["c4_real_reads"]
     assert c4["value"] > 0 and c4["parity"]["mismatches"] == 0 and c4["parity"]["checked"] > 0
     assert c4["parity"]["mean_count_in_sample"] > 5      # a real 30x read set: present k-mers occur ~ coverage times
