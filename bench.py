@@ -142,7 +142,7 @@ def parse_args(argv=None):
     ap.add_argument("--table-depth", type=int, default=-2, help="-2 = library default")
     ap.add_argument("--query-length-hint", type=int, default=-1, help="msbwt_rle_set_query_length before the load: the k the index is built for (default: this run's k; 0 = "
                                                                       "unknown, i.e. the automatic sparse table stops at depth 23 whatever k is)")
-    ap.add_argument("--sparse-depth", type=int, default=-2, help="msbwt_rle_set_sparse_table before the load: 0 = off, 16..28 = that depth (default: the library's automatic choice)")
+    ap.add_argument("--sparse-depth", type=int, default=-2, help="msbwt_rle_set_sparse_table before the load: 0 = off, 16..31 = that depth (default: the library's automatic choice)")
     ap.add_argument("--sparse-tiers", type=int, default=-2, help="msbwt_rle_set_sparse_tiers before the load: 1 = the two-tier form of the sparse table (entries for the "
                                                                   "suffixes that occur at least twice, filter bits for the rest), 0 = complete tables only (default: automatic)")
     ap.add_argument("--blocks", default="planes", choices=["planes", "runs"],
@@ -638,7 +638,7 @@ def main():
     if args.sparse_tiers > -2:
         bwt.set_sparse_tiers(args.sparse_tiers)
     # the index is built for the k it will be asked about (a deployment knows its k; results never depend on it): the automatic sparse
-    # table then reaches min(k, 27) -- a table of d-mers serves k >= d only
+    # table then goes as deep as min(k, 31) where it fits -- a table of d-mers serves k >= d only
     bwt.set_query_length(k if args.query_length_hint < 0 else args.query_length_hint)
     if args.no_table_side:
         bwt.set_table_side(0)

@@ -176,7 +176,7 @@ class RleBWT final : public BWT {
     void set_batch_order(int mode) { check(msbwt_rle_set_batch_order(raw_, mode)); }
     /// sparse suffix table (the suffixes that occur, one hashed 128-byte bucket per lookup): -1 = automatic (default), 0 = off, 16..31 = that depth
     void set_sparse_table(int depth) { check(msbwt_rle_set_sparse_table(raw_, depth)); }
-    /// the k this index will mostly be asked about (0 = unknown): the automatic sparse table reaches min(k, 27) instead of 23
+    /// the k this index will mostly be asked about (0 = unknown): the automatic sparse table goes as deep as min(k, 31) where its table fits, instead of 23
     void set_query_length(int k) { check(msbwt_rle_set_query_length(raw_, k)); }
     int get_query_length() const { return msbwt_rle_get_query_length(raw_); }
     /// two-tier form of the sparse table (entries for the suffixes that occur at least twice, filter bits for the rest: read sets with errors):

@@ -311,7 +311,7 @@ class RleBWT(BWT):
             _raise(rc, self._h)
 
     def set_query_length(self, k):
-        """The k this index will mostly be asked about (0 = unknown): the AUTOMATIC sparse table goes as deep as min(k, 27) instead of 23
+        """The k this index will mostly be asked about (0 = unknown): the AUTOMATIC sparse table goes as deep as min(k, 31) -- where its table fits -- instead of 23
         -- a table of d-mers serves k >= d only.  Results never depend on it."""
         rc = _lib.lib().msbwt_rle_set_query_length(self._h, int(k))
         if rc:

@@ -66,7 +66,7 @@ extern "C" {
     // sparse suffix table (round 5): ranges of the suffixes that occur, depth 16..31 (-1 = automatic, 0 = off); info = 80 u64 words
     fn msbwt_rle_set_sparse_table(bwt: *mut MsbwtRle, depth: c_int) -> c_int;
     fn msbwt_rle_get_sparse_table(bwt: *const MsbwtRle) -> c_int;
-    // the k the index will mostly be asked about (0 = unknown): the automatic sparse table then reaches min(k, 27) instead of 23
+    // the k the index will mostly be asked about (0 = unknown): the automatic sparse table then goes as deep as min(k, 31) where its table fits, instead of 23
     fn msbwt_rle_set_query_length(bwt: *mut MsbwtRle, k: c_int) -> c_int;
     fn msbwt_rle_get_query_length(bwt: *const MsbwtRle) -> c_int;
     fn msbwt_rle_set_sparse_tiers(bwt: *mut MsbwtRle, mode: c_int) -> c_int;
