@@ -291,6 +291,7 @@ def device_random_kmers(torch, dev, lo, hi, k, seed, chunk=50_000_000):
 def index_shape(bwt, k, fused, n):
     """what decides the kernel and the bytes of a launch on this index, read NOW (later table rebuilds do not change a record made of it)"""
     return {"lookup_depth": lookup_depth(bwt, k), "kernel": kernel_label(bwt, k, fused), "pair_index": bwt.get_pair_index(), "pair_stride": bwt.get_pair_stride(),
+            "two_tier": bool(bwt.get_sparse_table()) and bwt.get_sparse_tiers(),
             "ordered": (not fused) and bwt.batch_order_for(k, n), "sparse_depth": bwt.get_sparse_table()}
 
 
@@ -305,7 +306,7 @@ def lookup_traffic(workload, k, shape, kind, total, fused, full_size):
             same = (ent["workload"] == workload and ent["k"] == k and ent["table_depth"] == shape["lookup_depth"]
                     and ent.get("pair_index", False) == shape["pair_index"] and ent.get("pair_stride", shape["pair_stride"]) == shape["pair_stride"]
                     and ent.get("query_kind") == kind and ent.get("bwt_symbols", total) == total and full_size
-                    and bool(ent.get("fused", False)) == bool(fused))
+                    and bool(ent.get("fused", False)) == bool(fused) and bool(ent.get("two_tier", False)) == bool(shape.get("two_tier", False)))
             if same and ent.get("kernel_stamp") != stamp:
                 note = "stale: %s was taken with kernel sources %s, the tree has %s" % (ent["source"], ent.get("kernel_stamp"), stamp)
             elif same:

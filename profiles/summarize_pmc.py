@@ -68,13 +68,14 @@ if "traffic_bytes_per_launch" in d:
     kind = cfg.get("query_kind") or ("walk" if "LF-walk" in cfg["workload"] else "reads" if "read-derived" in cfg["workload"] else "random")
     entry = {
         "workload": workload, "k": cfg["k"], "table_depth": cfg["table_depth"], "pair_index": cfg["pair_index"], "pair_stride": cfg.get("pair_stride"),
-        "query_kind": kind, "fused": "prepared in-kernel" in cfg["workload"], "bwt_symbols": cfg["bwt_symbols"], "queries_per_launch": nq,
+        "query_kind": kind, "fused": "prepared in-kernel" in cfg["workload"], "two_tier": cfg.get("sparse_table_tiers") == 2, "bwt_symbols": cfg["bwt_symbols"], "queries_per_launch": nq,
         "traffic_bytes_per_launch": d["traffic_bytes_per_launch"], "traffic_bytes_per_query": d["traffic_bytes_per_launch"] / nq,
         "l2_hit_rate": d.get("l2_hit_rate"), "kernel_stamp": bench_mod.kernel_stamp(), "source": rel_path,
     }
     tj = os.path.join(REPO, "profiles", "traffic.json")
     doc = json.load(open(tj))
-    key = lambda e: (e["workload"], e["k"], e["table_depth"], e.get("pair_index"), e.get("pair_stride"), e.get("query_kind"), e.get("bwt_symbols"), bool(e.get("fused", False)))
+    key = lambda e: (e["workload"], e["k"], e["table_depth"], e.get("pair_index"), e.get("pair_stride"), e.get("query_kind"), e.get("bwt_symbols"), bool(e.get("fused", False)),
+                     bool(e.get("two_tier", False)))
     doc["entries"] = [e for e in doc["entries"] if key(e) != key(entry)] + [entry]
     json.dump(doc, open(tj, "w"), indent=1)
     print("registered in profiles/traffic.json:", json.dumps(entry))
