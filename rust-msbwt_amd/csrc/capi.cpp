@@ -2216,8 +2216,9 @@ int msbwt_rle_set_memory_budget(msbwt_rle *h, uint64_t bytes) {
     if (!h->loaded) return MSBWT_OK;
     DeviceScope scope(h->device);
     if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
-    // the optional structures are rebuilt under the new budget (the plan counts the memory they hold now as free)
-    release_sparse(h);
+    // the optional structures are rebuilt under the new budget (the plan counts the memory they hold now as free).  Run blocks: their sparse
+    // table was built at load time and cannot be rebuilt (the plane blocks it came from are gone) -- it stays while the index fits the budget
+    if (h->block_format == kBlocksPlanes || (bytes != 0 && msbwt_rle_device_bytes(h) > bytes)) release_sparse(h);
     if (h->d_table) (void)hipFree(h->d_table);
     if (h->d_table_side) (void)hipFree(h->d_table_side);
     if (h->d_filter) (void)hipFree(h->d_filter);

@@ -33,6 +33,8 @@ hipError_t sparse_count_levels(const IndexView &ix, const void *flat_entries, in
 // Fill pass at `depth` (any depth the sizing pass reached or passed): `lines` (nbuckets x 128 bytes, zeroed here) and `side`
 // (nside = report->escapes[depth] entries of 16 bytes, may be nullptr when 0) are written; d_counts: nbuckets x u32 of scratch.
 // hipErrorInvalidValue when some entry found no slot within `probe` buckets (the caller retries with more buckets).
+// `report` is IN and OUT: it must be the sizing pass's report (distinct[depth] is read to derive `entries`); depth, nbuckets, nescapes,
+// displaced, entries, tier and filtered are filled in.
 // tier: the two-tier form (sparse_table.hpp) -- ranges 1 wide set filter bits of their own bucket instead of taking an entry.
 hipError_t sparse_fill(const IndexView &ix, const void *flat_entries, int flat_depth, int depth, bool tier, void *lines, uint64_t nbuckets, uint32_t probe,
                        void *side, uint64_t nside, void *d_counts, void *d_work, size_t work_bytes, SparseBuildReport *report, hipStream_t stream);
