@@ -1497,11 +1497,11 @@ def main():
                     tier = timed_mode("two_tier")
                     bwt4.set_sparse_tiers(-1)
                     # a budget that the complete table of NO depth fits but a two-tier one does: plane blocks + overlapping pair blocks + the packed
-                    # depth-15 direct table (what a budgeted index keeps beside a sparse table) + 0.45 of the complete table's bytes.  (On this index
-                    # the depth-23 tables of both forms sit at the least bucket count their 24-bit tags allow -- 2^25, 4.3 GB --, so under the budget the
-                    # automatic choice is the two-tier table of depth 21: 1.6 GB against the complete one's 3.3.)
+                    # depth-15 direct table (what a budgeted index keeps beside a sparse table) + 0.6 of the complete table's bytes.  (On this index
+                    # the complete depth-23 table sits at the least bucket count its 24-bit tags allow -- 2^25, 4.3 GB; depth 21's needs 3.3 GB --
+                    # while the two-tier one, whose buckets hold a third of the entries, gets by with a probe limit of 3 and half the buckets: 2.1 GB.)
                     rest = (total4 // 256 + 1) * 128 + (total4 // 96 + 1) * 128 + ((4 ** 15 + 29) // 30) * 128 + 150_000_000
-                    budget = rest + int(complete["sparse_table_bytes"] * 0.45)
+                    budget = rest + int(complete["sparse_table_bytes"] * 0.6)
                     bwt4.set_memory_budget(budget)
                     timed_mode("two_tier_budgeted")["budget_bytes"] = budget
                     bwt4.set_memory_budget(0)

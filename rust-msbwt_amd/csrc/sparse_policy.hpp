@@ -38,6 +38,27 @@ inline int sparse_auto_max_depth(int query_length) {
 // distinct[d] / wide[d]: non-empty ranges at depth d and how many of them are 255 or more wide (0 for depths the pass did not reach);
 // parent_depth: the direct table the pass started from; avail: bytes the table (and its build scratch) may take;
 // explicit_depth: 0 = automatic, else exactly that depth or nothing.
+// Fewest buckets of a TWO-TIER table: a probe limit of 3 suffices there (4 W <= 2^bits instead of the complete table's 8 W) -- its buckets hold
+// only the solid suffixes, 6.4 of 10 slots on average at the most and far fewer wherever this bound binds (a chr20-sized read set at depth 23:
+// 4.0 per bucket, 0.3 % of the buckets over-subscribed, three in a row never), so what the complete table needs seven further buckets for the
+// two-tier one does with three; should an entry find no slot after all, the fill fails and the loader retries with a quarter more buckets.
+// Half the complete table's least size: 2^24 buckets (2.1 GB) at depth 23.
+inline uint64_t sparse_tier_min_buckets(int depth) {
+    const int bits = int(sparse_tag_bits(uint32_t(depth)));
+    const int shift = 2 * depth - 32 + 2;  // 4 W <= 2^bits  <=>  ceil(2^32 / nb) <= 2^(bits - 2 - (n - 32))
+    if (shift >= bits) return ~uint64_t(0);
+    if (bits - shift >= 32) return 1;
+    const uint64_t per_top = uint64_t(1) << (bits - shift);
+    return ((uint64_t(1) << 32) + per_top - 1) / per_top;
+}
+
+// buckets of the two-tier form: `solid` entries at its load, room in the filters for `singles` suffixes that occur once, what its tags allow
+inline uint64_t sparse_tier_buckets(int depth, uint64_t solid, uint64_t singles) {
+    const uint64_t by_entries = uint64_t(double(solid) / sparse_load(depth, true)) + 1;
+    const uint64_t by_filter = uint64_t(double(singles) / kTierMaxSinglesPerBucket) + 1;
+    return std::max(std::max(by_entries, by_filter), sparse_tier_min_buckets(depth));
+}
+
 // singles[d]: of distinct[d], the suffixes that occur exactly once (nullptr: not counted -- no two-tier form); tiers: -1 = the complete
 // table where it fits, else the two-tier form of the SAME depth where that fits (reads with errors: the complete table follows the error
 // k-mers, the two-tier one the genome), else the next shallower depth; 0 = complete tables only; 1 = two-tier only.
@@ -51,7 +72,8 @@ inline SparseChoice choose_sparse_depth(const uint64_t *distinct, const uint64_t
             if (tier ? (tiers == 0 || singles == nullptr || d > kTierMaxDepth) : (tiers == 1 && singles != nullptr && d <= kTierMaxDepth)) continue;
             const uint64_t single = tier ? std::min(singles[d], distinct[d]) : 0, entries = distinct[d] - single;
             const uint64_t needed = uint64_t(double(entries) / sparse_load(d, tier != 0)) + 1;
-            const uint64_t nb = tier ? sparse_tier_buckets_for(d, entries, single) : sparse_buckets_for(d, distinct[d]);
+            const uint64_t nb = tier ? sparse_tier_buckets(d, entries, single) : sparse_buckets_for(d, distinct[d]);
+            const uint64_t least = tier ? sparse_tier_min_buckets(d) : sparse_min_buckets(d);
             const uint64_t lines = nb + kSparseMaxProbe;
             if (lines > 0xFFFFFFFFull) continue;
             // a table that the tags force to be far larger than its entries need is not worth its depth: 16 x for the cheap depths (a toy index
@@ -59,7 +81,7 @@ inline SparseChoice choose_sparse_depth(const uint64_t *distinct, const uint64_t
             // chr20-sized one would fill 7 % and takes depth 27 in 4.3 GB instead)
             const uint64_t slack = d == 29 ? 4 : 16;
             const uint64_t data_needs = std::max<uint64_t>(needed, tier ? uint64_t(double(single) / kTierMaxSinglesPerBucket) + 1 : 0);
-            if (!explicit_depth && sparse_min_buckets(d) > std::max<uint64_t>(slack * data_needs, 65536)) continue;
+            if (!explicit_depth && least > std::max<uint64_t>(slack * data_needs, 65536)) continue;
             SparseChoice c;
             c.depth = d;
             c.nbuckets = nb;

@@ -600,6 +600,15 @@ def test_two_tier_sparse_table_is_chosen_where_the_complete_one_does_not_fit():
     assert choose(noisy, once, 120 * GB, tiers=0)[0] == 0                     # complete tables only: nothing fits
     assert choose(noisy, once, 200 * GB, tiers=1)[:2] == (23, 1)
     assert choose(noisy, once, 50 * GB)[0] == 0                               # not even the two-tier form of any depth: the deep direct table
+    # a chr20-sized read set with errors (config C4 as the device builder counted it): the complete depth-23 table sits at the 2^25 buckets its
+    # 24-bit tags demand (4.3 GB), depth 21's needs 3.3 GB; the two-tier form of depth 23 holds a third of the entries, gets by with a probe
+    # limit of 3 and half the buckets -- 2^24, 2.1 GB -- so a budget of 2.6 GB for the table keeps depth 23
+    c4 = {13: 62114725, 15: 173178299, 17: 201574823, 19: 215988570, 21: 228772228, 23: 240890440}
+    c4_once = {15: 30000000, 17: 120000000, 19: 145000000, 21: 161297690, 23: 173293266}
+    depth, tier, nbytes = choose(c4, c4_once, 2.6 * GB)
+    assert (depth, tier) == (23, 1) and 2.1 * GB < nbytes < 2.2 * GB
+    assert choose(c4, c4_once, 200 * GB)[:2] == (23, 0) and choose(c4, c4_once, 2.6 * GB, tiers=0)[0] < 21
+    assert choose(c4, c4_once, 1.5 * GB)[:2] == (21, 1)                       # 6.7e7 entries at 6.4 per bucket: 1.35 GB
     # the filter's load bounds the table from below: 32 once-only suffixes per bucket at most
     few_solid = {13: 1000, 15: 10**6, 17: 10**9, 19: 2 * 10**9}
     few_once = {17: 10**9 - 10**6, 19: 2 * 10**9 - 10**6}
@@ -615,7 +624,7 @@ def test_two_tier_sparse_table_is_chosen_where_the_complete_one_does_not_fit():
     deep_once.update({25: 1.11e10, 27: 1.23e10, 29: 1.35e10, 31: 1.47e10})
     depth, tier, nbytes = choose(deep, deep_once, 120 * GB, query_length=31)
     assert (depth, tier) == (29, 1) and nbytes <= 120 * GB
-    assert choose(deep, deep_once, 70 * GB, query_length=31)[:2] == (27, 1)   # depth 29 needs 2^29 buckets (69 GB + its slot counters)
+    assert choose(deep, deep_once, 70 * GB, query_length=31)[:2] == (29, 1)   # 5.76 entries per bucket: 66.7 GB + its slot counters (its tags would allow 2^28 buckets)
     assert choose(deep, deep_once, 64 * GB, query_length=31)[:2] == (23, 1)   # 5.76 entries per bucket at depths 25..29, 6.4 up to 24
     # the filter as a pure function: a word 0..7 and at most four bits, the same for the same tag
     word, mask, w2, m2 = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
