@@ -349,6 +349,24 @@ def test_bench_stdout_line_is_compact():
     assert c["cpu_baseline"]["value"] == full["cpu_baseline"]["value"] and c["cpu_baseline"]["cores"] == 1 and c["parity"] == {"checked": 2000000, "mismatches": 0}
     assert c["extras"]["c4_real_reads_qps"] == full["c4_real_reads"]["value"] and c["extras"]["c5_random_1e9_mismatches"] == 0
     assert "note" not in line and "telemetry" not in line and c["extras_file"] == "bench_extras.json"
+    # the N > 1 shape (sharded batch, exchange step): per-rank and gather figures travel as scalars
+    multi = dict(full, n_gpus=8, scaling="strong", weak_scaling={"value": 1.0e11, "note": "x" * 500},
+                 ranks={"kernel_ms": [1.2] * 8, "kernel_ms_min": 1.1, "kernel_ms_max": 1.3, "exchange_ms_alone": 4.2, "note": "y" * 900},
+                 native_gather={"value": 9.0e10, "equals_torch_path": True, "single_batch_latency_ms": 6.0, "single_batch_pipelined_ms": 4.5,
+                                "single_batch_pipelined_narrow_destination_ms": 4.1, "note": "z" * 900})
+    multi.pop("cpu_baseline", None)
+    cm = bench.compact_record(multi, "bench_extras.json")
+    assert len(json.dumps(cm)) < 4096 and cm["n_gpus"] == 8 and "cpu_baseline" not in cm
+    assert cm["extras"]["weak_scaling_qps"] == 1.0e11 and cm["extras"]["native_gather_qps"] == 9.0e10 and cm["extras"]["ranks_kernel_ms_max"] == 1.3
+    assert cm["extras"]["native_gather_single_batch_pipelined_ms"] == 4.5 and cm["extras"]["native_gather_equals_torch_path"] is True
+    # the round-6 record (variant lines, budgeted C4 modes, short k, host path) as committed
+    final = json.load(open(os.path.join(ROOT, "profiles", "r06_lab", "bench_extras_final.json")))
+    cf = bench.compact_record(final, "bench_extras.json")
+    assert len(json.dumps(cf)) < 4096
+    for key in ("undeclared_k_qps", "headline_sparse_off_qps", "c4_budgeted_two_tier_qps", "c4_budgeted_two_tier_budgeted_qps", "c4_budgeted_fallback_qps",
+                "short_k_worst_ratio_to_sparse_off", "host_api_bytes_qps", "host_api_packed_u32_qps", "c5_random_1e9_qps", "c4_real_reads_frac"):
+        assert cf["extras"][key] > 0, key
+    assert cf["value"] > 3e10 and cf["roofline"]["frac"] > 0.6 and cf["parity"]["mismatches"] == 0 and cf["extras"]["undeclared_k_counts_equal_headline"] is True
     # a record with absurdly long strings still fits
     full["config"]["workload"] = "x" * 100000
     full["roofline"]["traffic_source"] = "y" * 100000
