@@ -305,6 +305,10 @@ int msbwt_rle_set_sparse_table(msbwt_rle *bwt, int depth);
 int msbwt_rle_get_sparse_table(const msbwt_rle *bwt);
 int msbwt_rle_set_sparse_tiers(msbwt_rle *bwt, int mode);
 int msbwt_rle_get_sparse_tiers(const msbwt_rle *bwt);
+/* The second, shallower sparse level ([43] / [44] of msbwt_rle_sparse_table_info): -1 = automatic (default: k undeclared, plane blocks, the
+ * deep direct table does not fit beside the sparse table but a table of the 17-symbol suffixes does), 0 = never.  MSBWT_SPARSE_SECOND=0|auto
+ * sets the initial mode.  Takes effect immediately if an index is loaded.  Results never change. */
+int msbwt_rle_set_sparse_second(msbwt_rle *bwt, int mode);
 int msbwt_rle_sparse_table_info(const msbwt_rle *bwt, uint64_t *out);
 int msbwt_sparse_hash(uint64_t key, int depth, uint64_t nbuckets, uint32_t *bucket, uint32_t *tag);
 int msbwt_sparse_hash64(uint64_t key, int depth, uint64_t nbuckets, uint32_t *bucket, uint64_t *tag); /* the whole tag: 24, 32 or 40 bits by depth */

@@ -183,6 +183,8 @@ class RleBWT final : public BWT {
     /// -1 = where the complete table of a depth does not fit (default), 0 = never, 1 = always
     void set_sparse_tiers(int mode) { check(msbwt_rle_set_sparse_tiers(raw_, mode)); }
     bool get_sparse_tiers() const { return msbwt_rle_get_sparse_tiers(raw_) != 0; }
+    /// the second, shallower sparse level (17-symbol suffixes, k undeclared): -1 = automatic (default), 0 = never
+    void set_sparse_second(int mode) { check(msbwt_rle_set_sparse_second(raw_, mode)); }
     int get_sparse_table() const { return msbwt_rle_get_sparse_table(raw_); }
     void set_table_side(int mode) { check(msbwt_rle_set_table_side(raw_, mode)); }
     std::uint64_t device_bytes() const { return msbwt_rle_device_bytes(raw_); }

@@ -89,6 +89,7 @@ SIGNATURES = {
     "msbwt_auto_pair_stride": (_int, [_u64, _u64, _u64, C.c_double, C.POINTER(C.c_int)]),
     "msbwt_rle_set_sparse_tiers": (_int, [_vp, _int]),
     "msbwt_rle_get_sparse_tiers": (_int, [_vp]),
+    "msbwt_rle_set_sparse_second": (_int, [_vp, _int]),
     "msbwt_auto_sparse_choice": (_int, [_pu64, _pu64, _pu64, _int, _u64, _int, _int, C.POINTER(C.c_int), C.POINTER(C.c_int), _pu64]),
     "msbwt_sparse_filter_bits": (_int, [_u64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "msbwt_rle_set_query_length": (_int, [_vp, _int]),

@@ -2309,6 +2309,17 @@ int msbwt_rle_set_sparse_tiers(msbwt_rle *h, int mode) {
 
 int msbwt_rle_get_sparse_tiers(const msbwt_rle *h) { return (h && h->d_sparse && h->sparse_tier) ? 1 : 0; }
 
+int msbwt_rle_set_sparse_second(msbwt_rle *h, int mode) {
+    if (!h || mode < -1 || mode > 0) return MSBWT_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    const bool changes = mode != h->wanted_second;
+    h->wanted_second = mode;
+    if (!h->loaded || !changes || h->wanted_sparse == 0 || h->block_format != kBlocksPlanes) return MSBWT_OK;
+    DeviceScope scope(h->device);
+    if (!scope.ok()) return fail(h, MSBWT_ERR_HIP, scope.why());
+    return rebuild_table(h);
+}
+
 int msbwt_rle_set_query_length(msbwt_rle *h, int k) {
     if (!h || k < 0) return MSBWT_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(h->mu);

@@ -327,6 +327,12 @@ class RleBWT(BWT):
         if rc:
             _raise(rc, self._h)
 
+    def set_sparse_second(self, mode):
+        """The second, shallower sparse level (17-symbol suffixes, for k undeclared): -1 = automatic (default), 0 = never."""
+        rc = _lib.lib().msbwt_rle_set_sparse_second(self._h, int(mode))
+        if rc:
+            _raise(rc, self._h)
+
     def get_sparse_tiers(self):
         """True when the sparse table in HBM is of the two-tier form."""
         return bool(_lib.lib().msbwt_rle_get_sparse_tiers(self._h))

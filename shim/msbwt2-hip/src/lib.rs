@@ -71,6 +71,7 @@ extern "C" {
     fn msbwt_rle_get_query_length(bwt: *const MsbwtRle) -> c_int;
     fn msbwt_rle_set_sparse_tiers(bwt: *mut MsbwtRle, mode: c_int) -> c_int;
     fn msbwt_rle_get_sparse_tiers(bwt: *const MsbwtRle) -> c_int;
+    fn msbwt_rle_set_sparse_second(bwt: *mut MsbwtRle, mode: c_int) -> c_int;
     fn msbwt_auto_sparse_max_depth(query_length: c_int) -> c_int;
     fn msbwt_rle_sparse_table_info(bwt: *const MsbwtRle, out: *mut u64) -> c_int;
     // one batch counted and gathered as a pipeline (pieces searched while earlier pieces' counts travel over RCCL)
@@ -204,6 +205,12 @@ impl GpuRleBWT {
     }
 
     pub fn sparse_tiers(&self) -> bool { unsafe { msbwt_rle_get_sparse_tiers(self.raw) != 0 } }
+
+    /// The second, shallower sparse level (17-symbol suffixes, for k undeclared): -1 = automatic (default), 0 = never.
+    pub fn set_sparse_second(&mut self, mode: i32) {
+        let rc = unsafe { msbwt_rle_set_sparse_second(self.raw, mode) };
+        if rc != MSBWT_OK { panic!("set_sparse_second: {}", self.last_error()); }
+    }
 
     /// Depth of the sparse suffix table in HBM (0 = none) and how many distinct suffixes of that length occur.
     pub fn sparse_table(&self) -> (i32, u64) {

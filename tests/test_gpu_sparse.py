@@ -544,3 +544,40 @@ def test_run_blocks_behind_a_sparse_table(tiers, monkeypatch):
     b.set_sparse_table(0)
     assert b.get_sparse_table() == 0 and b.device_bytes() == lean.device_bytes()
     assert np.array_equal(b.count_kmers(q), ref.count_kmers(q))
+
+
+def test_second_sparse_level_serves_the_queries_the_first_is_too_deep_for(monkeypatch):
+    """k undeclared: the automatic table is up to 23 deep and serves k >= its depth; where the deep direct table is not kept beside it, a second
+    table of the 17-symbol suffixes serves 17 <= k < depth (msbwt_rle_set_sparse_second; sparse_for in csrc/kernels.hpp).  Counts never change."""
+    reads = read_set(61, 2_000_000, 400_000, 100, repeats=20, err=0.004)
+    rle = synth_bwt(reads)
+    # (an explicit direct-table depth: the loader then does not consider keeping the deep direct table, as it would on an index this small)
+    b, ref = load_pair(rle, monkeypatch, "auto", MSBWT_TABLE_DEPTH=9)
+    info = b.sparse_table_info()
+    assert info["depth"] >= 19 and info["second_depth"] == 17 and info["second_bytes"] > 0 and b.get_query_length() == 0, info
+    with_second = b.device_bytes()
+    exp, qs = {}, {}
+    for k in (12, 16, 17, 18, info["depth"] - 1, info["depth"], 31, 40):
+        windows = np.lib.stride_tricks.sliding_window_view(reads[:2000], k, axis=1).reshape(-1, k)
+        qs[k] = np.ascontiguousarray(np.concatenate([windows[::5], random_kmers(k, 4000, k)]))
+        exp[k] = ref.count_kmers(qs[k])
+        b.set_search_counters(True)
+        got = b.count_kmers(qs[k])
+        cnt = b.search_counters(0)
+        b.set_search_counters(False)
+        assert np.array_equal(got, exp[k]), k
+        assert (cnt["table_steps"] > 0) == (k >= 17), (k, cnt)      # looked up in one of the two sparse tables, or in the direct table
+    # a declared k gets no second level; switched off it goes; automatic again it comes back
+    b.set_query_length(31)
+    assert b.sparse_table_info()["second_depth"] == 0
+    b.set_query_length(0)
+    assert b.sparse_table_info()["second_depth"] == 17 and b.device_bytes() == with_second
+    b.set_sparse_second(0)
+    info0 = b.sparse_table_info()
+    assert info0["second_depth"] == 0 and info0["depth"] == info["depth"] and b.device_bytes() == with_second - info["second_bytes"]
+    for k, q in qs.items():
+        assert np.array_equal(b.count_kmers(q), exp[k]), k
+    b.set_sparse_second(-1)
+    assert b.sparse_table_info()["second_depth"] == 17
+    twin = b.replicate(b.device_ordinal())
+    assert twin.sparse_table_info()["second_depth"] == 17 and np.array_equal(twin.count_kmers(qs[18]), exp[18])
