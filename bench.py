@@ -25,8 +25,10 @@ Other workloads: c2, c3 (--fused = configs[2]), c4, big.  --genome repeats: the 
 
 --gpus N: one rank per GPU.  Launched plainly (no torchrun) the script starts torch.distributed.run
 itself as a child process and relays its JSON line.  The index is replicated; ONE fixed batch is
-sharded across the ranks (strong scaling, BASELINE configs[3]'s shape) and every rank ends each step
-holding all counts after one RCCL all_gather.  The weak-scaling figure (every rank the whole batch) is
+sharded across the ranks (strong scaling, BASELINE configs[3]'s shape) and each step ends with the final
+gather of the counts to rank 0 over RCCL (--exchange gather, the default since round 6: the root receives every
+shard over that rank's own xGMI link at once) or with an all_gather after which every rank holds all counts
+(--exchange allgather, rounds 1-5).  The weak-scaling figure (every rank the whole batch) is
 reported in the extra key `weak_scaling`; `ranks` carries per-rank kernel and exchange times;
 `native_gather` repeats the measurement with the library's own RCCL call (msbwt_rle_allgather_counts).
 
@@ -157,6 +159,9 @@ def parse_args(argv=None):
                     help="random queries: generate the batch in HBM (torch PRNG) instead of uploading it")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N>1: strong = one fixed batch sharded over the ranks (default), weak = every rank the whole batch")
+    ap.add_argument("--exchange", default="gather", choices=["gather", "allgather"],
+                    help="N > 1: the step's exchange -- `gather`: the final gather of the counts to rank 0 (what the north-star names; the root receives "
+                         "every other rank's shard over its own xGMI link at once); `allgather`: every rank ends each step holding ALL counts (rounds 1-5)")
     ap.add_argument("--payload", default="auto", choices=["auto", "int64"],
                     help="N>1: auto = int16 counts on the wire when exact (falls back to int64), int64 = always wide")
     ap.add_argument("--sort-queries", action="store_true",
@@ -779,16 +784,19 @@ def main():
                 batch.bwt.allgather_counts(native, outs[i & 1].data_ptr(), per_rank, d_all.data_ptr(), 16 if narrow else 64, stream)
             return outs[(nsteps - 1) & 1], d_all, False  # (an overflow shows up in device_status)
         pay_dtype = torch.int16 if narrow else torch.int64
+        to_root = args.exchange == "gather"
+        have_all = (not to_root) or rank == 0     # who ends a step holding every rank's counts
         sends = [torch.zeros(per_rank, dtype=pay_dtype, device=dev) for _ in range(2)]
-        recvs = [torch.empty(per_rank * world, dtype=pay_dtype, device=dev) for _ in range(2)]
-        d_all = torch.empty(per_rank * world, dtype=torch.int64, device=dev)
+        recvs = [torch.empty(per_rank * world, dtype=pay_dtype, device=dev) if have_all else None for _ in range(2)]
+        d_all = torch.empty(per_rank * world, dtype=torch.int64, device=dev) if have_all else None
         overflow = torch.zeros((), dtype=torch.bool, device=dev)
         works = [None, None]
 
         def finish(j):  # widen what slot j received (the collective is done once wait() returns)
             if works[j] is not None:
                 works[j].wait()
-                d_all.copy_(recvs[j])
+                if have_all:
+                    d_all.copy_(recvs[j])
                 works[j] = None
 
         for i in range(nsteps):
@@ -801,10 +809,21 @@ def main():
                 overflow |= (mx > NARROW_MAX) | (mn < 0)
             sends[j].copy_(outs[j])
             # the payload crosses as raw bytes: neither NCCL/RCCL nor gloo has a 16-bit integer type
-            if args.dist_backend == "nccl":
+            if args.dist_backend == "nccl" and to_root:
+                # the final gather of the counts: rank 0 receives every shard over that rank's own link (grouped send / recv inside RCCL)
+                chunks = [recvs[j][r * per_rank:(r + 1) * per_rank].view(torch.uint8) for r in range(world)] if rank == 0 else None
+                works[j] = dist.gather(sends[j].view(torch.uint8), gather_list=chunks, dst=0, async_op=True)
+            elif args.dist_backend == "nccl":
                 works[j] = dist.all_gather_into_tensor(recvs[j].view(torch.uint8), sends[j].view(torch.uint8),
                                                        async_op=True)  # RCCL over xGMI
-            else:  # rehearsal: same logic, collective through host memory
+            elif to_root:  # rehearsal: same logic, collective through host memory
+                host_send = sends[j].cpu().view(torch.uint8)
+                host_chunks = [torch.empty_like(host_send) for _ in range(world)] if rank == 0 else None
+                dist.gather(host_send, gather_list=host_chunks, dst=0)
+                if rank == 0:
+                    recvs[j].copy_(torch.cat(host_chunks).view(pay_dtype))
+                    d_all.copy_(recvs[j])
+            else:
                 host = torch.empty(per_rank * world, dtype=pay_dtype)
                 dist.all_gather_into_tensor(host.view(torch.uint8), sends[j].cpu().view(torch.uint8))
                 recvs[j].copy_(host)
@@ -886,6 +905,8 @@ def main():
         """the whole batch's counts as one vector (strong: stitched from the gathered shards)"""
         if not strong:
             return d_out
+        if d_all is None:   # (gather to the root: only rank 0 holds the whole batch's counts)
+            return None
         spans = [msbwt.sharded.shard_bounds(n_all, world, r) for r in range(world)]
         return torch.cat([d_all[r * cap:r * cap + (b - a)] for r, (a, b) in enumerate(spans)])
 
@@ -929,8 +950,18 @@ def main():
     # cross-rank consistency: a failed check does not abort the run (a crashed rank leaves no record at all); it is
     # reported in the JSON line and voids `value`
     inconsistent = []
-    if multi and not torch.equal(d_all[rank * cap:rank * cap + mine_n], d_out[:mine_n]):  # the gathered vector must contain this rank's own counts where they belong
+    if multi and d_all is not None and not torch.equal(d_all[rank * cap:rank * cap + mine_n], d_out[:mine_n]):  # the gathered vector must contain this rank's own counts where they belong
         inconsistent.append("rank %d: gathered counts differ from the local ones" % rank)
+    if multi and args.exchange == "gather":
+        # gather to the root: every rank reports the sum and the length of its shard's counts (exact in float64: below 2^53), the root compares
+        # them with what it received from that rank
+        reported = gather_floats([float(d_out[:mine_n].sum().item()), float(mine_n)])
+        if rank == 0:
+            for r, (shard_sum, shard_len) in enumerate(reported):
+                a_r, b_r = msbwt.sharded.shard_bounds(nq, world, r) if strong else (0, nq)
+                got_sum = float(d_all[r * cap:r * cap + (b_r - a_r)].sum().item())
+                if int(shard_len) != b_r - a_r or got_sum != shard_sum:
+                    inconsistent.append("root: the counts received from rank %d sum to %.0f over %d queries, that rank reports %.0f over %d" % (r, got_sum, b_r - a_r, shard_sum, int(shard_len)))
     ms_per_step = elapsed / args.steps * 1e3
     counters = None
     if args.counters and not multi:
@@ -954,7 +985,7 @@ def main():
         ranks_info = {"kernel_ms": [p[0] for p in per], "kernel_ms_min": min(p[0] for p in per), "kernel_ms_max": max(p[0] for p in per),
                       "exchange_ms_alone": max(p[1] for p in per), "step_ms": ms_per_step,
                       "step_minus_slowest_kernel_ms": ms_per_step - max(p[0] for p in per),
-                      "note": "kernel_ms: average count-kernel duration per rank; exchange_ms_alone: narrow + all_gather + widen of one step "
+                      "note": "kernel_ms: average count-kernel duration per rank; exchange_ms_alone: narrow + gather (or all_gather) + widen of one step "
                               "with no kernel running (max over ranks); inside a step the exchange overlaps the next step's kernel"}
 
     # the same batch handed over in the order of its batch-order keys (include/msbwt_hip.h, "batch order"): what a caller
@@ -983,9 +1014,11 @@ def main():
         was_strong, strong = strong, False
         w_out, w_all, w_elapsed, _, _, w_narrow = measure(main_batch, 0, nw, nw)
         strong = was_strong
-        if not torch.equal(w_all[rank * nw:(rank + 1) * nw], w_out):
-            inconsistent.append("rank %d: weak-scaling gather differs from the local counts" % rank)
-        if not torch.equal(w_out, d_counts[:nw]):  # (also what would show if the replicas of the index differed between ranks)
+        if w_all is not None:   # every rank counted the SAME queries: each received block must equal this rank's own counts
+            for r in range(world):
+                if not torch.equal(w_all[r * nw:(r + 1) * nw], w_out):
+                    inconsistent.append("rank %d: the weak-scaling counts of rank %d differ from the local ones" % (rank, r))
+        if d_counts is not None and not torch.equal(w_out, d_counts[:nw]):  # (also what would show if the replicas of the index differed between ranks)
             inconsistent.append("rank %d: sharded counts differ from this GPU's own counts of the same queries" % rank)
         weak = {"value": nw * world * args.steps / w_elapsed, "unit": "queries/s", "ms_per_step": w_elapsed / args.steps * 1e3,
                 "queries_per_gpu": nw, "payload": "int16" if w_narrow else "int64",
@@ -1023,7 +1056,9 @@ def main():
                 raise RuntimeError("communicator set-up failed or timed out on some rank: %s" % box.get("error", "no answer within 120 s"))
             comm = box["comm"]
             n_out, n_all, n_elapsed, n_kms, _, n_narrow = measure(main_batch, lo, hi, cap, native=comm)
-            same = bool(torch.equal(n_all, d_all))
+            # (the library's own call is an all-gather: every rank holds n_all; with --exchange gather only the root holds the torch path's vector)
+            same = bool(torch.equal(n_all, d_all)) if d_all is not None else bool(torch.equal(n_all[rank * cap:rank * cap + mine_n], d_out[:mine_n]))
+            ref_all = d_all if d_all is not None else n_all.clone()
             native = {"value": nq * args.steps / n_elapsed, "unit": "queries/s", "ms_per_step": n_elapsed / args.steps * 1e3,
                       "kernel_ms": n_kms, "payload": "uint16" if n_narrow else "uint64", "equals_torch_path": same,
                       "note": "msbwt_rle_allgather_counts (ncclAllGather bound at run time inside libmsbwt_hip.so), in stream order "
@@ -1060,9 +1095,9 @@ def main():
 
                     native["single_batch_latency_ms"] = latency(serial)
                     native["single_batch_pipelined_ms"] = latency(lambda: bwt.count_kmers_allgather_device(comm, qptr, k, cap, d_m.data_ptr(), d_a.data_ptr(), wire, 64, 4, stream))
-                    native["single_batch_pipelined_equals_torch_path"] = bool(torch.equal(d_a, d_all))
+                    native["single_batch_pipelined_equals_torch_path"] = bool(torch.equal(d_a, ref_all))
                     native["single_batch_pipelined_narrow_destination_ms"] = latency(lambda: bwt.count_kmers_allgather_device(comm, qptr, k, cap, d_m.data_ptr(), d_n.data_ptr(), wire, wire, 4, stream))
-                    native["single_batch_narrow_destination_equals_torch_path"] = bool(torch.equal(d_n.to(torch.int64), d_all))
+                    native["single_batch_narrow_destination_equals_torch_path"] = bool(torch.equal(d_n.to(torch.int64), ref_all))
                     bwt.device_status(stream)
                     native["single_batch_note"] = ("one batch, not a stream of them: kernel, all-gather and widening in stream order (single_batch_latency_ms) against the "
                                                    "shard counted in 4 pieces while the finished pieces' counts travel on a second stream "
@@ -1121,10 +1156,11 @@ def main():
             "sparse_table": {kk: vv for kk, vv in bwt.sparse_table_info().items() if kk != "wide"}, "query_length_hint": bwt.get_query_length(),
             "pair_index": bwt.get_pair_index(), "pair_stride": bwt.get_pair_stride(),
             "typical_range_width": bwt.get_typical_range_width(), "block_format": bwt.get_block_format(),
-            "parallelism": ("index replicated x%d; %s; per step one %s all_gather of all counts (%s payload, widened to u64 on "
+            "parallelism": ("index replicated x%d; %s; per step one %s %s of all counts (%s payload, widened to u64 on "
                             "arrival), overlapped with the next step's kernel"
                             % (world, "ONE fixed batch sharded over the ranks" if strong else "every rank its own whole batch",
                                "RCCL" if args.dist_backend == "nccl" else "gloo (rehearsal)",
+                               "gather to rank 0" if args.exchange == "gather" else "all_gather",
                                "int16" if narrow else "int64")) if multi else "1 GPU",
         },
     }

@@ -160,7 +160,7 @@ def test_bench_two_ranks_rehearsal(payload):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
            "--workload", "c2", "--scale", "0.003", "--steps", "3", "--warmup", "1", "--parity-sample", "5000", "--payload", payload,
-           "--scaling", "weak"]
+           "--scaling", "weak", "--exchange", "gather" if payload == "auto" else "allgather"]   # (both forms of the step's exchange)
     extras = os.path.join(ROOT, "gpurun_out", "bench_extras_test_ranks_%d_%s.json" % (os.getpid(), payload))
     os.makedirs(os.path.dirname(extras), exist_ok=True)
     out = subprocess.run(cmd + ["--extras-file", extras], capture_output=True, text=True, timeout=900, cwd=ROOT)
@@ -172,6 +172,7 @@ def test_bench_two_ranks_rehearsal(payload):
     assert "cpu_baseline" not in r            # reported at N=1 only
     assert r["value"] > 0 and "x2" in r["config"]["parallelism"]
     assert ("int16" if payload == "auto" else "int64") in r["config"]["parallelism"]
+    assert ("gather to rank 0" if payload == "auto" else "all_gather") in r["config"]["parallelism"]
 
 
 @pytest.mark.parametrize("payload", ["auto", "int64"])
@@ -189,7 +190,8 @@ def test_bench_rccl_calls_on_one_rank(payload):
     extras = os.path.join(ROOT, "gpurun_out", "bench_extras_test_rccl_%d_%s.json" % (os.getpid(), payload))
     os.makedirs(os.path.dirname(extras), exist_ok=True)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--dist-backend", "nccl", "--scale", "0.00003",
-                          "--steps", "4", "--warmup", "1", "--parity-sample", "5000", "--payload", payload, "--no-c5", "--extras-file", extras],
+                          "--steps", "4", "--warmup", "1", "--parity-sample", "5000", "--payload", payload, "--no-c5", "--extras-file", extras,
+                          "--exchange", "gather" if payload == "auto" else "allgather"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     compact, r = check_compact_line(out.stdout, extras)   # (stdout carries the JSON line only: RCCL's banner belongs on stderr)
