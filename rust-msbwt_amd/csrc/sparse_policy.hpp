@@ -52,9 +52,15 @@ inline uint64_t sparse_tier_min_buckets(int depth) {
     return ((uint64_t(1) << 32) + per_top - 1) / per_top;
 }
 
+// Entries per bucket the two-tier form aims for: 5.8 of its 10 slots (5.0 of 9 with 32-bit tags), NOT the complete table's 64 % -- a bucket of 10
+// overflows relatively more often than one of 14, and at 6.4 per bucket the chains of over-subscribed buckets grow past the probe limit of 15
+// somewhere in a table of 5e8 buckets (round 6: the human-scale fill failed once and was retried with a quarter more buckets, 74 GB instead of
+// 60; a simulation of the cascade gives runs of 12 in 3e6 buckets at 6.43, of 8 at 5.8, of 7 for the complete table's 9 of 14).
+inline double sparse_tier_load(int depth) { return sparse_wide(uint32_t(depth)) ? 5.0 : 5.8; }
+
 // buckets of the two-tier form: `solid` entries at its load, room in the filters for `singles` suffixes that occur once, what its tags allow
 inline uint64_t sparse_tier_buckets(int depth, uint64_t solid, uint64_t singles) {
-    const uint64_t by_entries = uint64_t(double(solid) / sparse_load(depth, true)) + 1;
+    const uint64_t by_entries = uint64_t(double(solid) / sparse_tier_load(depth)) + 1;
     const uint64_t by_filter = uint64_t(double(singles) / kTierMaxSinglesPerBucket) + 1;
     return std::max(std::max(by_entries, by_filter), sparse_tier_min_buckets(depth));
 }
@@ -71,7 +77,7 @@ inline SparseChoice choose_sparse_depth(const uint64_t *distinct, const uint64_t
             // (tiers = 1 asks for the two-tier form wherever it exists: depths 30..31 have none and stay complete)
             if (tier ? (tiers == 0 || singles == nullptr || d > kTierMaxDepth) : (tiers == 1 && singles != nullptr && d <= kTierMaxDepth)) continue;
             const uint64_t single = tier ? std::min(singles[d], distinct[d]) : 0, entries = distinct[d] - single;
-            const uint64_t needed = uint64_t(double(entries) / sparse_load(d, tier != 0)) + 1;
+            const uint64_t needed = uint64_t(double(entries) / (tier ? sparse_tier_load(d) : sparse_load(d))) + 1;
             const uint64_t nb = tier ? sparse_tier_buckets(d, entries, single) : sparse_buckets_for(d, distinct[d]);
             const uint64_t least = tier ? sparse_tier_min_buckets(d) : sparse_min_buckets(d);
             const uint64_t lines = nb + kSparseMaxProbe;

@@ -613,11 +613,11 @@ def test_two_tier_sparse_table_is_chosen_where_the_complete_one_does_not_fit():
     noisy = {13: 67108864, 15: 1.07e9, 17: 9.0e9, 19: 1.05e10, 21: 1.17e10, 23: 1.29e10}
     once = {13: 0, 15: 2.0e7, 17: 6.2e9, 19: 7.5e9, 21: 8.7e9, 23: 9.9e9}
     depth, tier, nbytes = choose(noisy, once, 120 * GB)
-    assert (depth, tier) == (23, 1) and 55 * GB < nbytes < 65 * GB          # 3.0e9 entries at 6.4 per 128-byte bucket
+    assert (depth, tier) == (23, 1) and 62 * GB < nbytes < 68 * GB          # 3.0e9 entries at 5.8 per 128-byte bucket
     assert choose(noisy, once, 200 * GB)[:2] == (23, 0)                       # the complete table where it fits (185 GB)
     assert choose(noisy, once, 120 * GB, tiers=0)[0] == 0                     # complete tables only: nothing fits
     assert choose(noisy, once, 200 * GB, tiers=1)[:2] == (23, 1)
-    assert choose(noisy, once, 50 * GB)[0] == 0                               # not even the two-tier form of any depth: the deep direct table
+    assert choose(noisy, once, 55 * GB)[0] == 0                               # not even the two-tier form of any depth: the deep direct table
     # a chr20-sized read set with errors (config C4 as the device builder counted it): the complete depth-23 table sits at the 2^25 buckets its
     # 24-bit tags demand (4.3 GB), depth 21's needs 3.3 GB; the two-tier form of depth 23 holds a third of the entries, gets by with a probe
     # limit of 3 and half the buckets -- 2^24, 2.1 GB -- so a budget of 2.6 GB for the table keeps depth 23
@@ -626,7 +626,7 @@ def test_two_tier_sparse_table_is_chosen_where_the_complete_one_does_not_fit():
     depth, tier, nbytes = choose(c4, c4_once, 2.6 * GB)
     assert (depth, tier) == (23, 1) and 2.1 * GB < nbytes < 2.2 * GB
     assert choose(c4, c4_once, 200 * GB)[:2] == (23, 0) and choose(c4, c4_once, 2.6 * GB, tiers=0)[0] < 21
-    assert choose(c4, c4_once, 1.5 * GB)[:2] == (21, 1)                       # 6.7e7 entries at 6.4 per bucket: 1.35 GB
+    assert choose(c4, c4_once, 1.6 * GB)[:2] == (21, 1)                       # 6.7e7 entries at 5.8 per bucket: 1.49 GB
     # the filter's load bounds the table from below: 32 once-only suffixes per bucket at most
     few_solid = {13: 1000, 15: 10**6, 17: 10**9, 19: 2 * 10**9}
     few_once = {17: 10**9 - 10**6, 19: 2 * 10**9 - 10**6}
@@ -642,8 +642,8 @@ def test_two_tier_sparse_table_is_chosen_where_the_complete_one_does_not_fit():
     deep_once.update({25: 1.11e10, 27: 1.23e10, 29: 1.35e10, 31: 1.47e10})
     depth, tier, nbytes = choose(deep, deep_once, 120 * GB, query_length=31)
     assert (depth, tier) == (29, 1) and nbytes <= 120 * GB
-    assert choose(deep, deep_once, 70 * GB, query_length=31)[:2] == (29, 1)   # 5.76 entries per bucket: 66.7 GB + its slot counters (its tags would allow 2^28 buckets)
-    assert choose(deep, deep_once, 64 * GB, query_length=31)[:2] == (23, 1)   # 5.76 entries per bucket at depths 25..29, 6.4 up to 24
+    assert choose(deep, deep_once, 80 * GB, query_length=31)[:2] == (29, 1)   # 5.0 entries per bucket: 76.8 GB + its slot counters (its tags would allow 2^28 buckets)
+    assert choose(deep, deep_once, 70 * GB, query_length=31)[:2] == (23, 1)   # 5.0 entries per bucket at depths 25..29, 5.8 up to 24: 66.2 GB
     # the filter as a pure function: a word 0..7 and at most four bits, the same for the same tag
     word, mask, w2, m2 = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
     seen = set()
