@@ -62,8 +62,8 @@
 //     bytes 90..91   header (entries that wanted this bucket; > 10 = some were displaced)
 //     words 23..30   the filter: key -> one word (3 hash bits) and 4 bits in it (4 x 5 hash bits)
 // and with 32-bit tags (depths 25..29): 9 entries -- tags in words 0..8, l_lo in words 9..17, l_hi in bytes 72..80, widths in bytes
-// 81..89, header and filter as above.  Size: solid / 6.4 (5.76) buckets, at least singles / 32 (the filter's load): the 30x human
-// read set with errors keeps depth 23 in about 60 GB.
+// 81..89, header and filter as above.  Size: solid / 5.8 (5.0) buckets, at least singles / 32 (the filter's load): the 30x human
+// read set with errors keeps depth 23 in about 66 GB (5.8 entries per bucket: sparse_policy.hpp, sparse_tier_load).
 #pragma once
 #include <cstdint>
 

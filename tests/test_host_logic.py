@@ -595,7 +595,7 @@ def test_automatic_sparse_depth_follows_the_distinct_counts():
 def test_two_tier_sparse_table_is_chosen_where_the_complete_one_does_not_fit():
     """csrc/sparse_policy.hpp through msbwt_auto_sparse_choice (no device).  A 30x human read set WITH 0.5 % substitutions counts about 1.3e10
     distinct 23-mers of which the genome's 3e9 occur more than once: the complete depth-23 table needs 185 GB, the two-tier one
-    -- entries for the suffixes that occur at least twice, filter bits for the rest -- about 60 GB, so with 120 GB free the two-tier form of
+    -- entries for the suffixes that occur at least twice, filter bits for the rest -- about 66 GB, so with 120 GB free the two-tier form of
     depth 23 is what the loader builds; where the complete table fits it is preferred; tiers = 0 / 1 force either form."""
     def choose(distinct, once, avail, parent=13, tiers=-1, query_length=0, wide=None):
         d, w, o = (C.c_uint64 * 32)(), (C.c_uint64 * 32)(), (C.c_uint64 * 32)()
